@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = sys.argv[:1]          # vpho_amd.configs.args parses sys.argv at import, like the reference's lib/configs/args.py
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def assets():
+    from vpho_amd.assets import synthetic_assets
+    return synthetic_assets(0)
+
+
+@pytest.fixture(scope='session')
+def model_cpu(assets):
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_state_dict
+    m = vpho_net(assets)
+    m.load_state_dict(synth_state_dict(m, seed=1))
+    return m.eval()
+
+
+@pytest.fixture(scope='session')
+def sd(model_cpu):
+    return {k: v.clone() for k, v in model_cpu.state_dict().items()}

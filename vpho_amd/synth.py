@@ -1,0 +1,114 @@
+"""Seeded synthetic weights and input batches for benchmarks, smoke and parity tests.
+
+The reference's own ``init_weights`` (VPHO.py:34-45) zero-initialises the score heads (score == 0), which would not
+exercise the sampler, so synthetic runs use Kaiming-scaled weights with non-zero score output layers (sigma 0.02) and
+randomised BatchNorm statistics.  Every tensor is generated from ``crc32(key) ^ seed`` so the values do not depend on
+module construction order.
+"""
+import zlib
+import numpy as np
+import torch
+
+from .assets import YCB_NAMES
+
+
+def _rng(key, seed):
+    return np.random.default_rng((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
+
+
+def synth_state_dict(model, seed=0):
+    """Return a new state_dict for ``model`` (a vpho_net or any sub-module) with seeded values."""
+    sd = model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        r = _rng(k, seed)
+        shp = tuple(v.shape)
+        if k.startswith(('head_obj.', 'head_mano.mano_layer.')) or k.endswith(('pose_embedder.pe', 'head_physics.anchor', '.anchor', '.pe')):
+            out[k] = v.clone()
+            continue
+        if k.endswith('num_batches_tracked'):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith('running_mean'):
+            out[k] = torch.from_numpy(r.normal(0, 0.1, shp).astype(np.float32))
+        elif k.endswith('running_var'):
+            out[k] = torch.from_numpy(r.uniform(0.5, 1.5, shp).astype(np.float32))
+        elif k.endswith('t_encoder.0.W'):
+            out[k] = torch.from_numpy((r.normal(0, 1, shp) * 30.0).astype(np.float32))
+        elif ('.bn' in k or '.norm' in k or 'downsample.1' in k or k.endswith(('layer0_h.1.weight', 'layer0_h.1.bias'))
+              or 'conv_layers.2.' in k or 'deconv_layers.1.' in k) and len(shp) == 1:
+            if k.endswith('weight'):
+                lo, hi = (0.15, 0.35) if ('.bn3.' in k) else ((0.4, 0.7) if 'downsample.1' in k else (0.7, 1.3))
+                out[k] = torch.from_numpy(r.uniform(lo, hi, shp).astype(np.float32))
+            else:
+                out[k] = torch.from_numpy(r.normal(0, 0.1, shp).astype(np.float32))
+        elif k.endswith('final_layer.bias'):                  # positive heat-maps (well-conditioned top-k weights)
+            out[k] = torch.from_numpy(r.uniform(0.4, 0.6, shp).astype(np.float32))
+        elif k.endswith('bias'):
+            out[k] = torch.from_numpy(r.normal(0, 0.05, shp).astype(np.float32))
+        elif 'head.head.2.weight' in k:
+            out[k] = torch.from_numpy(r.normal(0, 0.02, shp).astype(np.float32))
+        elif 'head.head.0.weight' in k:                       # ParallelLinear (n, in, out)
+            out[k] = torch.from_numpy(r.normal(0, np.sqrt(2.0 / shp[1]), shp).astype(np.float32))
+        elif len(shp) == 4 and 'deconv' in k:                 # ConvTranspose (cin, cout, kh, kw)
+            out[k] = torch.from_numpy(r.normal(0, np.sqrt(2.0 / (shp[0] * 4)), shp).astype(np.float32))
+        elif len(shp) >= 2:                                   # conv (cout,cin,kh,kw) / linear (out,in)
+            fan_in = int(np.prod(shp[1:]))
+            gain = 2.0
+            if '.conv3.' in k and k.startswith('encoder_'):   # un-normalised residual branch of encoding.Residual
+                gain = 0.1
+            elif k.startswith(('feature_extractor.toplayer', 'feature_extractor.latlayer', 'feature_extractor.smooth')):
+                gain = 0.02
+            elif k.startswith('encoder_') and '.project.' in k:
+                gain = 0.25
+            elif 'final_layer' in k:
+                gain = 0.002
+            elif 'fc_shape' in k or 'fc_pose' in k:
+                gain = 0.5
+            out[k] = torch.from_numpy(r.normal(0, np.sqrt(gain / fan_in), shp).astype(np.float32))
+        else:
+            out[k] = torch.from_numpy(r.normal(0, 0.1, shp).astype(np.float32))
+    return out
+
+
+def synth_batch(bs, assets, seed=206, rank=0, patch=256):
+    """Synthetic batch dict with the schema ``vpho_net.forward`` consumes."""
+    r = np.random.default_rng(seed + 1000003 * rank)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    root = np.stack([r.uniform(-0.1, 0.1, bs), r.uniform(-0.1, 0.1, bs), r.uniform(0.6, 0.9, bs)], -1)
+    foc = r.uniform(400, 600, bs) * 1.2
+    Kmat = np.zeros((bs, 3, 3))
+    Kmat[:, 0, 0] = foc
+    Kmat[:, 1, 1] = foc
+    Kmat[:, 2, 2] = 1
+    # principal point such that the hand root projects near the crop centre
+    Kmat[:, 0, 2] = patch / 2 - foc * root[:, 0] / root[:, 2]
+    Kmat[:, 1, 2] = patch / 2 - foc * root[:, 1] / root[:, 2]
+    half = foc * 0.11 / root[:, 2]                                    # ~hand half-extent in pixels
+    ctr = patch / 2 + r.uniform(-6, 6, size=(bs, 2))
+    hw = half[:, None] * r.uniform(0.75, 1.15, size=(bs, 2))
+    bbox_hand = np.clip(np.concatenate([ctr - hw, ctr + hw], -1), 0, patch)
+    octr = ctr + r.uniform(-25, 25, size=(bs, 2))
+    ohw = half[:, None] * r.uniform(0.6, 1.1, size=(bs, 2))
+    bbox_obj = np.clip(np.concatenate([octr - ohw, octr + ohw], -1), 0, patch)
+
+    def rect(b):
+        c = (b[:, :2] + b[:, 2:]) / 2
+        m = (b[:, 2:] - b[:, :2]).max(-1, keepdims=True)
+        return np.concatenate([c - m / 2, c + m / 2], -1)
+
+    is_right = r.random(bs) < 0.5
+    g = r.normal(size=(bs, 1, 3))
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    root_unflip = root.copy()
+    root_unflip[~is_right, 0] *= -1
+    return {
+        'rgb': f32(r.normal(size=(bs, 3, patch, patch))),
+        'bbox_hand': f32(bbox_hand), 'bbox_obj': f32(bbox_obj),
+        'bbox_hand_rect': f32(rect(bbox_hand)), 'bbox_obj_rect': f32(rect(bbox_obj)),
+        'is_right': torch.from_numpy(is_right), 'is_ho3d': torch.zeros(bs, dtype=torch.bool),
+        'is_grasped': torch.from_numpy(r.random(bs) < 0.8),
+        'gravity': f32(g), 'obj_CoM': f32(r.normal(0, 0.05, size=(bs, 1, 3))),
+        'root_joint_flip': f32(root), 'root_joint': f32(root_unflip),
+        'cam_intr_crop_flip': f32(Kmat),
+        'obj_name': [YCB_NAMES[i] for i in r.integers(0, len(YCB_NAMES), bs)],
+    }
