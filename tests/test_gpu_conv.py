@@ -1,0 +1,99 @@
+"""conv_igemm (fp32 MFMA implicit GEMM) against torch CPU fp32 convolutions.  Tolerance: fp32 accumulation-order
+differences only -> 2e-5 relative to the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(size=shape) * scale).astype(np.float32))
+
+
+def _close(got, ref, tol=2e-5):
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), f'max abs err {err:.3e} vs scale {ref.abs().max().item():.3e}'
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (2, 16, 16, 64, 128, 3, 1, 1),
+    (3, 17, 13, 32, 21, 3, 2, 1),        # odd sizes, Cout tail, small tile
+    (1, 32, 32, 4, 64, 7, 2, 3),         # stem: Cin padded 3->4, K=196 (K tail)
+    (8, 32, 32, 128, 256, 3, 1, 1),      # big-tile path (>=192 tiles of 128x128)
+    (4, 64, 64, 256, 128, 1, 1, 0),      # big-tile, 1x1
+    (5, 9, 9, 280, 256, 1, 1, 0),        # Cin not multiple of 32
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_matches_torch(case):
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    N, H, W, Cin, Cout, k, st, pad = case
+    x = _rand((N, Cin, H, W), 1)
+    w = _rand((Cout, Cin, k, k), 2, (2.0 / (Cin * k * k)) ** 0.5)
+    b = _rand((Cout,), 3)
+    ref = F.conv2d(x, w, b, st, pad)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda(), kh=k, kw=k, stride=st, pad=pad)
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_epilogue_residual_lrelu_and_prologue_affine():
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    N, H, W, Cin, Cout = 2, 16, 16, 128, 256
+    x, w, b = _rand((N, Cin, H, W), 4), _rand((Cout, Cin, 1, 1), 5, 0.1), _rand((Cout,), 6)
+    res = _rand((N, Cout, H, W), 7)
+    sc, sh = _rand((Cin,), 8).abs() + 0.5, _rand((Cin,), 9)
+    pre = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.01)
+    ref = F.leaky_relu(F.conv2d(pre, w, b) + res, 0.01)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda(),
+                        res=res.permute(0, 2, 3, 1).contiguous().cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                        in_slope=0.01, out_slope=0.01)
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_prologue_affine_pads_with_zero_after_activation():
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    x, w = _rand((1, 8, 6, 6), 10), _rand((16, 8, 3, 3), 11, 0.2)
+    sc, sh = _rand((8,), 12).abs() + 0.5, _rand((8,), 13) + 1.0
+    pre = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    ref = F.conv2d(pre, w, None, 1, 1)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), None, kh=3, kw=3, pad=1,
+                        in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope=0.0)
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_transposed_conv_as_four_phase_convs():
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_deconv4x4s2
+    N, Cin, Cout, H = 2, 32, 16, 8
+    x, w = _rand((N, Cin, H, H), 14), _rand((Cin, Cout, 4, 4), 15, 0.1)
+    ref = F.conv_transpose2d(x, w, None, 2, 1)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.empty((N, 2 * H, 2 * H, Cout), device='cuda')
+    for (py, px), (wp, pady, padx) in pack_deconv4x4s2(w).items():
+        ops.conv2d_nhwc(xg, wp.cuda(), None, kh=2, kw=2, pad_y=pady, pad_x=padx, out_hw=(H, H),
+                        out_view=(y, 2 * H * 2 * H * Cout, 2 * 2 * H * Cout, 2 * Cout, (py * 2 * H + px) * Cout))
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_linear_and_small_rows():
+    from vpho_amd import ops
+    x, w, b = _rand((3, 1024), 16), _rand((96, 1024), 17, 0.03), _rand((96,), 18)
+    _close(ops.linear(x.cuda(), w.cuda(), b.cuda(), out_slope=0.01), F.leaky_relu(F.linear(x, w, b), 0.01))
+
+
+def test_bad_arguments_raise():
+    from vpho_amd import ops
+    x = torch.zeros((1, 4, 4, 6), device='cuda')
+    with pytest.raises(ops.VphoError):
+        ops.conv2d_nhwc(x, torch.zeros((8, 6), device='cuda'))           # Cin % 4 != 0
+    with pytest.raises(ops.VphoError):
+        ops.conv2d_nhwc(torch.zeros((1, 4, 4, 8)), torch.zeros((8, 8)))  # CPU tensors: no fallback

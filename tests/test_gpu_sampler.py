@@ -1,0 +1,64 @@
+"""Score network + on-device RK45 sampler (rows a10/a11 of SURVEY.md 8) against the oracle and the reference fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_blocks.npz'))
+
+
+def seeded(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(size=shape) * scale).astype(np.float32))
+
+
+@pytest.fixture(scope='module')
+def nets(sd):
+    from vpho_amd import ops
+    return {k: ops.ScoreNet(sd, f'denoiser_{k}', 'cuda') for k in ('hand', 'obj')}
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_score_matches_oracle(sd, nets, name, D):
+    from oracle import nets as N
+    bs, S = 3, 50                      # 150 rows: one full 128-row tile + a ragged one; rows share per-image features
+    feat, x = seeded((bs, 1024), 30, 0.3), seeded((bs * S, D), 31, 1.5)
+    for t in (0.65, 0.3, 1e-5):
+        ref = N.denoiser(sd, f'denoiser_{name}', feat[:, None].repeat(1, S, 1).reshape(-1, 1024), x, torch.full((bs * S, 1), t))
+        got = nets[name].score(feat.cuda(), x.cuda(), t, S).cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-5 * scale, (t, (got - ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_ode_sampler_matches_oracle_and_reference_fixture(sd, nets, name, D):
+    """Same run as the reference fixture (tests/golden/make_golden.py: 8 rows, 5 stamps, T0=0.65, seed 5)."""
+    from oracle import nets as N
+    torch.manual_seed(5)
+    init = torch.randn(8, D) * N.ve_prior_sigma(0.65)
+    feat = seeded((8, 1024), 22, 0.3)
+    xs_o, x_o, info = N.ode_sample(sd, f'denoiser_{name}', feat, init, 0.65, 5)
+    xs, x, st = nets[name].sample(feat.cuda(), init.cuda(), 1, 0.65, 5, xs_f64=True)
+    assert st['nfev'] == info['nfev'] == int(G[f'ode_{name}_nfev'])
+    assert st['nan_count'] == 0
+    # accepted/rejected sequence and step sizes follow the oracle's controller
+    assert [s[3] for s in st['steps']] == [s[3] for s in info['steps']]
+    np.testing.assert_allclose([s[1] for s in st['steps']], [s[1] for s in info['steps']], rtol=2e-4)
+    # tolerance: 1e-3 of north_star on the sampled pose, in practice ~1e-5
+    assert (xs.cpu() - xs_o).abs().max().item() < 1e-3
+    assert (x.cpu() - x_o).abs().max().item() < 1e-3
+    assert np.abs(xs.cpu().numpy() - G[f'ode_{name}_xs']).max() < 1e-3
+    assert np.abs(x.cpu().numpy() - G[f'ode_{name}_x']).max() < 1e-3
+
+
+def test_ode_sampler_ragged_rows_and_f32_trajectory(sd, nets):
+    from oracle import nets as N
+    bs, S, steps = 3, 7, 4             # 21 rows
+    feat = seeded((bs, 1024), 40, 0.3)
+    init = seeded((bs * S, 96), 41, N.ve_prior_sigma(0.4))
+    xs_o, x_o, info = N.ode_sample(sd, 'denoiser_hand', feat[:, None].repeat(1, S, 1).reshape(-1, 1024), init, 0.4, steps)
+    xs, x, st = nets['hand'].sample(feat.cuda(), init.cuda(), S, 0.4, steps, xs_f64=False)
+    assert xs.dtype == torch.float32 and st['nfev'] == info['nfev']
+    assert (xs.cpu().double() - xs_o).abs().max().item() < 1e-3
+    assert (x.cpu() - x_o).abs().max().item() < 1e-3

@@ -1,0 +1,212 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  NHWC activations make every (r,s) slice of an im2col
+// row a contiguous channel run, so the A tile is gathered with 16-byte loads; weights are pre-packed [Cout][K].
+// Block = 256 threads = 4 waves in a 2x2 arrangement; block tile BMxBN (128x128 or 64x64), BK = 32.  Both LDS tiles
+// are K-contiguous with a 4-float pad (row stride 36 floats): each lane fetches 4 consecutive k of its row with one
+// conflict-free ds_read_b128 and feeds them to 4 MFMAs (lanes 0-31 supply k = 4h+q of one half, lanes 32-63 the other;
+// A and B use the same k permutation so the sum is unchanged).  Global->register prefetch of tile k+1 overlaps the
+// MFMAs of tile k (double-buffered LDS, one barrier per K-step).  Blocks are renumbered so that the 8 round-robin
+// dispatched XCDs each walk consecutive N-tiles of the same M-tile (A tile reuse in that XCD's L2).
+//
+// Roofline: fp32 MFMA, 2*M*N*K flop per launch against 157.3 TFLOP/s.
+#include "common.h"
+#include "../../include/vpho_hip.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct Geo {
+    vpho_conv_desc d;
+    int M, K, tiles_m, tiles_n, ntiles;
+    int y_linear, r_linear;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+
+    const vpho_conv_desc& d = g.d;
+    // XCD-aware renumbering: hardware block b runs on XCD (b % 8); give each XCD a contiguous run of logical tiles
+    const int per_xcd = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= g.ntiles) return;
+    const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kq = tid & 7, lrow = tid >> 3;
+
+    // per-thread A rows (output pixels) -> input coordinates
+    int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
+    const int ohw = d.OH * d.OW;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        int m = m0 + lrow + 32 * j;
+        if (m < g.M) {
+            int n = m / ohw, rem = m - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            a_base[j] = n * d.H;
+            a_iy0[j] = oy * d.stride - d.pad_y;
+            a_ix0[j] = ox * d.stride - d.pad_x;
+        } else {
+            a_base[j] = -1; a_iy0[j] = 0; a_ix0[j] = 0;
+        }
+    }
+
+    f32x4 ra[A_LD], rb[B_LD];
+    auto load_tiles = [&](int k0) {
+        const int kg = k0 + 4 * kq;
+        const bool kin = kg < g.K;
+        int rs = 0, c = 0, r = 0, s = 0;
+        if (kin) { rs = kg / d.Cin; c = kg - rs * d.Cin; r = rs / d.KW; s = rs - r * d.KW; }
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (d.in_scale != nullptr && kin) {
+            sc = *reinterpret_cast<const f32x4*>(d.in_scale + c);
+            sh = *reinterpret_cast<const f32x4*>(d.in_shift + c);
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
+            if (kin && a_base[j] >= 0 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) {
+                const float* p = d.x + ((long long)(a_base[j] + iy) * d.W + ix) * d.x_ld + c;
+                v = *reinterpret_cast<const f32x4*>(p);
+                if (d.in_scale != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e] * sc[e] + sh[e];
+                        v[e] = t > 0.f ? t : t * d.in_slope;
+                    }
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int n = n0 + lrow + 32 * j;
+            if (kin && n < d.Cout) v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * g.K + kg);
+            rb[j] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LDS_LD;
+        float* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_LD + 4 * kq) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + 4 * kq) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
+        const float* Bs = smem + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+        if (col >= d.Cout) continue;
+        const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                long long yo, ro = 0;
+                if (g.y_linear && g.r_linear) {
+                    yo = (long long)row * d.y_sx;
+                    ro = (long long)row * d.r_sx;
+                } else {
+                    int n = row / ohw, rem = row - n * ohw;
+                    int oy = rem / d.OW, ox = rem - oy * d.OW;
+                    yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
+                    ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+                }
+                float v = acc[i][j][e] + bv;
+                if (d.res) v += d.res[ro + col];
+                v = v > 0.f ? v : v * d.out_slope;
+                d.y[yo + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
+    VPHO_REQUIRE(dp != nullptr, "vpho_conv2d_nhwc_f32: null descriptor");
+    const vpho_conv_desc& d = *dp;
+    VPHO_REQUIRE(d.x && d.w && d.y, "vpho_conv2d_nhwc_f32: null tensor");
+    VPHO_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
+                 "vpho_conv2d_nhwc_f32: non-positive dimension");
+    VPHO_REQUIRE(d.Cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_ld >= d.Cin, "vpho_conv2d_nhwc_f32: Cin=%d x_ld=%d must be multiples of 4, x_ld>=Cin", d.Cin, d.x_ld);
+    VPHO_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, "vpho_conv2d_nhwc_f32: x/w must be 16-byte aligned");
+    VPHO_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "vpho_conv2d_nhwc_f32: in_scale/in_shift must come together");
+    VPHO_REQUIRE(d.in_scale == nullptr || (((uintptr_t)d.in_scale & 15) == 0 && ((uintptr_t)d.in_shift & 15) == 0), "vpho_conv2d_nhwc_f32: in_scale/in_shift alignment");
+    VPHO_REQUIRE(d.OH > 0 && d.OW > 0, "vpho_conv2d_nhwc_f32: empty output");
+    // the last tap of the last output pixel may not start beyond the padded input by more than the pad
+    VPHO_REQUIRE((d.OH - 1) * d.stride - d.pad_y < d.H && (d.OW - 1) * d.stride - d.pad_x < d.W, "vpho_conv2d_nhwc_f32: output larger than input allows");
+    long long M = (long long)d.N * d.OH * d.OW;
+    VPHO_REQUIRE(M < (1ll << 31), "vpho_conv2d_nhwc_f32: too many output pixels");
+    Geo g;
+    g.d = d;
+    g.M = (int)M;
+    g.K = d.KH * d.KW * d.Cin;
+    g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
+    g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+    if (big_tiles >= 192 && d.Cout >= 96) {
+        g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (d.Cout + 127) / 128;
+        g.ntiles = g.tiles_m * g.tiles_n;
+        int grid = (g.ntiles + 7) / 8 * 8;
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), dim3(grid), dim3(256), 0, s, g);
+    } else {
+        g.tiles_m = (int)((M + 63) / 64); g.tiles_n = (d.Cout + 63) / 64;
+        g.ntiles = g.tiles_m * g.tiles_n;
+        int grid = (g.ntiles + 7) / 8 * 8;
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, g);
+    }
+    return vpho::check_launch("conv_igemm_kernel");
+}

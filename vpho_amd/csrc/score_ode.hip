@@ -1,0 +1,570 @@
+// Score network evaluation and the on-device Dormand-Prince RK45 probability-flow ODE sampler.
+//
+// One right-hand-side evaluation = 4 launches: time embedding (GEMV), two pose-encoder layers (conv_igemm) and the
+// fused score head `score_head_kernel`:
+//   block (row tile of 128 hypotheses, head n): H^T[256 x 128] = W1p[n] (256x256, "A") x P2^T ("B") on fp32 MFMA with the
+//   hidden unit on the accumulator ROW (registers) and the hypothesis on the COLUMN (lane), so that the second
+//   ParallelLinear (256 -> 3) is a register-local dot product followed by ONE cross-half shuffle; the (R x 8192) hidden
+//   activation never leaves the CU.  Each wave owns 32 hypotheses x all 256 hidden units (8 MFMA row tiles).
+// Roofline: fp32 MFMA; algorithmic flop per evaluation in the restructured formulation =
+//   R * (2*Dp*256 + 2*256*256 + nheads*(2*256*256 + 2*256*3)) (+ once per image 2*1024*NH, once per eval 2*128*NH).
+//
+// The RK stage algebra (fp64 state, fp32 stage derivatives exactly as numpy stores them), the error norm and the dense
+// output run as elementwise / two-pass-reduction kernels; only the 8-byte error norm crosses PCIe per attempted step.
+#include "common.h"
+#include "../../include/vpho_hip.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int HB_K = 32, HB_LD = HB_K + 4;
+constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
+
+// --------------------------------------------------------------------------------------------- time embedding
+// ct[o] = b1[o] + sum_k relu(t_b[k] + sum_i t_w[k][i] * gfp(t)[i]) * w1_t[k][o]        (denoiser.py:29-31,71-72)
+__global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weights w, float t, int NH, float* __restrict__ ct) {
+    __shared__ float emb[128], tf[128];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        // x[:, None] * W[None, :] * 2 * np.pi : three fp32 multiplications, left to right
+        float a = t * w.t_W[tid];
+        a = a * 2.0f;
+        a = a * 3.14159265358979323846f;
+        emb[tid] = sinf(a);
+        emb[tid + 64] = cosf(a);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float s = 0.f;
+        for (int i = 0; i < 128; ++i) s += w.t_w[tid * 128 + i] * emb[i];
+        s += w.t_b[tid];
+        tf[tid] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    const int o = blockIdx.x * 256 + tid;
+    if (o < NH) {
+        float s = 0.f;
+        for (int k = 0; k < 128; ++k) s += tf[k] * w.w1_t[(long long)k * NH + o];
+        ct[o] = s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------- fused score head
+struct HeadArgs {
+    const float* w1p;    // [NH][256]
+    const float* p2;     // [R][256]
+    const float* cimg;   // [bs][NH]  (feat part + b1)
+    const float* ct;     // [NH]
+    const float* w2;     // [NH][4]
+    const float* b2;     // [nheads*3]
+    float* out;          // [R][D]
+    int* nan_count;
+    int R, S, NH, D;
+    float inv_std_den;   // std + 1e-7
+    float coef;          // rhs = 0 - coef*score when rhs_mode, else score
+    int rhs_mode;
+};
+
+__global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [2][256*HB_LD] weights | [2][128*HB_LD] activations | [256][4] {ct, w2_0, w2_1, w2_2}
+    float* Wb = smem;
+    float* Pb = smem + 2 * 256 * HB_LD;
+    float* Eb = Pb + 2 * 128 * HB_LD;
+    const int n = blockIdx.y, r0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int kq = tid & 7, lrow = tid >> 3;
+    const float* Wg = a.w1p + (long long)n * 256 * 256;
+
+    {   // epilogue table
+        f32x4 e;
+        e[0] = a.ct[n * 256 + tid];
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(a.w2 + (long long)(n * 256 + tid) * 4);
+        e[1] = w2[0]; e[2] = w2[1]; e[3] = w2[2];
+        *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
+    }
+
+    f32x4 rw[8], rp[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + 32 * j) * 256 + k0 + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + lrow + 32 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < a.R) v = *reinterpret_cast<const f32x4*>(a.p2 + (long long)r * 256 + k0 + 4 * kq);
+            rp[j] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + 32 * j) * HB_LD + 4 * kq) = rw[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + 32 * j) * HB_LD + 4 * kq) = rp[j];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    constexpr int NK = 256 / HB_K;
+    for (int kt = 0; kt < NK; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < NK) load_tiles((kt + 1) * HB_K);
+        const float* As = Wb + buf * 256 * HB_LD + li * HB_LD + 4 * lh;
+        const float* Bs = Pb + buf * 128 * HB_LD + (wave * 32 + li) * HB_LD + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < HB_K / 8; ++kk) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+            f32x4 av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_LD + kk * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b[q], acc[i], 0, 0, 0);
+        }
+        if (kt + 1 < NK) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: hidden unit j = 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
+    const int row = r0 + wave * 32 + li;
+    const bool live = row < a.R;
+    const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Eb + j * 4);
+            float h = acc[i][e] + cim[j] + t[0];
+            h = h > 0.f ? h : 0.f;
+            o0 += h * t[1]; o1 += h * t[2]; o2 += h * t[3];
+        }
+    }
+    o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 32);
+    if (live && lh == 0) {
+        float o[3] = {o0 + a.b2[n * 3 + 0], o1 + a.b2[n * 3 + 1], o2 + a.b2[n * 3 + 2]};
+        int nans = 0;
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) {
+            float s = o[dd] / a.inv_std_den;
+            if (s != s) { s = 0.f; ++nans; }
+            if (a.rhs_mode) s = 0.f - a.coef * s;
+            a.out[(long long)row * a.D + n * 3 + dd] = s;
+        }
+        if (nans) atomicAdd(a.nan_count, nans);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- RK stage algebra
+struct LinComb { double c[7]; int n; double h; };
+
+// X[r][0..Dp) = (float)(y + h * sum_j c_j K_j), pad columns zero; optionally also stores the fp64 sum to ynew
+__global__ void stage_input_kernel(const double* __restrict__ y, const float* __restrict__ K, long long n_el, int D, int Dp,
+                                   LinComb lc, float* __restrict__ X, double* __restrict__ ynew) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long R = n_el / D;
+    if (i >= R * Dp) return;
+    const long long r = i / Dp;
+    const int c = (int)(i - r * Dp);
+    if (c >= D) { X[i] = 0.f; return; }
+    const long long e = r * D + c;
+    double s = 0.0;
+    for (int j = 0; j < lc.n; ++j) s += (double)K[j * n_el + e] * lc.c[j];
+    const double v = y[e] + s * lc.h;
+    X[i] = (float)v;
+    if (ynew) ynew[e] = v;
+}
+
+__global__ void f32_to_state_kernel(const float* __restrict__ x, long long n_el, int D, int Dp, double* __restrict__ y, float* __restrict__ X) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long R = n_el / D;
+    if (i >= R * Dp) return;
+    const long long r = i / Dp;
+    const int c = (int)(i - r * Dp);
+    if (c >= D) { X[i] = 0.f; return; }
+    const float v = x[r * D + c];
+    y[r * D + c] = (double)v;
+    X[i] = v;
+}
+
+// mode 0: (y/scale)^2, scale = atol+|y|rtol; 1: (Ka/scale)^2; 2: ((Kb-Ka)/scale)^2; 3: RK45 error with scale from (y, ynew)
+struct NormArgs {
+    const double* y; const double* ynew; const float* Ka; const float* Kb; const float* K; long long n_el;
+    double rtol, atol, h; double E[7]; int mode; double* partial;
+};
+__global__ __launch_bounds__(256) void norm_partial_kernel(const NormArgs a) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n_el; i += (long long)gridDim.x * 256) {
+        double v, scale;
+        if (a.mode == 3) {
+            double e = 0.0;
+            for (int j = 0; j < 7; ++j) e += (double)a.K[j * a.n_el + i] * a.E[j];
+            v = e * a.h;
+            scale = a.atol + fmax(fabs(a.y[i]), fabs(a.ynew[i])) * a.rtol;
+        } else {
+            scale = a.atol + fabs(a.y[i]) * a.rtol;
+            v = a.mode == 0 ? a.y[i] : (a.mode == 1 ? (double)a.Ka[i] : (double)a.Kb[i] - (double)a.Ka[i]);
+        }
+        const double q = v / scale;
+        s += q * q;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
+}
+__global__ void norm_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        *out = s;
+    }
+}
+
+// dense output (scipy RkDenseOutput): y_old + h * (K^T P) . [x, x^2, x^3, x^4]
+struct DenseArgs { double P[7][4]; double p[4]; double h; };
+__global__ void dense_kernel(const double* __restrict__ y_old, const float* __restrict__ K, long long n_el, int D,
+                             DenseArgs da, void* __restrict__ xs, int is_f64, int num_steps, int idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    double acc = 0.0;
+    for (int m = 0; m < 4; ++m) {
+        double q = 0.0;
+        for (int j = 0; j < 7; ++j) q += (double)K[j * n_el + i] * da.P[j][m];
+        acc += q * da.p[m];
+    }
+    const double v = da.h * acc + y_old[i];
+    const long long r = i / D;
+    const int c = (int)(i - r * D);
+    const long long o = (r * num_steps + idx) * D + c;
+    if (is_f64) reinterpret_cast<double*>(xs)[o] = v; else reinterpret_cast<float*>(xs)[o] = (float)v;
+}
+
+// x = y + (0 - g^2 * grad) * step  (fp32 product, fp64 add; score_based_model.py:95-104)
+__global__ void denoise_kernel(const double* __restrict__ y, const float* __restrict__ grad, long long n_el, float g, float step,
+                               double* __restrict__ x) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    const float drift = 0.f - (g * g) * grad[i];
+    x[i] = y[i] + (double)(drift * step);
+}
+
+// --------------------------------------------------------------------------------------------- host side
+inline long long align_up(long long v) { return (v + 255) / 256 * 256; }
+
+struct Workspace {
+    float *cimg, *ct, *X, *P1, *P2, *K, *tmp;
+    double *y, *ynew, *partial, *result;
+    int* nan_count;
+    long long bytes;
+};
+
+Workspace carve(const vpho_score_weights& w, int bs, int S, char* base) {
+    const long long R = (long long)bs * S, NH = (long long)w.nheads * 256;
+    long long off = 0;
+    Workspace ws;
+    auto take = [&](long long b) { char* p = base ? base + off : nullptr; off += align_up(b); return p; };
+    ws.cimg = (float*)take(bs * NH * 4);
+    ws.ct = (float*)take(NH * 4);
+    ws.X = (float*)take(R * w.Dp * 4);
+    ws.P1 = (float*)take(R * 256 * 4);
+    ws.P2 = (float*)take(R * 256 * 4);
+    ws.K = (float*)take(7 * R * w.D * 4);
+    ws.tmp = (float*)take(R * w.D * 4);
+    ws.y = (double*)take(R * w.D * 8);
+    ws.ynew = (double*)take(R * w.D * 8);
+    ws.partial = (double*)take(1024 * 8);
+    ws.result = (double*)take(64);
+    ws.nan_count = (int*)take(64);
+    ws.bytes = off;
+    return ws;
+}
+
+int check_weights(const vpho_score_weights* w) {
+    VPHO_REQUIRE(w != nullptr, "score weights: null");
+    VPHO_REQUIRE(w->nheads > 0 && w->D == w->nheads * 3 && w->Dp >= w->D && w->Dp % 4 == 0, "score weights: D=%d Dp=%d nheads=%d inconsistent", w->D, w->Dp, w->nheads);
+    VPHO_REQUIRE(w->t_W && w->t_w && w->t_b && w->pe0_w && w->pe0_b && w->pe2_w && w->pe2_b && w->w1_t && w->w1_p && w->w1_f && w->b1 && w->w2 && w->b2, "score weights: null tensor");
+    return 0;
+}
+
+int linear(const float* x, int rows, int cin, const float* wt, const float* bias, int cout, float slope, float* y, hipStream_t s) {
+    vpho_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = wt; d.bias = bias; d.y = y;
+    d.N = rows; d.H = 1; d.W = 1; d.Cin = cin; d.x_ld = cin; d.Cout = cout; d.KH = 1; d.KW = 1; d.stride = 1;
+    d.OH = 1; d.OW = 1; d.y_sx = cout; d.y_sy = cout; d.y_sn = cout; d.in_slope = 1.f; d.out_slope = slope;
+    return vpho_conv2d_nhwc_f32(&d, s);
+}
+
+float sigma_f32(float t) { return (float)SIGMA_MIN * powf((float)(SIGMA_MAX / SIGMA_MIN), t); }
+
+struct Ctx {
+    const vpho_score_weights* w; Workspace ws; int bs, S; long long R, n_el; int NH; hipStream_t s;
+};
+
+int prepare_cimg(Ctx& c, const float* feat_img) {
+    // cimg[img][o] = b1[o] + feat[img] . w1_f[o]
+    return linear(feat_img, c.bs, 1024, c.w->w1_f, c.w->b1, c.NH, 1.f, c.ws.cimg, c.s);
+}
+
+// X (R x Dp, fp32) -> out (R x D)
+int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out) {
+    hipLaunchKernelGGL(time_embed_kernel, dim3((c.NH + 255) / 256), dim3(256), 0, c.s, *c.w, t, c.NH, c.ws.ct);
+    if (int e = vpho::check_launch("time_embed_kernel")) return e;
+    if (int e = linear(X, (int)c.R, c.w->Dp, c.w->pe0_w, c.w->pe0_b, 256, 0.f, c.ws.P1, c.s)) return e;
+    if (int e = linear(c.ws.P1, (int)c.R, 256, c.w->pe2_w, c.w->pe2_b, 256, 0.f, c.ws.P2, c.s)) return e;
+    HeadArgs a;
+    a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct; a.w2 = c.w->w2; a.b2 = c.w->b2;
+    a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
+    a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
+    const size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4) * sizeof(float);
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(256), lds, c.s, a);
+    return vpho::check_launch("score_head_kernel");
+}
+
+// rhs(t, .) of the probability-flow ODE: 0 - f32(0.5 g(t)^2) * score     (score_based_model.py:74-83)
+int eval_rhs(Ctx& c, const float* X, double t, float* out) {
+    const float tf = (float)t;
+    const double g = (double)sigma_f32(tf) * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
+    const float coef = (float)(0.5 * g * g);
+    return eval_net(c, X, tf, 1, coef, out);
+}
+
+double* pinned_slot() {
+    static thread_local double* p = nullptr;
+    if (!p) { if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+    return p;
+}
+
+int reduce_norm(Ctx& c, NormArgs na, double* value) {
+    const int nb = (int)std::min<long long>(1024, (c.n_el + 255) / 256);
+    na.n_el = c.n_el; na.partial = c.ws.partial;
+    hipLaunchKernelGGL(norm_partial_kernel, dim3(nb), dim3(256), 0, c.s, na);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(64), 0, c.s, c.ws.partial, nb, c.ws.result);
+    if (int e = vpho::check_launch("norm kernels")) return e;
+    double* h = pinned_slot();
+    VPHO_REQUIRE(h != nullptr, "hipHostMalloc failed");
+    VPHO_HIP(hipMemcpyAsync(h, c.ws.result, 8, hipMemcpyDeviceToHost, c.s));
+    VPHO_HIP(hipStreamSynchronize(c.s));
+    *value = std::sqrt(*h) / std::sqrt((double)c.n_el);
+    return 0;
+}
+
+const double RK_C[6] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
+const double RK_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+const double RK_B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+const double RK_P[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+}  // namespace
+
+extern "C" long long vpho_score_workspace_bytes(const vpho_score_weights* w, int bs, int S) {
+    if (!w || bs <= 0 || S <= 0) return -1;
+    return carve(*w, bs, S, nullptr).bytes;
+}
+
+extern "C" int vpho_score_eval(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* x, float t,
+                               float* out, void* workspace, long long workspace_bytes, void* stream) {
+    if (int e = check_weights(w)) return e;
+    VPHO_REQUIRE(bs > 0 && S > 0 && feat_img && x && out && workspace, "vpho_score_eval: bad argument");
+    Ctx c;
+    c.w = w; c.bs = bs; c.S = S; c.R = (long long)bs * S; c.n_el = c.R * w->D; c.NH = w->nheads * 256; c.s = (hipStream_t)stream;
+    c.ws = carve(*w, bs, S, (char*)workspace);
+    VPHO_REQUIRE(workspace_bytes >= c.ws.bytes, "vpho_score_eval: workspace %lld < %lld bytes", workspace_bytes, c.ws.bytes);
+    VPHO_HIP(hipMemsetAsync(c.ws.nan_count, 0, 4, c.s));
+    if (int e = prepare_cimg(c, feat_img)) return e;
+    const int nb = (int)((c.R * w->Dp + 255) / 256);
+    hipLaunchKernelGGL(f32_to_state_kernel, dim3(nb), dim3(256), 0, c.s, x, c.n_el, w->D, w->Dp, c.ws.y, c.ws.X);
+    return eval_net(c, c.ws.X, t, 0, 0.f, out);
+}
+
+extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
+                               double T0, double eps, int num_steps, double rtol, double atol,
+                               void* xs_out, int xs_is_f64, double* x_out, void* workspace, long long workspace_bytes,
+                               vpho_ode_stats* st, double* step_log, int step_log_cap, void* stream) {
+    if (int e = check_weights(w)) return e;
+    VPHO_REQUIRE(bs > 0 && S > 0 && num_steps >= 1 && feat_img && init_x && xs_out && x_out && workspace && st, "vpho_ode_sample: bad argument");
+    VPHO_REQUIRE(T0 > eps, "vpho_ode_sample: T0 must exceed eps (backward integration)");
+    Ctx c;
+    c.w = w; c.bs = bs; c.S = S; c.R = (long long)bs * S; c.n_el = c.R * w->D; c.NH = w->nheads * 256; c.s = (hipStream_t)stream;
+    c.ws = carve(*w, bs, S, (char*)workspace);
+    VPHO_REQUIRE(workspace_bytes >= c.ws.bytes, "vpho_ode_sample: workspace %lld < %lld bytes", workspace_bytes, c.ws.bytes);
+    memset(st, 0, sizeof(*st));
+    const long long n_el = c.n_el;
+    const int D = w->D, Dp = w->Dp;
+    const int nbX = (int)((c.R * Dp + 255) / 256), nbE = (int)((n_el + 255) / 256);
+    float* K = c.ws.K;
+    auto Kp = [&](int j) { return K + (long long)j * n_el; };
+
+    VPHO_HIP(hipMemsetAsync(c.ws.nan_count, 0, 4, c.s));
+    if (int e = prepare_cimg(c, feat_img)) return e;
+    double* y = c.ws.y;
+    double* ynew = c.ws.ynew;
+    hipLaunchKernelGGL(f32_to_state_kernel, dim3(nbX), dim3(256), 0, c.s, init_x, n_el, D, Dp, y, c.ws.X);
+
+    // t_eval = np.linspace(T0, eps, num_steps)
+    std::vector<double> te(num_steps);
+    {
+        const int div = num_steps > 1 ? num_steps - 1 : 1;
+        const double step = (eps - T0) / div;
+        for (int i = 0; i < num_steps; ++i) te[i] = (double)i * step + T0;
+        if (num_steps > 1) te[num_steps - 1] = eps;
+    }
+    const double direction = -1.0, tf = eps, max_step = 10.0;
+    double t = T0;
+    int next_idx = 0;
+    auto log_step = [&](double tt, double hh, double err, int acc) {
+        if (step_log && st->n_log < step_log_cap) {
+            double* p = step_log + 4 * st->n_log;
+            p[0] = tt; p[1] = hh; p[2] = err; p[3] = acc;
+        }
+        ++st->n_log;
+    };
+
+    // f0 = fun(t0, y0); select_initial_step
+    if (int e = eval_rhs(c, c.ws.X, t, Kp(0))) return e;
+    ++st->nfev;
+    double h_abs;
+    {
+        NormArgs na;
+        memset(&na, 0, sizeof(na));
+        na.y = y; na.rtol = rtol; na.atol = atol;
+        double d0, d1, d2;
+        na.mode = 0;
+        if (int e = reduce_norm(c, na, &d0)) return e;
+        na.mode = 1; na.Ka = Kp(0);
+        if (int e = reduce_norm(c, na, &d1)) return e;
+        const double interval = std::fabs(tf - t);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, interval);
+        LinComb lc;
+        memset(&lc, 0, sizeof(lc));
+        lc.n = 1; lc.c[0] = 1.0; lc.h = h0 * direction;
+        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
+        if (int e = eval_rhs(c, c.ws.X, t + h0 * direction, Kp(1))) return e;
+        ++st->nfev;
+        na.mode = 2; na.Ka = Kp(0); na.Kb = Kp(1);
+        if (int e = reduce_norm(c, na, &d2)) return e;
+        d2 /= h0;
+        double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+        h_abs = std::min(std::min(100 * h0, h1), std::min(interval, max_step));
+    }
+
+    const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10.0, ERR_EXP = -1.0 / 5.0;
+    while (t != tf) {
+        const double min_step = 10 * std::fabs(std::nextafter(t, direction * INFINITY) - t);
+        if (h_abs > max_step) h_abs = max_step; else if (h_abs < min_step) h_abs = min_step;
+        bool accepted = false, rejected = false;
+        double h = 0, t_new = t;
+        while (!accepted) {
+            if (h_abs < min_step) { st->status = 1; return vpho::fail("vpho_ode_sample: step size underflow at t=%g", t); }
+            h = h_abs * direction;
+            t_new = t + h;
+            if (direction * (t_new - tf) > 0) t_new = tf;
+            h = t_new - t;
+            h_abs = std::fabs(h);
+            for (int s = 1; s < 6; ++s) {
+                LinComb lc;
+                memset(&lc, 0, sizeof(lc));
+                lc.n = s; lc.h = h;
+                for (int j = 0; j < s; ++j) lc.c[j] = RK_A[s][j];
+                hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
+                if (int e = eval_rhs(c, c.ws.X, t + RK_C[s] * h, Kp(s))) return e;
+            }
+            {
+                LinComb lc;
+                memset(&lc, 0, sizeof(lc));
+                lc.n = 6; lc.h = h;
+                for (int j = 0; j < 6; ++j) lc.c[j] = RK_B[j];
+                hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, ynew);
+                if (int e = eval_rhs(c, c.ws.X, t + h, Kp(6))) return e;
+            }
+            st->nfev += 6;
+            NormArgs na;
+            memset(&na, 0, sizeof(na));
+            na.mode = 3; na.y = y; na.ynew = ynew; na.K = K; na.h = h; na.rtol = rtol; na.atol = atol;
+            for (int j = 0; j < 7; ++j) na.E[j] = RK_E[j];
+            double err;
+            if (int e = reduce_norm(c, na, &err)) return e;
+            if (err < 1) {
+                double factor = err == 0 ? MAX_FACTOR : std::min(MAX_FACTOR, SAFETY * std::pow(err, ERR_EXP));
+                if (rejected) factor = std::min(1.0, factor);
+                log_step(t, h, err, 1);
+                h_abs *= factor;
+                accepted = true;
+                ++st->n_accepted;
+            } else {
+                log_step(t, h, err, 0);
+                h_abs *= std::max(MIN_FACTOR, SAFETY * std::pow(err, ERR_EXP));
+                rejected = true;
+                ++st->n_rejected;
+            }
+        }
+        // dense output on the stamps inside (t_new, t]  (decreasing time: stamps >= t_new)
+        while (next_idx < num_steps && te[next_idx] >= t_new) {
+            DenseArgs da;
+            for (int j = 0; j < 7; ++j) for (int m = 0; m < 4; ++m) da.P[j][m] = RK_P[j][m];
+            const double x = (te[next_idx] - t) / h;
+            da.p[0] = x; da.p[1] = x * x; da.p[2] = da.p[1] * x; da.p[3] = da.p[2] * x;
+            da.h = h;
+            hipLaunchKernelGGL(dense_kernel, dim3(nbE), dim3(256), 0, c.s, y, K, n_el, D, da, xs_out, xs_is_f64, num_steps, next_idx);
+            ++next_idx;
+        }
+        // accept: y <- y_new, f <- f_new (first-same-as-last)
+        std::swap(y, ynew);
+        VPHO_HIP(hipMemcpyAsync(Kp(0), Kp(6), n_el * 4, hipMemcpyDeviceToDevice, c.s));
+        t = t_new;
+    }
+    // reverse-diffusion predictor "denoise" step at t = eps
+    {
+        const float tfl = (float)eps;
+        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, LinComb{{0}, 0, 0.0}, c.ws.X, (double*)nullptr);
+        if (int e = eval_net(c, c.ws.X, tfl, 0, 0.f, c.ws.tmp)) return e;
+        ++st->nfev;
+        const float g = sigma_f32(tfl) * (float)std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
+        const float stepf = (float)((1.0 - eps) / num_steps);
+        hipLaunchKernelGGL(denoise_kernel, dim3(nbE), dim3(256), 0, c.s, y, c.ws.tmp, n_el, g, stepf, x_out);
+    }
+    if (int e = vpho::check_launch("ode tail")) return e;
+    int nan_host = 0;
+    VPHO_HIP(hipMemcpyAsync(&nan_host, c.ws.nan_count, 4, hipMemcpyDeviceToHost, c.s));
+    VPHO_HIP(hipStreamSynchronize(c.s));
+    st->nan_count = nan_host;
+    return 0;
+}

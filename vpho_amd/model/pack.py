@@ -1,0 +1,44 @@
+"""Weight packing for the HIP kernels: NHWC implicit-GEMM layout, eval-mode BatchNorm folding."""
+import torch
+
+
+def bn_affine(sd, p, eps=1e-5):
+    """Eval-mode BatchNorm as per-channel (scale, shift)."""
+    scale = sd[p + '.weight'] / torch.sqrt(sd[p + '.running_var'] + eps)
+    return scale, sd[p + '.bias'] - sd[p + '.running_mean'] * scale
+
+
+def pack_conv(w, cin_pad=None):
+    """(Cout, Cin, kh, kw) -> (Cout, kh*kw*cin_pad) with k = (r*kw + s)*cin_pad + c."""
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin if cin_pad is None else cin_pad
+    wp = w.permute(0, 2, 3, 1)
+    if cin_pad != cin:
+        wp = torch.nn.functional.pad(wp, (0, cin_pad - cin))
+    return wp.reshape(cout, kh * kw * cin_pad).contiguous()
+
+
+def fold_conv_bn(sd, conv, bn=None, cin_pad=None, device=None):
+    """conv (+ following BatchNorm) -> (packed weight, bias) on ``device``."""
+    w = sd[conv + '.weight'].float()
+    b = sd.get(conv + '.bias')
+    b = torch.zeros(w.shape[0]) if b is None else b.float()
+    if bn is not None:
+        s, t = bn_affine(sd, bn)
+        w = w * s[:, None, None, None]
+        b = b * s + t
+    return pack_conv(w, cin_pad).to(device), b.contiguous().to(device)
+
+
+def pack_deconv4x4s2(w):
+    """ConvTranspose2d(k=4, s=2, p=1) weight (Cin, Cout, 4, 4) -> four 2x2 sub-convolutions, one per output parity
+    (py, px): out[2a+py, 2b+px] = sum_{dy,dx in {0,1}} in[a+dy-(1-py), b+dx-(1-px)] * w[:, :, ky(py,dy), kx(px,dx)]
+    with ky(0,.) = (3,1), ky(1,.) = (2,0).  Returns {(py,px): (Cout, 4*Cin) packed, pad_y, pad_x}."""
+    tap = {0: (3, 1), 1: (2, 0)}
+    out = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            sub = torch.stack([torch.stack([w[:, :, tap[py][dy], tap[px][dx]] for dx in (0, 1)], -1) for dy in (0, 1)], -2)
+            # sub: (Cin, Cout, 2(dy), 2(dx)) -> conv weight (Cout, Cin, 2, 2)
+            out[(py, px)] = (pack_conv(sub.permute(1, 0, 2, 3).contiguous()), 1 - py, 1 - px)
+    return out
