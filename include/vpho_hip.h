@@ -86,15 +86,122 @@ typedef struct {
 
 /* Full cond_ode_sampler run.  init_x: [R][D] fp32 prior draw (already scaled by sigma(T0)).
  * xs_out: [R][num_steps][D] dense output at t_eval = linspace(T0, eps, num_steps), fp64 if xs_is_f64 else fp32
- * (the reference casts the hand trajectory to fp32 right after sampling, VPHO.py:243); x_out: [R][D] fp64 final
- * sample after the denoise step.  SYNCHRONISES `stream` once per attempted RK step (8-byte error norm D2H) --
+ * (the reference casts the hand trajectory to fp32 right after sampling, VPHO.py:243); x_out: [R][D] final sample
+ * after the denoise step, fp64 if x_is_f64 else rounded to fp32 the same way.  SYNCHRONISES `stream` once per attempted RK step (8-byte error norm D2H) --
  * the scalar step controller runs on the host exactly as scipy's.  stats_host / step_log_host are host memory
  * (step_log_host may be NULL; capacity in entries of 4 doubles). */
 int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
                     double T0, double eps, int num_steps, double rtol, double atol,
-                    void* xs_out, int xs_is_f64, double* x_out,
+                    void* xs_out, int xs_is_f64, void* x_out, int x_is_f64,
                     void* workspace, long long workspace_bytes,
                     vpho_ode_stats* stats_host, double* step_log_host, int step_log_cap, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HBM-bound glue of the feature path (NHWC fp32).  c_off / ld* let a kernel write straight into a channel slice of a
+ * wider (concatenation) buffer.
+ */
+/* rgb (N,C,H,W) -> (N,H,W,ldy) with channels >= C zero-filled (input of the 7x7 stem, backbone_FPN_HFL.py:206) */
+int vpho_nchw_to_nhwc_f32(const float* x, int N, int C, int H, int W, float* y, int ldy, void* stream);
+/* (N,H,W,C | ldx) -> (N,C,H,W): heat-map outputs (VPHO.py:232-233) and Encoder's x.flatten(1) (encoding.py:72) */
+int vpho_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, void* stream);
+/* nn.MaxPool2d (backbone_FPN_HFL.py:209 k3 s2 p1; encoding.py:54 k2 s2) */
+int vpho_maxpool_nhwc_f32(const float* x, int N, int H, int W, int C, int k, int stride, int pad, float* y, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False); accumulate=1 gives FPN._upsample_add (backbone_FPN_HFL.py:66-68),
+ * accumulate=0 with c_off the heat-map 64->32 resize into the encoder input (VPHO.py:143-144,148-149) */
+int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW,
+                                  float* y, int ldy, int c_off, int accumulate, void* stream);
+/* torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), one box per image, boxes (N,4) xyxy (VPHO.py:125-128);
+ * flip_w[n] != 0 mirrors the output along W (flip_tensor_by_mask_index, VPHO.py:138) */
+int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+                            int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream);
+/* align_hm_to_bbox_rectangle (VPHO.py:333-346, transposing, quirk Q2) (+ optional W flip, VPHO.py:139) */
+int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
+                                const unsigned char* flip_w, float* out, void* stream);
+/* NeRF embedding of gravity (cross_module.py:8-46), x negated where flip_x (VPHO.py:167); out (N,64), column 63 = 0 */
+int vpho_nerf_embed_f32(const float* g, int N, const unsigned char* flip_x, float* out, void* stream);
+/* (bs,65,512) token tensor of CrossModule.forward (cross_module.py:124-133) incl. the positional code of the BATCH index */
+int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const float* grav_emb, const float* pe,
+                          int bs, float* out, void* stream);
+/* multi-head attention core over the first axis of qkv (S,B,3E) (nn.MultiheadAttention inside cross_module.py:104-107) */
+int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream);
+/* out = LayerNorm(x + r) (post-norm TransformerEncoderLayer) */
+int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,
+                           float eps, float* out, void* stream);
+/* HeadPhysics: |scale| * normalise(softmax(softmax(logits)) . friction-cone anchors) (physics.py:546-557,700-712).
+ * Output row r reads token row (r / group) * group_stride + r % group (+ off_scale | off_logits) of the MLP outputs, so the
+ * 32 hand / 32 object tokens are picked out of the (bs, 65, .) transformer output without a copy. */
+int vpho_force_local_f32(const float* scale, int ld_scale, const float* logits, int ld_logits, const float* anchor,
+                         float friction, long long rows, int group, int group_stride, int off_scale, int off_logits,
+                         float* out, void* stream);
+/* matrix_to_axis_angle(rotation_6d_to_matrix(x)) for rows of rot_per_row rotations (head_mano.py:66-69, VPHO.py:314-324) */
+int vpho_rot6d_to_axis_angle_f32(const float* x, long long rows, int rot_per_row, int ldx, float* out, int ldo, void* stream);
+/* out[row, 48:58] = betas[row / rows_per_image] (VPHO.py:318-319,325-326) */
+int vpho_append_betas_f32(const float* betas, long long rows, long long rows_per_image, float* out, int ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * MANO forward kinematics (manopth.ManoLayer as configured at head_mano.py:48-55; metres, head_mano.py:78-87).
+ * posedirs_t is the pose-blend table transposed to [135][778*3] (coalesced over vertices).
+ */
+typedef struct {
+    const float *v_template;   /* [778][3]      */
+    const float *shapedirs;    /* [778][3][10]  */
+    const float *posedirs_t;   /* [135][778*3]  */
+    const float *J_regressor;  /* [16][778]     */
+    const float *weights;      /* [778][16]     */
+} vpho_mano_tables;
+/* per image: v_shaped (n_img,778,3), J (n_img,16,3) from betas (n_img,10) */
+int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream);
+/* per hand: pose rows of ld_pose floats (first 48 = axis-angle); hand h uses image h / hands_per_image.
+ * verts may be NULL (joints only).  ho3d_per_image (optional) selects hand_fn.get_joint_aligned_with_HO3D ordering. */
+int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, int ld_pose, long long n_hands, int hands_per_image,
+                     const float* v_shaped, const float* J, const unsigned char* ho3d_per_image,
+                     float* verts, float* joints, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Aggregation (lib/model/aggregation.py HOI_Aggregator.__call__ :1167-1353 and callees; lib/utils/transform_fn.py:101-125;
+ * lib/utils/physics_fn.py:224-257).  Top-k order: value descending, ties by ascending candidate index.
+ */
+typedef struct { const float* kpt; const float* vert; const float* com; int n_kpt, n_vert, n_obj; } vpho_obj_tables;
+    /* kpt [n_obj][n_kpt][3], vert [n_obj][n_vert][3], com [n_obj][3]   (head_object.py:13-33) */
+typedef struct { const int* face_idx; const float* anchor_weight; const float* vert2joint; const int* skeleton; } vpho_anchor_tables;
+    /* face_idx [32][3], anchor_weight [32][2], vert2joint [21][778], skeleton [32][2]   (physics_fn.py:120-171) */
+
+/* pose (bs,2S,48): [S diffusion | S regression with the diffusion wrist] (aggregation.py:120-126,140-143) */
+int vpho_hand_candidates_f32(const float* diff_pose, int ld_diff, const float* reg_pose, int bs, int S, float* pose, void* stream);
+/* hv (bs,C,n_obs): bicubic heat-map value of each observed joint of each candidate (aggregation.py:196-213);
+ * joints (bs,C,21,3) root-relative, heatmap (bs,J,H,W) planar; observe_host is a HOST int array */
+int vpho_hand_heat_f32(const float* joints, const float* root, const float* Kmat, const float* bbox, const float* heatmap,
+                       int bs, int C, int J, int H, int W, const int* observe_host, int n_obs, float* out, void* stream);
+/* one cascade level (aggregation.py:215-269): score -> top-k -> weighted quaternion mean -> broadcast into all candidates.
+ * val/idx: [bs][F][k] with F = 1 (level 0) or 5; topk_pose (optional) [bs][k][F][3] */
+int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
+                             float* val, int* idx, float* topk_pose, void* stream);
+/* generic wavefront top-k: element c of row (o,f) at scores[(o*n + c)*F + f]; val/idx [o][f][k] */
+int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream);
+int vpho_topk_weights_f32(const float* val, int rows, int k, float* w, void* stream);
+/* select_topk_object_by_heatmap score (aggregation.py:742-776); pose (bs,n,9) fp64 */
+int vpho_obj_heat_score(const double* pose, int n, const double* transl_override, const float* root, const vpho_obj_tables* t,
+                        const int* obj_id, const unsigned char* is_right, const float* Kmat, const float* bbox,
+                        const float* heatmap, int bs, int H, int W, float* score, void* stream);
+int vpho_obj_cross_candidates(const double* pose, int n, const int* transl_idx, const int* rot_idx, int bs, int ko, double* cand, void* stream);
+/* select_topk_object_by_physics3 score (aggregation.py:947-985) */
+int vpho_obj_physics_score(const double* cand, int n, const float* root, const vpho_obj_tables* t, const int* obj_id,
+                           const unsigned char* is_right, const float* force_point, const float* force_global, int bs,
+                           float* score, void* stream);
+/* fuse_topk + average_rot6d in fp64 (aggregation.py:729-740,50-56); source b (if given) is used where pick_b[b] != 0 */
+int vpho_obj_fuse_f64(const double* pose, int n, const int* idx_a, const float* w_a, const int* idx_b, const float* w_b,
+                      const unsigned char* pick_b, int bs, int k, double* fused, void* stream);
+int vpho_obj_verts_f32(const double* pose, const float* root, const vpho_obj_tables* t, const int* obj_id,
+                       const unsigned char* is_right, int bs, float* out, void* stream);
+/* ForceAnchor.__call__ on (verts + root) and from_local_to_global (physics_fn.py:224-257, physics.py:362-371) */
+int vpho_force_anchor_f32(const vpho_anchor_tables* t, const float* verts, const float* root, const float* force_local,
+                          long long n_hands, int hands_per_image, float* force_point, float* force_global, void* stream);
+/* aggregation.py:1306-1325 / :561-596 / :598-617 */
+int vpho_hand_phys_candidates_f32(const float* agg_pose, int ld_agg, const float* betas, const float* topk_pose, int bs, int k,
+                                  float* out, void* stream);
+int vpho_hand_phys_score_f32(const float* force_point, const float* force_global, const float* obj_vert, int n_vert,
+                             int bs, int n_cand, float* finger_score, void* stream);
+int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int bs, int k, float* out, void* stream);
 
 #ifdef __cplusplus
 }

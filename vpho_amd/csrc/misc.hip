@@ -1,0 +1,439 @@
+// HBM-bound glue kernels of the feature path: layout changes, pooling, bilinear resampling, RoIAlign, token assembly,
+// attention over the batch axis (quirk Q3), layer norm, friction-cone force head, rotation conversions.
+// All are coalesced along the NHWC channel axis (one thread per (pixel, channel) with channel fastest); none is
+// reshaped into a GEMM.  Roofline: HBM bytes = inputs read once + outputs written once.
+#include "common.h"
+#include "rot.h"
+#include "../../include/vpho_hip.h"
+
+namespace {
+
+inline int nblocks(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W, float* __restrict__ y, int ldy) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * H * W * ldy;
+    if (i >= total) return;
+    const int c = (int)(i % ldy);
+    const long long p = i / ldy;                 // n*H*W + h*W + w
+    const long long hw = (long long)H * W;
+    const long long n = p / hw, r = p - n * hw;
+    y[i] = c < C ? x[(n * C + c) * hw + r] : 0.f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long hw = (long long)H * W, total = (long long)N * C * hw;
+    if (i >= total) return;
+    const long long r = i % hw;
+    const long long nc = i / hw;
+    const int c = (int)(nc % C);
+    const long long n = nc / C;
+    y[i] = x[(n * hw + r) * ldx + c];
+}
+
+// ------------------------------------------------------------------------------------------------ max pool
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, int N, int H, int W, int C, int k, int stride, int pad,
+                                    int OH, int OW, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * OH * OW * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const long long n = p / OH;
+    float m = -INFINITY;
+    for (int r = 0; r < k; ++r) {
+        const int iy = oy * stride - pad + r;
+        if (iy < 0 || iy >= H) continue;
+        for (int s = 0; s < k; ++s) {
+            const int ix = ox * stride - pad + s;
+            if (ix < 0 || ix >= W) continue;
+            m = fmaxf(m, x[((n * H + iy) * W + ix) * C + c]);
+        }
+    }
+    y[i] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear resize
+// F.interpolate(mode='bilinear', align_corners=False): src = max((dst+0.5)*scale-0.5, 0), scale = in/out
+__device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = ((float)dst + 0.5f) * scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// y[n,oy,ox,c_off+c] (=|+=) bilinear(x)[n,oy,ox,c]
+__global__ void resize_bilinear_nhwc_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int OH, int OW,
+                                            float* __restrict__ y, int ldy, int c_off, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * OH * OW * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const long long n = p / OH;
+    int y0, y1, x0, x1; float ly, lx;
+    lin_src(oy, (float)H / (float)OH, H, y0, y1, ly);
+    lin_src(ox, (float)W / (float)OW, W, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = x + n * H * W * (long long)ldx + c;
+    const float v = hy * (hx * b[((long long)y0 * W + x0) * ldx] + lx * b[((long long)y0 * W + x1) * ldx]) +
+                    ly * (hx * b[((long long)y1 * W + x0) * ldx] + lx * b[((long long)y1 * W + x1) * ldx]);
+    float* o = y + ((n * OH + oy) * OW + ox) * (long long)ldy + c_off + c;
+    *o = accumulate ? (*o + v) : v;
+}
+
+// ------------------------------------------------------------------------------------------------ RoIAlign
+// torchvision roi_align, aligned=False, sampling_ratio=-1 (adaptive), one RoI per image (batch index = roi index)
+__device__ inline float roi_bilinear(const float* __restrict__ f, int H, int W, int ld, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * hx * f[((long long)yl * W + xl) * ld] + hy * lx * f[((long long)yl * W + xh) * ld] +
+           ly * hx * f[((long long)yh * W + xl) * ld] + ly * lx * f[((long long)yh * W + xh) * ld];
+}
+
+__global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int H, int W, int C, const float* __restrict__ boxes,
+                                      float scale, int P, const unsigned char* __restrict__ flip_w,
+                                      float* __restrict__ out, int ldo, int c_off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * P * P * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int pw = (int)(p % P); p /= P;
+    const int ph = (int)(p % P);
+    const int n = (int)(p / P);
+    const float x1 = boxes[n * 4 + 0] * scale, y1 = boxes[n * 4 + 1] * scale;
+    const float x2 = boxes[n * 4 + 2] * scale, y2 = boxes[n * 4 + 3] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = fmaxf((float)(gh * gw), 1.f);
+    const float* f = feat + (long long)n * H * W * C + c;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+        const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            acc += roi_bilinear(f, H, W, C, y, x);
+        }
+    }
+    const int ow = (flip_w && flip_w[n]) ? P - 1 - pw : pw;
+    out[(((long long)n * P + ph) * P + ow) * ldo + c_off + c] = acc / cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ heat-map re-alignment
+// VPHO.py:333-346 (quirk Q2): out[b,i,j,c] = bilinear_zero(hm[b], x = (i/(S-1)*2-1)*rel_w, y = (j/(S-1)*2-1)*rel_h)
+// then optional flip along the last spatial axis (VPHO.py:139).  NHWC in, NHWC out.
+__global__ void align_heatmap_kernel(const float* __restrict__ hm, int N, int S, int C, const float* __restrict__ bbox,
+                                     const float* __restrict__ bbox_rect, const unsigned char* __restrict__ flip_w,
+                                     float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * S * S * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long long p = idx / C;
+    const int j = (int)(p % S); p /= S;
+    const int i = (int)(p % S);
+    const int n = (int)(p / S);
+    const float relw = (bbox_rect[n * 4 + 2] - bbox_rect[n * 4 + 0]) / (bbox[n * 4 + 2] - bbox[n * 4 + 0]);
+    const float relh = (bbox_rect[n * 4 + 3] - bbox_rect[n * 4 + 1]) / (bbox[n * 4 + 3] - bbox[n * 4 + 1]);
+    const float gx = ((float)i / (float)(S - 1) * 2.f - 1.f) * relw;
+    const float gy = ((float)j / (float)(S - 1) * 2.f - 1.f) * relh;
+    const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f, iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    const float* b = hm + (long long)n * S * S * C + c;
+    auto at = [&](int yy, int xx) { return (yy >= 0 && yy < S && xx >= 0 && xx < S) ? b[((long long)yy * S + xx) * C] : 0.f; };
+    const float v = at(y0, x0) * (1.f - tx) * (1.f - ty) + at(y0, x0 + 1) * tx * (1.f - ty) +
+                    at(y0 + 1, x0) * (1.f - tx) * ty + at(y0 + 1, x0 + 1) * tx * ty;
+    const int oj = (flip_w && flip_w[n]) ? S - 1 - j : j;
+    out[(((long long)n * S + i) * S + oj) * C + c] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ CrossModule tokens
+// NeRF positional embedding of gravity (cross_module.py:8-46): [g, sin(g f0), cos(g f0), ...], f = 2^0..2^9 -> 63 (+1 pad)
+__global__ void nerf_embed_kernel(const float* __restrict__ g, int N, const unsigned char* __restrict__ flip_x, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 64) return;
+    const int n = i / 64, e = i % 64;
+    float v = 0.f;
+    if (e < 63) {
+        const int d = e % 3, blk = e / 3;           // blk 0: identity, 1: sin f0, 2: cos f0, 3: sin f1 ...
+        float x = g[n * 3 + d];
+        if (d == 0 && flip_x && flip_x[n]) x = -x;
+        if (blk == 0) v = x;
+        else {
+            const float f = exp2f((float)((blk - 1) / 2));
+            v = ((blk - 1) & 1) ? cosf(x * f) : sinf(x * f);
+        }
+    }
+    out[i] = v;
+}
+
+// x[b, n, f] = proj[b, 8n + f/64 (channel), (f%64)/8, f%8] + pe[b][f]   (cross_module.py:126-133; NHWC proj (bs,8,8,256))
+__global__ void cross_tokens_kernel(const float* __restrict__ ph, const float* __restrict__ po, const float* __restrict__ ge,
+                                    const float* __restrict__ pe, int bs, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)bs * 65 * 512) return;
+    const int f = (int)(i % 512);
+    const int tkn = (int)((i / 512) % 65);
+    const int b = (int)(i / (512 * 65));
+    float v;
+    if (tkn == 64) v = ge[b * 512 + f];
+    else {
+        const float* src = tkn < 32 ? ph : po;
+        const int n = tkn & 31;
+        v = src[((long long)b * 64 + (f & 63)) * 256 + 8 * n + (f >> 6)];
+    }
+    out[i] = v + pe[b * 512 + f];
+}
+
+// ------------------------------------------------------------------------------------------------ attention over S
+// qkv: (S, B, 3E) rows s*B+b; one block per (b, head); S <= 256.  out (S, B, E).  softmax(q k^T / sqrt(hd)) v.
+// K (row stride hd+1, conflict-free for "lane = key") and V are staged in LDS when they fit, otherwise read in place.
+__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, int use_lds,
+                                                  float* __restrict__ out) {
+    extern __shared__ float sm[];
+    const int hd = E / nhead;
+    const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
+    const float* Kp = qkv + (long long)b * 3 * E + E + h * hd;
+    const float* Vp = Kp + E;
+    long long ks = (long long)B * 3 * E, vs = ks;
+    if (use_lds) {
+        float* Ks = sm;
+        float* Vs = sm + S * (hd + 1);
+        for (int i = threadIdx.x; i < S * hd; i += blockDim.x) {
+            const int s = i / hd, d = i % hd;
+            Ks[s * (hd + 1) + d] = Kp[s * ks + d];
+            Vs[s * hd + d] = Vp[s * vs + d];
+        }
+        __syncthreads();
+        Kp = Ks; Vp = Vs; ks = hd + 1; vs = hd;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const float scl = 1.0f / sqrtf((float)hd);
+    for (int s = wave; s < S; s += nw) {
+        const float* q = qkv + ((long long)s * B + b) * 3 * E + h * hd;
+        float p[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float mx = -INFINITY;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) {
+            const int t = slot * 64 + lane;
+            if (t < S) {
+                float a = 0.f;
+                for (int d = 0; d < hd; ++d) a += (q[d] * scl) * Kp[t * ks + d];
+                p[slot] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) {
+            const int t = slot * 64 + lane;
+            p[slot] = t < S ? expf(p[slot] - mx) : 0.f;
+            sum += p[slot];
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int d0 = 0; d0 < hd; d0 += 64) {
+            const int d = d0 + lane;
+            float a = 0.f;
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                const int tmax = min(64, S - slot * 64);
+                for (int tl = 0; tl < tmax; ++tl) {
+                    const float pt = __shfl(p[slot], tl);
+                    if (d < hd) a += pt * Vp[(slot * 64 + tl) * vs + d];
+                }
+            }
+            if (d < hd) out[((long long)s * B + b) * E + h * hd + d] = a * inv;
+        }
+    }
+}
+
+// out = LayerNorm(x + r) over the last dim E (one wave per row)
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            long long rows, int E, float eps, float* __restrict__ out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* a = x + row * E;
+    const float* b = r + row * E;
+    float s = 0.f;
+    for (int i = lane; i < E; i += 64) s += a[i] + b[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)E;
+    float v = 0.f;
+    for (int i = lane; i < E; i += 64) { const float d = a[i] + b[i] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / (float)E + eps);
+    for (int i = lane; i < E; i += 64) out[row * E + i] = (a[i] + b[i] - mean) * rstd * gamma[i] + beta[i];
+}
+
+// ------------------------------------------------------------------------------------------------ friction-cone force
+// physics.py:546-557 + :700-712 (double softmax, quirk Q4): scale (rows), logits (rows,8), anchor (8,3)
+__global__ void force_local_kernel(const float* __restrict__ scale, int ld_scale, const float* __restrict__ logits, int ld_logits,
+                                   const float* __restrict__ anchor, float friction, long long rows, int group, int group_stride,
+                                   int off_scale, int off_logits, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const long long base = (r / group) * group_stride + r % group;      // token row inside the (bs, 65, .) token tensors
+    const long long rs = base + off_scale, rl = base + off_logits;
+    float w[8];
+    for (int pass = 0; pass < 2; ++pass) {
+        float mx = -INFINITY;
+        for (int i = 0; i < 8; ++i) { if (pass == 0) w[i] = logits[rl * ld_logits + i]; mx = fmaxf(mx, w[i]); }
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) { w[i] = expf(w[i] - mx); s += w[i]; }
+        for (int i = 0; i < 8; ++i) w[i] /= s;
+    }
+    float d[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) {
+        d[0] += w[i] * (anchor[i * 3 + 0] * friction);
+        d[1] += w[i] * (anchor[i * 3 + 1] * friction);
+        d[2] += w[i] * anchor[i * 3 + 2];
+    }
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-8f;
+    const float sc = fabsf(scale[rs * ld_scale]);
+    for (int k = 0; k < 3; ++k) out[r * 3 + k] = d[k] / nrm * sc;
+}
+
+// ------------------------------------------------------------------------------------------------ rotations
+// rot6d (n, 6) -> axis-angle (n, 3): matrix_to_axis_angle(rotation_6d_to_matrix(.)) (head_mano.py:66-69, VPHO.py:316,323)
+// rows of x are `ldx` floats apart starting at x; output rows `ldo` apart, element j of hand-row goes to out[row*ldo + j]
+__global__ void rot6d_to_aa_kernel(const float* __restrict__ x, long long n_rot, int rot_per_row, int ldx, float* __restrict__ out, int ldo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rot) return;
+    const long long row = i / rot_per_row;
+    const int j = (int)(i - row * rot_per_row);
+    float R[9], q[4], aa[3];
+    vpho::rot6d_to_matrix(x + row * ldx + 6 * j, R);
+    vpho::matrix_to_quaternion(R, q);
+    vpho::quaternion_to_axis_angle(q, aa);
+    float* o = out + row * ldo + 3 * j;
+    o[0] = aa[0]; o[1] = aa[1]; o[2] = aa[2];
+}
+
+// append per-image betas: out[row*ldo + 48 + k] = betas[(row / rows_per_image)*10 + k]
+__global__ void append_betas_kernel(const float* __restrict__ betas, long long rows, long long rows_per_image, float* __restrict__ out, int ldo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 10) return;
+    const long long row = i / 10;
+    const int k = (int)(i - row * 10);
+    out[row * ldo + 48 + k] = betas[(row / rows_per_image) * 10 + k];
+}
+
+}  // namespace
+
+#define LAUNCH1D(kernel, total, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+extern "C" int vpho_nchw_to_nhwc_f32(const float* x, int N, int C, int H, int W, float* y, int ldy, void* stream) {
+    VPHO_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldy >= C, "vpho_nchw_to_nhwc_f32: bad argument");
+    LAUNCH1D(nchw_to_nhwc_kernel, (long long)N * H * W * ldy, stream, x, N, C, H, W, y, ldy);
+    return vpho::check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int vpho_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, void* stream) {
+    VPHO_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C, "vpho_nhwc_to_nchw_f32: bad argument");
+    LAUNCH1D(nhwc_to_nchw_kernel, (long long)N * H * W * C, stream, x, N, H, W, C, ldx, y);
+    return vpho::check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int vpho_maxpool_nhwc_f32(const float* x, int N, int H, int W, int C, int k, int stride, int pad, float* y, void* stream) {
+    VPHO_REQUIRE(x && y && N > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k, "vpho_maxpool_nhwc_f32: bad argument");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    VPHO_REQUIRE(OH > 0 && OW > 0, "vpho_maxpool_nhwc_f32: empty output");
+    LAUNCH1D(maxpool_nhwc_kernel, (long long)N * OH * OW * C, stream, x, N, H, W, C, k, stride, pad, OH, OW, y);
+    return vpho::check_launch("maxpool_nhwc_kernel");
+}
+
+extern "C" int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW,
+                                             float* y, int ldy, int c_off, int accumulate, void* stream) {
+    VPHO_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && ldx >= C && ldy >= c_off + C && c_off >= 0,
+                 "vpho_resize_bilinear_nhwc_f32: bad argument");
+    LAUNCH1D(resize_bilinear_nhwc_kernel, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
+    return vpho::check_launch("resize_bilinear_nhwc_kernel");
+}
+
+extern "C" int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+                                       int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream) {
+    VPHO_REQUIRE(feat && boxes && out && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_nhwc_f32: bad argument");
+    LAUNCH1D(roi_align_nhwc_kernel, (long long)N * out_size * out_size * C, stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
+    return vpho::check_launch("roi_align_nhwc_kernel");
+}
+
+extern "C" int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
+                                           const unsigned char* flip_w, float* out, void* stream) {
+    VPHO_REQUIRE(hm && bbox && bbox_rect && out && N > 0 && size > 1 && C > 0, "vpho_align_heatmap_nhwc_f32: bad argument");
+    LAUNCH1D(align_heatmap_kernel, (long long)N * size * size * C, stream, hm, N, size, C, bbox, bbox_rect, flip_w, out);
+    return vpho::check_launch("align_heatmap_kernel");
+}
+
+extern "C" int vpho_nerf_embed_f32(const float* g, int N, const unsigned char* flip_x, float* out, void* stream) {
+    VPHO_REQUIRE(g && out && N > 0, "vpho_nerf_embed_f32: bad argument");
+    LAUNCH1D(nerf_embed_kernel, (long long)N * 64, stream, g, N, flip_x, out);
+    return vpho::check_launch("nerf_embed_kernel");
+}
+
+extern "C" int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const float* grav_emb, const float* pe,
+                                     int bs, float* out, void* stream) {
+    VPHO_REQUIRE(proj_hand && proj_obj && grav_emb && pe && out && bs > 0 && bs <= 5000, "vpho_cross_tokens_f32: bad argument");
+    LAUNCH1D(cross_tokens_kernel, (long long)bs * 65 * 512, stream, proj_hand, proj_obj, grav_emb, pe, bs, out);
+    return vpho::check_launch("cross_tokens_kernel");
+}
+
+extern "C" int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream) {
+    VPHO_REQUIRE(qkv && out && S > 0 && S <= 256 && B > 0 && nhead > 0 && E % nhead == 0, "vpho_mha_f32: bad argument (sequence = batch axis, quirk Q3, must be <= 256; got %d)", S);
+    const int hd = E / nhead;
+    size_t lds = (size_t)(S * (hd + 1) + S * hd) * sizeof(float);
+    const int use_lds = lds <= 150 * 1024;
+    if (!use_lds) lds = 0;
+    static bool opt_in = false;
+    if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
+    hipLaunchKernelGGL(mha_kernel, dim3(B * nhead), dim3(256), lds, (hipStream_t)stream, qkv, S, B, E, nhead, use_lds, out);
+    return vpho::check_launch("mha_kernel");
+}
+
+extern "C" int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,
+                                      float eps, float* out, void* stream) {
+    VPHO_REQUIRE(x && r && gamma && beta && out && rows > 0 && E > 0, "vpho_add_layernorm_f32: bad argument");
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, rows, E, eps, out);
+    return vpho::check_launch("add_layernorm_kernel");
+}
+
+extern "C" int vpho_force_local_f32(const float* scale, int ld_scale, const float* logits, int ld_logits, const float* anchor,
+                                    float friction, long long rows, int group, int group_stride, int off_scale, int off_logits,
+                                    float* out, void* stream) {
+    VPHO_REQUIRE(scale && logits && anchor && out && rows > 0 && ld_scale >= 1 && ld_logits >= 8 && group > 0 && group_stride >= group,
+                 "vpho_force_local_f32: bad argument");
+    LAUNCH1D(force_local_kernel, rows, stream, scale, ld_scale, logits, ld_logits, anchor, friction, rows, group, group_stride, off_scale, off_logits, out);
+    return vpho::check_launch("force_local_kernel");
+}
+
+extern "C" int vpho_rot6d_to_axis_angle_f32(const float* x, long long rows, int rot_per_row, int ldx, float* out, int ldo, void* stream) {
+    VPHO_REQUIRE(x && out && rows > 0 && rot_per_row > 0 && ldx >= 6 * rot_per_row && ldo >= 3 * rot_per_row, "vpho_rot6d_to_axis_angle_f32: bad argument");
+    LAUNCH1D(rot6d_to_aa_kernel, rows * rot_per_row, stream, x, rows * rot_per_row, rot_per_row, ldx, out, ldo);
+    return vpho::check_launch("rot6d_to_aa_kernel");
+}
+
+extern "C" int vpho_append_betas_f32(const float* betas, long long rows, long long rows_per_image, float* out, int ldo, void* stream) {
+    VPHO_REQUIRE(betas && out && rows > 0 && rows_per_image > 0 && ldo >= 58, "vpho_append_betas_f32: bad argument");
+    LAUNCH1D(append_betas_kernel, rows * 10, stream, betas, rows, rows_per_image, out, ldo);
+    return vpho::check_launch("append_betas_kernel");
+}

@@ -260,11 +260,12 @@ __global__ void dense_kernel(const double* __restrict__ y_old, const float* __re
 
 // x = y + (0 - g^2 * grad) * step  (fp32 product, fp64 add; score_based_model.py:95-104)
 __global__ void denoise_kernel(const double* __restrict__ y, const float* __restrict__ grad, long long n_el, float g, float step,
-                               double* __restrict__ x) {
+                               void* __restrict__ x, int is_f64) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
     const float drift = 0.f - (g * g) * grad[i];
-    x[i] = y[i] + (double)(drift * step);
+    const double v = y[i] + (double)(drift * step);
+    if (is_f64) reinterpret_cast<double*>(x)[i] = v; else reinterpret_cast<float*>(x)[i] = (float)v;
 }
 
 // --------------------------------------------------------------------------------------------- host side
@@ -416,7 +417,7 @@ extern "C" int vpho_score_eval(const vpho_score_weights* w, const float* feat_im
 
 extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
                                double T0, double eps, int num_steps, double rtol, double atol,
-                               void* xs_out, int xs_is_f64, double* x_out, void* workspace, long long workspace_bytes,
+                               void* xs_out, int xs_is_f64, void* x_out, int x_is_f64, void* workspace, long long workspace_bytes,
                                vpho_ode_stats* st, double* step_log, int step_log_cap, void* stream) {
     if (int e = check_weights(w)) return e;
     VPHO_REQUIRE(bs > 0 && S > 0 && num_steps >= 1 && feat_img && init_x && xs_out && x_out && workspace && st, "vpho_ode_sample: bad argument");
@@ -559,7 +560,7 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
         ++st->nfev;
         const float g = sigma_f32(tfl) * (float)std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
         const float stepf = (float)((1.0 - eps) / num_steps);
-        hipLaunchKernelGGL(denoise_kernel, dim3(nbE), dim3(256), 0, c.s, y, c.ws.tmp, n_el, g, stepf, x_out);
+        hipLaunchKernelGGL(denoise_kernel, dim3(nbE), dim3(256), 0, c.s, y, c.ws.tmp, n_el, g, stepf, x_out, x_is_f64);
     }
     if (int e = vpho::check_launch("ode tail")) return e;
     int nan_host = 0;

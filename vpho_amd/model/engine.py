@@ -1,0 +1,313 @@
+"""Execution plan of ``vpho_net.forward(mode='predict')`` on the HIP kernels.
+
+``Engine`` packs the module's parameters once (BatchNorm folded, NHWC implicit-GEMM layout, score-net restructuring) and
+replays the reference's data flow (VPHO.py:112-304, aggregation.py:1167-1353) as a sequence of C-ABI calls on the current
+HIP stream.  Torch is used for allocation, views and dtype/flag conversion only.
+"""
+import torch
+
+from .. import ops
+from ..configs.args import cfg
+from . import pack as P
+
+MANO_JOINT_LEVEL = {0: [0], 1: [1, 5, 9, 13, 17], 2: [2, 6, 10, 14, 18], 3: [3, 7, 11, 15, 19], 4: [4, 8, 12, 16, 20]}
+PHY_TOPK = 5          # aggregation.py:1246
+
+
+def _signature(model):
+    return (tuple(int(t._version) for t in model.state_dict(keep_vars=True).values()),
+            str(next(model.parameters()).device))
+
+
+class Engine:
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise ops.VphoError("vpho_net.forward(mode='predict') runs on the GPU only: move the module with .to('cuda')")
+        self.dev = dev
+        self.sig = _signature(model)
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        d = lambda t: t.contiguous().to(dev)
+        fold = lambda conv, bn=None, cin_pad=None: P.fold_conv_bn(sd, conv, bn, cin_pad, dev)
+
+        # ---- backbone ------------------------------------------------------------------------------------------
+        fe = 'feature_extractor'
+        self.stem = fold(f'{fe}.layer0_h.0', f'{fe}.layer0_h.1', cin_pad=4)
+
+        def res_layer(name, blocks, stride):
+            out = []
+            for i in range(blocks):
+                p = f'{fe}.{name}.0.{i}'
+                blk = dict(c1=fold(p + '.conv1', p + '.bn1'), c2=fold(p + '.conv2', p + '.bn2'),
+                           c3=fold(p + '.conv3', p + '.bn3'), stride=stride if i == 0 else 1, down=None)
+                if (p + '.downsample.0.weight') in sd:
+                    blk['down'] = fold(p + '.downsample.0', p + '.downsample.1')
+                out.append(blk)
+            return out
+
+        self.layers = dict(layer1_h=res_layer('layer1_h', 3, 1), layer2_h=res_layer('layer2_h', 4, 2),
+                           layer3_h=res_layer('layer3_h', 6, 2), layer4_h=res_layer('layer4_h', 3, 2),
+                           layer2_o=res_layer('layer2_o', 4, 2), layer3_o=res_layer('layer3_o', 6, 2))
+        self.fpn = {k: fold(f'{fe}.{k}') for k in ('toplayer_h', 'toplayer_o', 'smooth3_h', 'smooth3_o', 'latlayer1_h',
+                                                   'latlayer2_h', 'latlayer3_h', 'latlayer1_o', 'latlayer2_o', 'latlayer3_o')}
+
+        # ---- heat-map heads, encoders ------------------------------------------------------------------------------
+        def hm_head(p):
+            s, t = P.bn_affine(sd, p + '.deconv_layers.1')
+            wd = sd[p + '.deconv_layers.0.weight'] * s[None, :, None, None]
+            phases = {k: (d(w), py, px) for k, (w, py, px) in P.pack_deconv4x4s2(wd).items()}
+            return dict(c0=fold(p + '.conv_layers.0'), c1=fold(p + '.conv_layers.1', p + '.conv_layers.2'), deconv=phases,
+                        deconv_b=d(t), final=fold(p + '.final_layer'))
+
+        self.hm = dict(hand=hm_head('head_hm_hand'), obj=hm_head('head_hm_obj'))
+
+        def encoder(p, cin):
+            cin_pad = (cin + 3) // 4 * 4
+            blocks = []
+            for i in range(8):
+                q = f'{p}.reg.{i}'
+                s, t = P.bn_affine(sd, q + '.bn')
+                blocks.append(dict(pre=(d(s), d(t)), c1=fold(q + '.conv1', q + '.bn1'), c2=fold(q + '.conv2', q + '.bn2'), c3=fold(q + '.conv3')))
+            return dict(project=fold(p + '.project', cin_pad=cin_pad), blocks=blocks, cin_pad=cin_pad)
+
+        self.enc = dict(hand=encoder('encoder_hand', 277), obj=encoder('encoder_obj', 283))
+
+        lin = lambda p: (d(sd[p + '.weight']), d(sd[p + '.bias']))
+        self.head_mano = dict(l0=lin('head_mano.base_layer.0'), l2=lin('head_mano.base_layer.2'), pose=lin('head_mano.fc_pose'),
+                              shape=lin('head_mano.fc_shape'))
+
+        def cross(p):
+            a = p + '.attn.layers.0'
+            return dict(proj_hand=fold(p + '.proj_hand'), proj_obj=fold(p + '.proj_obj'),
+                        grav=(d(torch.nn.functional.pad(sd[p + '.gravity_proj.weight'], (0, 1))), d(sd[p + '.gravity_proj.bias'])),
+                        pe=d(sd[p + '.pose_embedder.pe'][:, 0, :]),
+                        in_proj=(d(sd[a + '.self_attn.in_proj_weight']), d(sd[a + '.self_attn.in_proj_bias'])),
+                        out_proj=lin(a + '.self_attn.out_proj'), l1=lin(a + '.linear1'), l2=lin(a + '.linear2'),
+                        n1=lin(a + '.norm1'), n2=lin(a + '.norm2'))
+
+        self.cross = dict(hand=cross('cross_hand'), obj=cross('cross_obj'))
+        self.phys = dict(s0=lin('head_physics.fc_scale.0'), s2=lin('head_physics.fc_scale.2'), w0=lin('head_physics.fc_weight.0'),
+                         w2=lin('head_physics.fc_weight.2'), anchor=d(sd['head_physics.anchor']))
+
+        # ---- sampler, MANO, aggregation tables ---------------------------------------------------------------------
+        self.score_hand = ops.ScoreNet(sd, 'denoiser_hand', dev)
+        self.score_obj = ops.ScoreNet(sd, 'denoiser_obj', dev)
+        mano = dict(v_template=sd['head_mano.mano_layer.th_v_template'][0], shapedirs=sd['head_mano.mano_layer.th_shapedirs'],
+                    posedirs=sd['head_mano.mano_layer.th_posedirs'], J_regressor=sd['head_mano.mano_layer.th_J_regressor'],
+                    weights=sd['head_mano.mano_layer.th_weights'])
+        self.mano = ops.Mano(mano, dev)
+        names = model.head_obj.names
+        ycb = {n: dict(kpt3d=sd[f'head_obj.point_{n}'], verts_sampled=sd[f'head_obj.vert_{n}'], CoM=sd[f'head_obj.CoM_{n}'][0]) for n in names}
+        self.agg = ops.Aggregation(dict(ycb=ycb, anchor=model.assets['anchor']), model.anchor_skeleton, dev)
+        self.last_info = {}
+
+    def stale(self, model):
+        return _signature(model) != self.sig
+
+    # ------------------------------------------------------------------------------------------------ feature path
+    def _bottleneck(self, x, b):
+        y = ops.conv2d_nhwc(x, *b['c1'], out_slope=0.01)
+        y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01)
+        r = x if b['down'] is None else ops.conv2d_nhwc(x, *b['down'], stride=b['stride'])
+        return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01)
+
+    def _layer(self, x, name):
+        for b in self.layers[name]:
+            x = self._bottleneck(x, b)
+        return x
+
+    def _fpn(self, rgb):
+        x = ops.nchw_to_nhwc(rgb, 4)
+        c1 = ops.maxpool_nhwc(ops.conv2d_nhwc(x, *self.stem, kh=7, kw=7, stride=2, pad=3, out_slope=0.01), 3, 2, 1)
+        c2 = self._layer(c1, 'layer1_h')
+        c3h, c3o = self._layer(c2, 'layer2_h'), self._layer(c2, 'layer2_o')
+        c4h, c4o = self._layer(c3h, 'layer3_h'), self._layer(c3o, 'layer3_o')
+        c5h, c5o = self._layer(c4h, 'layer4_h'), self._layer(c4o, 'layer4_h')          # shared layer4 (quirk Q6)
+        out = []
+        for br, c5, c4, c3 in (('h', c5h, c4h, c3h), ('o', c5o, c4o, c3o)):
+            p = ops.conv2d_nhwc(c5, *self.fpn[f'toplayer_{br}'])
+            for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2)):
+                q = ops.conv2d_nhwc(c, *self.fpn[lat])
+                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
+            out.append(ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1))
+        return out
+
+    def _hm_head(self, x, h):
+        y = ops.conv2d_nhwc(x, *h['c0'], kh=3, kw=3, pad=1)
+        y = ops.conv2d_nhwc(y, *h['c1'], kh=3, kw=3, pad=1)                              # BN folded; LeakyReLU(1.0) = identity (Q1)
+        N, H, W, _ = y.shape
+        co = h['deconv_b'].shape[0]
+        up = torch.empty((N, 2 * H, 2 * W, co), device=y.device)
+        for (py, px), (w, pady, padx) in h['deconv'].items():
+            ops.conv2d_nhwc(y, w, h['deconv_b'], kh=2, kw=2, pad_y=pady, pad_x=padx, out_hw=(H, W), out_slope=0.0,
+                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co))
+        return ops.conv2d_nhwc(up, *h['final'])
+
+    def _encoder(self, x, e):
+        x = ops.conv2d_nhwc(x, *e['project'])
+        stages = []
+        for i, b in enumerate(e['blocks']):
+            y = ops.conv2d_nhwc(x, *b['c1'], in_scale=b['pre'][0], in_shift=b['pre'][1], in_slope=0.01, out_slope=0.01)
+            y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, pad=1, out_slope=0.01)
+            x = ops.conv2d_nhwc(y, *b['c3'], res=x)
+            if i % 2 == 1:
+                x = ops.maxpool_nhwc(x, 2, 2, 0)
+                stages.append(x)
+        N = x.shape[0]
+        return ops.nhwc_to_nchw(x).view(N, -1), stages
+
+    def _cross(self, c, st_h, st_o, grav, flip_u8):
+        bs = st_h.shape[0]
+        ph = ops.conv2d_nhwc(st_h, *c['proj_hand'], kh=3, kw=3, pad=1)
+        po = ops.conv2d_nhwc(st_o, *c['proj_obj'], kh=3, kw=3, pad=1)
+        ge = ops.linear(ops.nerf_embed(grav, flip_u8), *c['grav'])
+        x = ops.cross_tokens(ph, po, ge, c['pe']).view(bs * 65, 512)
+        qkv = ops.linear(x, *c['in_proj'])
+        o = ops.linear(ops.mha(qkv, bs, 65, 512, 2).view(bs * 65, 512), *c['out_proj'])
+        x = ops.add_layernorm(x, o, *c['n1'])
+        ff = ops.linear(ops.linear(x, *c['l1'], out_slope=0.0), *c['l2'])
+        return ops.add_layernorm(x, ff, *c['n2'])                                       # (bs*65, 512)
+
+    def features(self, data):
+        """VPHO.py:112-172.  Returns a dict of device tensors (NHWC unless noted)."""
+        rgb = data['rgb'].float().contiguous()
+        bs = rgb.shape[0]
+        f32 = lambda k: data[k].float().contiguous()
+        is_right = data['is_right'].bool()
+        left_u8 = (~is_right).to(torch.uint8).contiguous()
+        R, HM = cfg.roi_size, cfg.heatmap_size
+        hand_feat, obj_feat = self._fpn(rgb)
+        bb_h, bb_o, bb_hr, bb_or = f32('bbox_hand'), f32('bbox_obj'), f32('bbox_hand_rect'), f32('bbox_obj_rect')
+        eh, eo = self.enc['hand'], self.enc['obj']
+        in_h = torch.zeros((bs, R, R, eh['cin_pad']), device=self.dev)
+        in_o = torch.zeros((bs, R, R, eo['cin_pad']), device=self.dev)
+        hf_hr = ops.roi_align_nhwc(hand_feat, bb_h, R, 0.25)
+        ops.roi_align_nhwc(hand_feat, bb_hr, R, 0.25, out=in_h)
+        of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25)
+        ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o)          # VPHO.py:138
+        hm_hand = self._hm_head(hf_hr, self.hm['hand'])                                  # (bs,64,64,21)
+        hm_obj = self._hm_head(of_or_rect, self.hm['obj'])                               # (bs,64,64,27)
+        ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_hand, bb_h, bb_hr), R, R, out=in_h, c_off=256)
+        ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_obj, bb_o, bb_or, flip_w=left_u8), R, R, out=in_o, c_off=256)
+        enc_h, st_h = self._encoder(in_h, eh)
+        enc_o, st_o = self._encoder(in_o, eo)
+        hmn = self.head_mano
+        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01), *hmn['l2'], out_slope=0.01)
+        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose']), 16)                  # (bs,48)
+        shape = ops.linear(h, *hmn['shape'])                                             # (bs,10)
+        ctx = self.mano.shape(shape)
+        ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
+        reg_vert, reg_joint = self.mano.fk(pose, ctx, 1, True, ho3d)
+        grav = f32('gravity').view(bs, 3)
+        tok_h = self._cross(self.cross['hand'], st_h[1], st_o[1], grav, left_u8)
+        tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
+        ph = self.phys
+        scale = ops.linear(ops.linear(tok_h, *ph['s0'], out_slope=0.01), *ph['s2'])      # (bs*65,1)
+        logits = ops.linear(ops.linear(tok_o, *ph['w0'], out_slope=0.01), *ph['w2'])     # (bs*65,8)
+        force_local = ops.force_local(scale, logits, ph['anchor'], bs * 32, 32, 65, 0, 32).view(bs, 32, 3)
+        return dict(hand_feat=hand_feat, obj_feat=obj_feat, hf_hr=hf_hr, enc_in_hand=in_h, enc_in_obj=in_o,
+                    hm_hand_nhwc=hm_hand, hm_obj_nhwc=hm_obj, hand_heatmap=ops.nhwc_to_nchw(hm_hand), obj_heatmap=ops.nhwc_to_nchw(hm_obj),
+                    encoding_hand=enc_h, encoding_obj=enc_o, stage_hand=st_h[1], stage_obj=st_o[1], mano_pose=pose, mano_shape=shape,
+                    mano_ctx=ctx, reg_hand_vert=reg_vert, reg_hand_joint=reg_joint, tok_hand=tok_h, tok_obj=tok_o, force_local=force_local)
+
+    # ------------------------------------------------------------------------------------------------ sampling
+    def _prior(self, rows, dim, T0):
+        """sde.py:26-28: CPU default generator, scaled by sigma(T0); drawn while the feature kernels are still running."""
+        return torch.randn(rows, dim) * (0.01 * (50 / 0.01) ** T0)
+
+    # ------------------------------------------------------------------------------------------------ aggregation
+    def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj):
+        """aggregation.py:1167-1353.  final58 (bs*S,58) f32, obj_pose (bs,S,9) f64."""
+        A, M = self.agg, self.mano
+        bs = obj_pose.shape[0]
+        f32 = lambda k: data[k].float().contiguous()
+        root_flip, root, Kmat = f32('root_joint_flip'), f32('root_joint'), f32('cam_intr_crop_flip').view(bs, 9)
+        bb_h, bb_or = f32('bbox_hand'), f32('bbox_obj_rect')
+        isr = data['is_right'].to(torch.uint8).contiguous()
+        ungrasp = (~data['is_grasped'].bool()).to(torch.uint8).contiguous()
+        oid = A.obj_ids(data['obj_name'])
+        ctx = f['mano_ctx']
+        dbg = dict(hand_topk=[], hand_val=[])
+        # 1. hand cascade
+        pose = A.hand_candidates(final58, f['mano_pose'], bs, S)
+        tp = None
+        for level in range(4):
+            observe = [j for l in range(level + 1, 5) for j in MANO_JOINT_LEVEL[l]]
+            _, joints = M.fk(pose.view(-1, 48), ctx, 2 * S, False)
+            hv = A.hand_heat(joints.view(bs, 2 * S, 21, 3), root_flip, Kmat, bb_h, f['hand_heatmap'], observe)
+            val, idx, tp = A.hand_fuse_level(hv, pose, k_hand, level, want_topk_pose=(level == 3))
+            dbg['hand_topk'].append(idx)
+            dbg['hand_val'].append(val)
+        fused_rows = pose.view(bs, 2 * S * 48)                                          # row b starts with candidate 0 = fused pose
+        agg_vert, _ = M.fk(fused_rows, ctx, 1, True)
+        fpnt, fglob = A.force_anchor(agg_vert, root_flip, f['force_local'], 1)
+        # 2-4. object
+        hm_o = f['obj_heatmap']
+        sc = A.obj_heat_score(obj_pose, root, oid, isr, Kmat, bb_or, hm_o)
+        tv, ti = A.topk(sc, k_obj)
+        transl = A.obj_fuse(obj_pose, ti.view(bs, -1), A.topk_weights(tv).view(bs, -1))[:, 6:].contiguous()
+        sc2 = A.obj_heat_score(obj_pose, root, oid, isr, Kmat, bb_or, hm_o, transl_override=transl)
+        _, ri = A.topk(sc2, k_obj)
+        cand = A.obj_cross(obj_pose, ti.view(bs, -1), ri.view(bs, -1))
+        ps = A.obj_physics_score(cand, root, oid, isr, fpnt, fglob)
+        _, pi = A.topk(ps, PHY_TOPK)
+        hs = A.obj_heat_score(cand, root, oid, isr, Kmat, bb_or, hm_o)
+        hval, hi = A.topk(hs, PHY_TOPK)
+        obj_fused = A.obj_fuse(cand, pi.view(bs, -1), None, hi.view(bs, -1), A.topk_weights(hval).view(bs, -1), ungrasp)
+        obj_vert = A.obj_verts(obj_fused, root, oid, isr)
+        # 5. hand distal joints by pseudo-force
+        cand58 = A.hand_phys_candidates(fused_rows, f['mano_shape'], tp)
+        n_c = cand58.shape[1]
+        cverts, _ = M.fk(cand58.view(-1, 58), ctx, n_c, True)
+        fp2, fg2 = A.force_anchor(cverts, root_flip, f['force_local'], n_c)
+        fs = A.hand_phys_score(fp2, fg2, obj_vert, bs, n_c)
+        _, fidx = A.topk(fs, PHY_TOPK, 5)
+        out58 = A.hand_phys_fuse(cand58, fidx)
+        out_vert, out_joint = M.fk(out58, ctx, 1, True)
+        dbg.update(transl_topk=ti, rot_topk=ri, phys_topk=pi, heat_topk=hi, phys_score=ps, hand_phys_topk=fidx, cand58=cand58,
+                   cascade_pose=fused_rows[:, :48], force_point=fpnt, force_global=fglob, obj_vert=obj_vert, pose6d_candidate=cand)
+        return dict(obj_agg_6d=obj_fused, hand_agg_mano=out58, hand_agg_vert=out_vert, hand_agg_joint=out_joint), dbg
+
+    # ------------------------------------------------------------------------------------------------ whole path
+    @torch.no_grad()
+    def predict(self, data, noise_hand=None, noise_obj=None):
+        S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
+        with torch.cuda.device(self.dev):
+            f = self.features(data)
+            bs = f['mano_pose'].shape[0]
+            sig = 0.01 * (50 / 0.01) ** T0
+            init_h = (self._prior(bs * S, 96, T0) if noise_hand is None else noise_hand.float().cpu() * sig)
+            init_o = (self._prior(bs * S, 9, T0) if noise_obj is None else noise_obj.float().cpu() * sig)
+            out = dict(reg_hand_vert=f['reg_hand_vert'], reg_hand_joint=f['reg_hand_joint'], hand_heatmap=f['hand_heatmap'],
+                       obj_heatmap=f['obj_heatmap'], force_local=f['force_local'])
+            # hand hypotheses
+            xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h.to(self.dev), S, T0, steps, xs_f64=False, x_f64=False)
+            inproc = torch.empty((bs * S * steps, 58), device=self.dev)
+            ops.rot6d_to_axis_angle(xs_h.view(bs * S * steps, 96), 16, out=inproc)
+            ops.append_betas(f['mano_shape'], inproc, S * steps)
+            final = torch.empty((bs * S, 58), device=self.dev)
+            ops.rot6d_to_axis_angle(x_h, 16, out=final)
+            ops.append_betas(f['mano_shape'], final, S)
+            out['diff_inprocess_hand_mano'] = inproc.view(bs, S, steps, 58)
+            out['diff_final_hand_mano'] = final.view(bs, S, 58)
+            ctx = f['mano_ctx']
+            viz = inproc.view(bs * S, steps, 58)[0, ::10].contiguous()                   # VPHO.py:250 (first sample, every 10th stamp)
+            vv, vj = self.mano.fk(viz, ctx, viz.shape[0], True)
+            out['diff_inprocess_hand_vert'], out['diff_inprocess_hand_joint'] = vv, vj
+            fv, fj = self.mano.fk(final, ctx, S, True)
+            out['diff_final_hand_vert'] = fv.view(bs, S, 778, 3)
+            out['diff_final_hand_joint'] = fj.view(bs, S, 21, 3)
+            # object hypotheses (stay fp64, quirk Q5)
+            xs_o, x_o, st_o = self.score_obj.sample(f['encoding_obj'], init_o.to(self.dev), S, T0, steps, xs_f64=True, x_f64=True)
+            out['diff_inprocess_obj_6d'] = xs_o.view(bs, S, steps, 9)
+            out['diff_final_obj_6d'] = x_o.view(bs, S, 9)
+            for name, st in (('hand', st_h), ('obj', st_o)):
+                if st['nan_count']:
+                    print("\033[31mWarning: NaN detected in score evaluation. \033[0m")
+            agg, dbg = self.aggregate(f, data, final, out['diff_final_obj_6d'], S, cfg.topk_hand, cfg.topk_obj)
+            out['agg_obj_6d'] = agg['obj_agg_6d']
+            out['agg_hand_mano'] = agg['hand_agg_mano']
+            out['agg_hand_vert'] = agg['hand_agg_vert']
+            out['agg_hand_joint'] = agg['hand_agg_joint']
+            self.last_info = dict(features=f, hand_ode=st_h, obj_ode=st_o, agg=dbg)
+        return out

@@ -130,7 +130,7 @@ lib.vpho_score_workspace_bytes.argtypes = [C.POINTER(ScoreWeights), C.c_int, C.c
 lib.vpho_score_eval.argtypes = [C.POINTER(ScoreWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p, C.c_longlong, C.c_void_p]
 lib.vpho_ode_sample.argtypes = [C.POINTER(ScoreWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double,
-                                C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong,
+                                C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong,
                                 C.POINTER(OdeStats), C.c_void_p, C.c_int, C.c_void_p]
 
 
@@ -178,20 +178,307 @@ class ScoreNet:
                                    _ptr(out), _ptr(ws), ws.numel(), _stream()))
         return out
 
-    def sample(self, feat_img, init_x, S, T0, num_steps, xs_f64, eps=1e-5, rtol=3e-3, atol=3e-4, log_cap=4096):
-        """cond_ode_sampler (score_based_model.py:45-105).  Returns xs (R,steps,D), x (R,D) f64, stats dict."""
+    def sample(self, feat_img, init_x, S, T0, num_steps, xs_f64, x_f64=True, eps=1e-5, rtol=3e-3, atol=3e-4, log_cap=4096):
+        """cond_ode_sampler (score_based_model.py:45-105).  Returns xs (R,steps,D), x (R,D), stats dict."""
         bs = feat_img.shape[0]
         R = bs * S
         assert init_x.shape == (R, self.D)
         ws = self.workspace(bs, S)
         xs = torch.empty((R, num_steps, self.D), device=self.device, dtype=torch.float64 if xs_f64 else torch.float32)
-        x = torch.empty((R, self.D), device=self.device, dtype=torch.float64)
+        x = torch.empty((R, self.D), device=self.device, dtype=torch.float64 if x_f64 else torch.float32)
         st = OdeStats()
         log = (C.c_double * (4 * log_cap))()
         _check(lib.vpho_ode_sample(C.byref(self.c), _ptr(feat_img, torch.float32), bs, S, _ptr(init_x, torch.float32),
                                    float(T0), float(eps), int(num_steps), float(rtol), float(atol), _ptr(xs),
-                                   1 if xs_f64 else 0, _ptr(x), _ptr(ws), ws.numel(), C.byref(st), log, log_cap, _stream()))
+                                   1 if xs_f64 else 0, _ptr(x), 1 if x_f64 else 0, _ptr(ws), ws.numel(), C.byref(st), log, log_cap,
+                                   _stream()))
         n = min(st.n_log, log_cap)
         steps = [(log[4 * i], log[4 * i + 1], log[4 * i + 2], bool(log[4 * i + 3])) for i in range(n)]
         return xs, x, dict(nfev=st.nfev, n_accepted=st.n_accepted, n_rejected=st.n_rejected, nan_count=st.nan_count,
                            steps=steps)
+
+
+# ----------------------------------------------------------------------------------------------- glue kernels
+def _i32(t):
+    return _ptr(t, torch.int32)
+
+
+def _u8(t):
+    return None if t is None else _ptr(t, torch.uint8)
+
+
+def _f32(t):
+    return None if t is None else _ptr(t, torch.float32)
+
+
+def _f64(t):
+    return None if t is None else _ptr(t, torch.float64)
+
+
+def _call(name, *args):
+    _check(getattr(lib, name)(*args, _stream()))
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+LL, I, F = C.c_longlong, C.c_int, C.c_float
+
+
+def nchw_to_nhwc(x, ld=None):
+    N, Cc, H, W = x.shape
+    ld = Cc if ld is None else ld
+    y = _new((N, H, W, ld), x)
+    _call('vpho_nchw_to_nhwc_f32', _f32(x), I(N), I(Cc), I(H), I(W), _f32(y), I(ld))
+    return y
+
+
+def nhwc_to_nchw(x, channels=None):
+    N, H, W, ld = x.shape
+    Cc = ld if channels is None else channels
+    y = _new((N, Cc, H, W), x)
+    _call('vpho_nhwc_to_nchw_f32', _f32(x), I(N), I(H), I(W), I(Cc), I(ld), _f32(y))
+    return y
+
+
+def maxpool_nhwc(x, k, stride, pad):
+    N, H, W, Cc = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = _new((N, OH, OW, Cc), x)
+    _call('vpho_maxpool_nhwc_f32', _f32(x), I(N), I(H), I(W), I(Cc), I(k), I(stride), I(pad), _f32(y))
+    return y
+
+
+def resize_bilinear_nhwc(x, OH, OW, out=None, c_off=0, accumulate=False, channels=None):
+    N, H, W, ldx = x.shape
+    Cc = ldx if channels is None else channels
+    if out is None:
+        out = _new((N, OH, OW, Cc), x)
+    assert out.shape[:3] == (N, OH, OW)
+    _call('vpho_resize_bilinear_nhwc_f32', _f32(x), I(N), I(H), I(W), I(Cc), I(ldx), I(OH), I(OW), _f32(out), I(out.shape[-1]),
+          I(c_off), I(1 if accumulate else 0))
+    return out
+
+
+def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, c_off=0):
+    N, H, W, Cc = feat.shape
+    if out is None:
+        out = _new((N, out_size, out_size, Cc), feat)
+    _call('vpho_roi_align_nhwc_f32', _f32(feat), I(N), I(H), I(W), I(Cc), _f32(boxes), F(spatial_scale), I(out_size), _u8(flip_w),
+          _f32(out), I(out.shape[-1]), I(c_off))
+    return out
+
+
+def align_heatmap_nhwc(hm, bbox, bbox_rect, flip_w=None):
+    N, S, _, Cc = hm.shape
+    out = torch.empty_like(hm)
+    _call('vpho_align_heatmap_nhwc_f32', _f32(hm), I(N), I(S), I(Cc), _f32(bbox), _f32(bbox_rect), _u8(flip_w), _f32(out))
+    return out
+
+
+def nerf_embed(g, flip_x=None):
+    N = g.shape[0]
+    out = _new((N, 64), g)
+    _call('vpho_nerf_embed_f32', _f32(g), I(N), _u8(flip_x), _f32(out))
+    return out
+
+
+def cross_tokens(proj_hand, proj_obj, grav_emb, pe):
+    bs = proj_hand.shape[0]
+    out = _new((bs, 65, 512), proj_hand)
+    _call('vpho_cross_tokens_f32', _f32(proj_hand), _f32(proj_obj), _f32(grav_emb), _f32(pe), I(bs), _f32(out))
+    return out
+
+
+def mha(qkv, S, B, E, nhead):
+    out = _new((S, B, E), qkv)
+    _call('vpho_mha_f32', _f32(qkv), I(S), I(B), I(E), I(nhead), _f32(out))
+    return out
+
+
+def add_layernorm(x, r, gamma, beta, eps=1e-5):
+    E = x.shape[-1]
+    out = torch.empty_like(x)
+    _call('vpho_add_layernorm_f32', _f32(x), _f32(r), _f32(gamma), _f32(beta), LL(x.numel() // E), I(E), F(eps), _f32(out))
+    return out
+
+
+def force_local(scale, logits, anchor, rows, group=1, group_stride=1, off_scale=0, off_logits=0, friction=0.8):
+    out = _new((rows, 3), scale)
+    _call('vpho_force_local_f32', _f32(scale), I(scale.shape[1]), _f32(logits), I(logits.shape[1]), _f32(anchor), F(friction), LL(rows),
+          I(group), I(group_stride), I(off_scale), I(off_logits), _f32(out))
+    return out
+
+
+def rot6d_to_axis_angle(x, rot_per_row, out=None, ldo=None):
+    rows, ldx = x.shape
+    if out is None:
+        out = _new((rows, 3 * rot_per_row), x)
+    _call('vpho_rot6d_to_axis_angle_f32', _f32(x), LL(rows), I(rot_per_row), I(ldx), _f32(out), I(out.shape[-1] if ldo is None else ldo))
+    return out
+
+
+def append_betas(betas, out, rows_per_image):
+    rows = out.numel() // out.shape[-1]
+    _call('vpho_append_betas_f32', _f32(betas), LL(rows), LL(rows_per_image), _f32(out), I(out.shape[-1]))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- MANO
+class ManoTables(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('v_template', 'shapedirs', 'posedirs_t', 'J_regressor', 'weights')]
+
+
+class Mano:
+    def __init__(self, mano, device):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
+        self.tensors = dict(v_template=t(mano['v_template']), shapedirs=t(mano['shapedirs']),
+                            posedirs_t=t(mano['posedirs']).reshape(778 * 3, 135).t().contiguous(),
+                            J_regressor=t(mano['J_regressor']), weights=t(mano['weights']))
+        self.c = ManoTables()
+        for k, v in self.tensors.items():
+            setattr(self.c, k, v.data_ptr())
+
+    def shape(self, betas):
+        n = betas.shape[0]
+        vs, J = _new((n, 778, 3), betas), _new((n, 16, 3), betas)
+        _call('vpho_mano_shape_f32', C.byref(self.c), _f32(betas), I(n), _f32(vs), _f32(J))
+        return vs, J
+
+    def fk(self, pose, shape_ctx, hands_per_image, want_verts=True, ho3d=None):
+        """pose (n, >=48) rows; shape_ctx = self.shape(betas).  -> verts (n,778,3)|None, joints (n,21,3)"""
+        n, ld = pose.shape
+        vs, J = shape_ctx
+        verts = _new((n, 778, 3), pose) if want_verts else None
+        joints = _new((n, 21, 3), pose)
+        _call('vpho_mano_fk_f32', C.byref(self.c), _f32(pose), I(ld), LL(n), I(hands_per_image), _f32(vs), _f32(J), _u8(ho3d),
+              _f32(verts), _f32(joints))
+        return verts, joints
+
+
+# ----------------------------------------------------------------------------------------------- aggregation
+class ObjTables(C.Structure):
+    _fields_ = [('kpt', C.c_void_p), ('vert', C.c_void_p), ('com', C.c_void_p), ('n_kpt', I), ('n_vert', I), ('n_obj', I)]
+
+
+class AnchorTables(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('face_idx', 'anchor_weight', 'vert2joint', 'skeleton')]
+
+
+class Aggregation:
+    """Device tables + thin wrappers of the aggregation kernels."""
+
+    def __init__(self, assets, anchor_skeleton, device):
+        ycb = assets['ycb']
+        self.names = list(ycb.keys())
+        self.name_to_id = {n: i for i, n in enumerate(self.names)}
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
+        stack = lambda key: torch.stack([torch.as_tensor(ycb[n][key], dtype=torch.float32).reshape(-1, 3) for n in self.names]).to(device).contiguous()
+        self.kpt, self.vert = stack('kpt3d'), stack('verts_sampled')
+        self.com = stack('CoM').reshape(len(self.names), 3).contiguous()
+        self.obj = ObjTables(self.kpt.data_ptr(), self.vert.data_ptr(), self.com.data_ptr(), self.kpt.shape[1], self.vert.shape[1], len(self.names))
+        a = assets['anchor']
+        self.face = torch.as_tensor(a['face_vert_idx'], dtype=torch.int32).to(device).contiguous()
+        self.aw = f(a['anchor_weight'])
+        self.v2j = f(a['vert2joint'])
+        self.skel = torch.as_tensor(anchor_skeleton, dtype=torch.int32).to(device).contiguous()
+        self.anchor = AnchorTables(self.face.data_ptr(), self.aw.data_ptr(), self.v2j.data_ptr(), self.skel.data_ptr())
+        self.device = device
+
+    def obj_ids(self, names):
+        return torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+
+    def hand_candidates(self, diff_pose, reg_pose, bs, S):
+        pose = _new((bs, 2 * S, 48), diff_pose)
+        _call('vpho_hand_candidates_f32', _f32(diff_pose), I(diff_pose.shape[-1]), _f32(reg_pose), I(bs), I(S), _f32(pose))
+        return pose
+
+    def hand_heat(self, joints, root, K, bbox, heatmap, observe):
+        bs, Cn = joints.shape[:2]
+        _, J, H, W = heatmap.shape
+        out = _new((bs, Cn, len(observe)), joints)
+        obs = (C.c_int * len(observe))(*observe)
+        _call('vpho_hand_heat_f32', _f32(joints), _f32(root), _f32(K), _f32(bbox), _f32(heatmap), I(bs), I(Cn), I(J), I(H), I(W), obs,
+              I(len(observe)), _f32(out))
+        return out
+
+    def hand_fuse_level(self, hv, pose, k, level, want_topk_pose=False):
+        bs, Cn, n_obs = hv.shape
+        Fn = 1 if level == 0 else 5
+        val, idx = _new((bs, Fn, k), hv), _new((bs, Fn, k), hv, torch.int32)
+        tp = _new((bs, k, Fn, 3), hv) if want_topk_pose else None
+        _call('vpho_hand_fuse_level_f32', _f32(hv), I(n_obs), _f32(pose), I(bs), I(Cn), I(k), I(level), _f32(val), _i32(idx), _f32(tp))
+        return val, idx, tp
+
+    def topk(self, scores, k, F_=1):
+        """scores (rows, n) [F_=1] or (rows, n, F_) -> val, idx (rows, F_, k)"""
+        rows, n = scores.shape[:2]
+        val, idx = _new((rows, F_, k), scores), _new((rows, F_, k), scores, torch.int32)
+        _call('vpho_topk_f32', _f32(scores), I(rows), I(n), I(F_), I(k), _f32(val), _i32(idx))
+        return val, idx
+
+    def topk_weights(self, val):
+        w = torch.empty_like(val)
+        _call('vpho_topk_weights_f32', _f32(val), I(val.numel() // val.shape[-1]), I(val.shape[-1]), _f32(w))
+        return w
+
+    def obj_heat_score(self, pose, root, obj_id, is_right, K, bbox, heatmap, transl_override=None):
+        bs, n = pose.shape[:2]
+        _, J, H, W = heatmap.shape
+        assert J == self.obj.n_kpt
+        score = _new((bs, n), root)
+        _call('vpho_obj_heat_score', _f64(pose), I(n), _f64(transl_override), _f32(root), C.byref(self.obj), _i32(obj_id), _u8(is_right),
+              _f32(K), _f32(bbox), _f32(heatmap), I(bs), I(H), I(W), _f32(score))
+        return score
+
+    def obj_cross(self, pose, transl_idx, rot_idx):
+        bs, n = pose.shape[:2]
+        ko = transl_idx.shape[-1]
+        cand = _new((bs, ko * ko, 9), pose, torch.float64)
+        _call('vpho_obj_cross_candidates', _f64(pose), I(n), _i32(transl_idx), _i32(rot_idx), I(bs), I(ko), _f64(cand))
+        return cand
+
+    def obj_physics_score(self, cand, root, obj_id, is_right, force_point, force_global):
+        bs, n = cand.shape[:2]
+        score = _new((bs, n), root)
+        _call('vpho_obj_physics_score', _f64(cand), I(n), _f32(root), C.byref(self.obj), _i32(obj_id), _u8(is_right), _f32(force_point),
+              _f32(force_global), I(bs), _f32(score))
+        return score
+
+    def obj_fuse(self, pose, idx_a, w_a, idx_b=None, w_b=None, pick_b=None):
+        bs, n = pose.shape[:2]
+        k = idx_a.shape[-1]
+        fused = _new((bs, 9), pose, torch.float64)
+        _call('vpho_obj_fuse_f64', _f64(pose), I(n), _i32(idx_a), _f32(w_a), None if idx_b is None else _i32(idx_b), _f32(w_b), _u8(pick_b),
+              I(bs), I(k), _f64(fused))
+        return fused
+
+    def obj_verts(self, pose, root, obj_id, is_right):
+        bs = pose.shape[0]
+        out = _new((bs, self.obj.n_vert, 3), root)
+        _call('vpho_obj_verts_f32', _f64(pose), _f32(root), C.byref(self.obj), _i32(obj_id), _u8(is_right), I(bs), _f32(out))
+        return out
+
+    def force_anchor(self, verts, root, force_local_, hands_per_image):
+        n = verts.shape[0]
+        fp, fg = _new((n, 32, 3), verts), _new((n, 32, 3), verts)
+        _call('vpho_force_anchor_f32', C.byref(self.anchor), _f32(verts), _f32(root), _f32(force_local_), LL(n), I(hands_per_image), _f32(fp), _f32(fg))
+        return fp, fg
+
+    def hand_phys_candidates(self, agg_pose, betas, topk_pose):
+        bs, k = topk_pose.shape[:2]
+        out = _new((bs, k + 1, 58), agg_pose)
+        _call('vpho_hand_phys_candidates_f32', _f32(agg_pose), I(agg_pose.shape[-1]), _f32(betas), _f32(topk_pose), I(bs), I(k), _f32(out))
+        return out
+
+    def hand_phys_score(self, force_point, force_global, obj_vert, bs, n_cand):
+        out = _new((bs, n_cand, 5), force_point)
+        _call('vpho_hand_phys_score_f32', _f32(force_point), _f32(force_global), _f32(obj_vert), I(obj_vert.shape[1]), I(bs), I(n_cand), _f32(out))
+        return out
+
+    def hand_phys_fuse(self, cand, idx):
+        bs, n_cand = cand.shape[:2]
+        out = _new((bs, 58), cand)
+        _call('vpho_hand_phys_fuse_f32', _f32(cand), I(n_cand), _i32(idx), I(bs), I(idx.shape[-1]), _f32(out))
+        return out
