@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: eval images/s of ``vpho_net.forward(mode='predict')`` at the README config
+(bs=64 per GPU, sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.65) on synthetic 256x256 crops.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one forward pass over one per-rank batch (inputs resident in HBM), incl. the CPU prior draw the reference
+makes (sde.py:26-28); after the K timed steps the ranks exchange their per-image metric rows with ONE all-gather.
+Prints one JSON line (rank 0) with `roofline` (dominant kernel: conv_igemm 128x128 tile, timed with HIP events on its
+launch stream during the timed steps) and `cpu_baseline` (the oracle on the host cores, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FEATURE_GFLOP_PER_IMAGE = 37.09
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--bs', type=int, default=64)
+    p.add_argument('--sample_num', type=int, default=100)
+    p.add_argument('--sampling_steps', type=int, default=50)
+    p.add_argument('--topk_hand', type=int, default=30)
+    p.add_argument('--topk_obj', type=int, default=10)
+    p.add_argument('--sample_T0', type=float, default=0.65)
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--no_kernel_timing', action='store_true')
+    p.add_argument('--cpu_images', type=int, default=2)
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    sys.argv = sys.argv[:1]
+    import torch
+    import torch.distributed as dist
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_state_dict, synth_batch
+    from vpho_amd.assets import synthetic_assets, ANCHOR_SKELETON
+    from vpho_amd import ops, evaluate as E
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = \
+        args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj, args.sample_T0
+    assets = synthetic_assets(0)
+    model = vpho_net(assets)
+    sd = synth_state_dict(model, seed=1)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    torch.manual_seed(206 + rank * 100000000)            # base_trainer.py:39-50 (seed + rank*1e8)
+    batches = []
+    for i in range(2):                                    # two resident batches, alternated
+        b = synth_batch(args.bs, assets, seed=206 + i, rank=rank)
+        batches.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+    # synthetic ground truth for the metric rows: MANO FK of a seeded small pose (through the HIP FK)
+    from vpho_amd.model.engine import Engine
+    model._engine = Engine(model)
+    eng = model._engine
+    g = torch.Generator().manual_seed(1234 + rank)
+    gt_pose = (torch.randn(args.bs, 48, generator=g) * 0.2).to(dev)
+    gt_ctx = eng.mano.shape((torch.randn(args.bs, 10, generator=g) * 0.5).to(dev))
+    gt_vert, gt_joint = eng.mano.fk(gt_pose, gt_ctx, 1, True)
+    gt_vert = gt_vert + batches[0]['root_joint'][:, None]
+    gt_joint = gt_joint + batches[0]['root_joint'][:, None]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rows = []
+    nfev = []
+    for i in range(args.warmup):
+        model(batches[i % 2], mode='predict')
+    barrier()
+    ops.prof_enable('conv_igemm_128x128', not args.no_kernel_timing)
+    ops.prof_enable('score_head', not args.no_kernel_timing)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = model(batches[i % 2], mode='predict')
+        rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * args.steps + i) * args.bs))
+        nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
+    all_rows = E.gather_rows(torch.cat(rows, 0))          # the ONE collective of the evaluation
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.prof_enable('conv_igemm_128x128', False)
+    ops.prof_enable('score_head', False)
+    conv = ops.prof_collect('conv_igemm_128x128')
+    head = ops.prof_collect('score_head')
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert all_rows.shape[0] == world * args.steps * args.bs
+
+    result = None
+    if rank == 0:
+        images = world * args.steps * args.bs
+        conv_tf = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
+        head_tf = head['flops'] / (head['total_ms'] * 1e-3) / 1e12 if head['total_ms'] > 0 else 0.0
+        result = {
+            'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
+            'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'vpho_net.forward(mode=predict) README eval config (BASELINE.json configs[1])',
+                       'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
+                       'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
+                       'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
+                       'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128> (fp32 MFMA implicit GEMM)', 'achieved': conv_tf,
+                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'launches_per_step': conv['launches'] / max(args.steps, 1),
+                         'avg_launch_us': conv['total_ms'] * 1e3 / max(conv['launches'], 1),
+                         'flop_per_launch_avg': conv['flops'] / max(conv['launches'], 1),
+                         'kernel_ms_per_step': conv['total_ms'] / max(args.steps, 1),
+                         'score_head': {'achieved': head_tf, 'frac': head_tf / FP32_MFMA_PEAK_TFLOPS,
+                                        'kernel_ms_per_step': head['total_ms'] / max(args.steps, 1),
+                                        'launches_per_step': head['launches'] / max(args.steps, 1)},
+                         'feature_path_gflop_per_image_ref': FEATURE_GFLOP_PER_IMAGE},
+            'metrics_rows_gathered': int(all_rows.shape[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result.update(cpu_baseline_leg(args, cfg, model, sd, assets, ANCHOR_SKELETON, dev))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload + MPJPE delta of the HIP path
+    against it on identical inputs and identical prior draws."""
+    import torch
+    from oracle import vpho as OV
+    from vpho_amd.synth import synth_batch
+    n = args.cpu_images
+    data = synth_batch(n, assets, seed=777)
+    torch.manual_seed(99)
+    nh, no = torch.randn(n * args.sample_num, 96), torch.randn(n * args.sample_num, 9)
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    ref, info = OV.predict(sd, assets, skeleton, data, sample_num=args.sample_num, sample_T0=args.sample_T0,
+                           sampling_steps=args.sampling_steps, topk_hand=args.topk_hand, topk_obj=args.topk_obj,
+                           noise_hand=nh, noise_obj=no)
+    t_cpu = time.perf_counter() - t0
+    gdata = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+    out = model._engine.predict(gdata, noise_hand=nh, noise_obj=no)
+    torch.cuda.synchronize()
+    d = (out['agg_hand_joint'].double().cpu() - ref['agg_hand_joint'].double())
+    mpjpe_delta_mm = float(d.norm(dim=-1).mean() * 1000)
+    return {'cpu_baseline': {'value': n / t_cpu, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+                             'sample': f'{n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
+                                       f'(torch-CPU + host RK45), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
+            'parity': {'mpjpe_delta_mm': mpjpe_delta_mm,
+                       'max_abs_agg_hand_joint': float(d.abs().max()),
+                       'max_abs_agg_hand_vert': float((out['agg_hand_vert'].double().cpu() - ref['agg_hand_vert'].double()).abs().max()),
+                       'max_abs_agg_obj_6d': float((out['agg_obj_6d'].double().cpu() - ref['agg_obj_6d'].double()).abs().max()),
+                       'nfev_equal': [model._engine.last_info['hand_ode']['nfev'] == info['hand_ode']['nfev'],
+                                      model._engine.last_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
+                       'sample': f'{n} images, identical inputs and prior draws'}}
+
+
+if __name__ == '__main__':
+    main()

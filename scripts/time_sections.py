@@ -1,0 +1,35 @@
+"""Wall-time breakdown of one predict step (synchronising between sections) at the README config."""
+import sys, time
+import torch
+sys.argv = sys.argv[:1]
+sys.path.insert(0, '.')
+from vpho_amd.configs.args import cfg
+from vpho_amd.model.VPHO import vpho_net
+from vpho_amd.synth import synth_state_dict, synth_batch
+from vpho_amd.assets import synthetic_assets
+from vpho_amd.model.engine import Engine
+from vpho_amd import ops
+
+cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 100, 50, 30, 10, 0.65
+a = synthetic_assets(0)
+m = vpho_net(a); m.load_state_dict(synth_state_dict(m, 1)); m = m.cuda().eval()
+data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(64, a).items()}
+eng = Engine(m)
+S, T0, steps, bs = 100, 0.65, 50, 64
+def sync(): torch.cuda.synchronize(); return time.perf_counter()
+for it in range(3):
+    t = [sync()]
+    f = eng.features(data); t.append(sync())
+    init_h = eng._prior(bs * S, 96, T0); init_o = eng._prior(bs * S, 9, T0); t.append(sync())
+    ih, io = init_h.cuda(), init_o.cuda(); t.append(sync())
+    xs_h, x_h, st_h = eng.score_hand.sample(f['encoding_hand'], ih, S, T0, steps, xs_f64=False, x_f64=False); t.append(sync())
+    inproc = torch.empty((bs * S * steps, 58), device='cuda'); ops.rot6d_to_axis_angle(xs_h.view(bs * S * steps, 96), 16, out=inproc)
+    ops.append_betas(f['mano_shape'], inproc, S * steps)
+    final = torch.empty((bs * S, 58), device='cuda'); ops.rot6d_to_axis_angle(x_h, 16, out=final); ops.append_betas(f['mano_shape'], final, S)
+    fv, fj = eng.mano.fk(final, f['mano_ctx'], S, True); t.append(sync())
+    xs_o, x_o, st_o = eng.score_obj.sample(f['encoding_obj'], io, S, T0, steps, xs_f64=True, x_f64=True); t.append(sync())
+    agg, dbg = eng.aggregate(f, data, final, x_o.view(bs, S, 9), S, 30, 10); t.append(sync())
+    names = ['features', 'prior randn (CPU)', 'H2D noise', 'hand sampler', 'postprocess+FK', 'obj sampler', 'aggregate']
+    print(' | '.join(f'{n} {1e3 * (t[i + 1] - t[i]):.1f}' for i, n in enumerate(names)), '| total', f'{1e3 * (t[-1] - t[0]):.1f} ms')
+# feature sub-sections
+t0 = sync(); hf, of = eng._fpn(data['rgb']); t1 = sync(); print('fpn only', 1e3 * (t1 - t0))

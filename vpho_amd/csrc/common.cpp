@@ -1,4 +1,7 @@
 #include "common.h"
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "../../include/vpho_hip.h"
 
 namespace vpho {
@@ -11,7 +14,41 @@ int fail(const char* fmt, ...) {
     va_end(ap);
     return 1;
 }
+
+struct ProfState { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; };
+static ProfState g_prof[PROF_NCLASS];
+static std::mutex g_prof_mu;
+bool prof_on(int cls) { return g_prof[cls].on; }
+void prof_record(int cls, hipEvent_t a, hipEvent_t b, double flops) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof[cls].ev.emplace_back(a, b);
+    g_prof[cls].flops += flops;
+}
 }  // namespace vpho
+
+extern "C" int vpho_prof_enable(int cls, int on) {
+    VPHO_REQUIRE(cls >= 0 && cls < vpho::PROF_NCLASS, "vpho_prof_enable: class %d", cls);
+    vpho::g_prof[cls].on = on != 0;
+    return 0;
+}
+
+extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches, double* total_flops) {
+    VPHO_REQUIRE(cls >= 0 && cls < vpho::PROF_NCLASS && total_ms && launches && total_flops, "vpho_prof_collect: bad argument");
+    std::lock_guard<std::mutex> l(vpho::g_prof_mu);
+    auto& st = vpho::g_prof[cls];
+    double ms = 0;
+    for (auto& e : st.ev) {
+        VPHO_HIP(hipEventSynchronize(e.second));
+        float t = 0;
+        VPHO_HIP(hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    *total_ms = ms; *launches = (long long)st.ev.size(); *total_flops = st.flops;
+    st.ev.clear(); st.flops = 0;
+    return 0;
+}
 
 extern "C" const char* vpho_last_error(void) { return vpho::err_slot(); }
 extern "C" int vpho_abi_version(void) { return 1; }

@@ -2,7 +2,7 @@
 //
 // GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  NHWC activations make every (r,s) slice of an im2col
 // row a contiguous channel run, so the A tile is gathered with 16-byte loads; weights are pre-packed [Cout][K].
-// Block = 256 threads = 4 waves in a 2x2 arrangement; block tile BMxBN (128x128 or 64x64), BK = 32.  Both LDS tiles
+// Block = WMxWN waves; block tile BMxBN (128x128 and 128x64 with 8 waves, 64x64 with 4 waves), BK = 32.  Both LDS tiles
 // are K-contiguous with a 4-float pad (row stride 36 floats): each lane fetches 4 consecutive k of its row with one
 // conflict-free ds_read_b128 and feeds them to 4 MFMAs (lanes 0-31 supply k = 4h+q of one half, lanes 32-63 the other;
 // A and B use the same k permutation so the sum is unchanged).  Global->register prefetch of tile k+1 overlaps the
@@ -12,6 +12,7 @@
 // Roofline: fp32 MFMA, 2*M*N*K flop per launch against 157.3 TFLOP/s.
 #include "common.h"
 #include "../../include/vpho_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -24,10 +25,13 @@ struct Geo {
     int y_linear, r_linear;
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A_LD = BM / 32, B_LD = BN / 32;
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
+    constexpr int NT = 64 * WM * WN;                  // threads per block; waves arranged WM x WN
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int ROWS = NT / 8;                      // tile rows covered by one pass of 16-byte loads
+    constexpr int A_LD = BM / ROWS, B_LD = BN / ROWS;
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile too small for the wave layout");
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
 
     const vpho_conv_desc& d = g.d;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int kq = tid & 7, lrow = tid >> 3;
 
     // per-thread A rows (output pixels) -> input coordinates
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
     const int ohw = d.OH * d.OW;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        int m = m0 + lrow + 32 * j;
+        int m = m0 + lrow + ROWS * j;
         if (m < g.M) {
             int n = m / ohw, rem = m - n * ohw;
             int oy = rem / d.OW, ox = rem - oy * d.OW;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int n = n0 + lrow + 32 * j;
+            int n = n0 + lrow + ROWS * j;
             if (kin && n < d.Cout) v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * g.K + kg);
             rb[j] = v;
         }
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
         float* As = smem + buf * (BM + BN) * LDS_LD;
         float* Bs = As + BM * LDS_LD;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_LD + 4 * kq) = ra[j];
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(As + (lrow + ROWS * j) * LDS_LD + 4 * kq) = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + 4 * kq) = rb[j];
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + ROWS * j) * LDS_LD + 4 * kq) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
-        const float* Bs = smem + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+        const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + li) * LDS_LD + 4 * lh;
+        const float* Bs = smem + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * (BN / WN) + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a[TM], b[TN];
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const Geo g) {
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+        const int col = n0 + wn * (BN / WN) + j * 32 + li;
         if (col >= d.Cout) continue;
         const float bv = d.bias ? d.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (row >= g.M) continue;
                 long long yo, ro = 0;
                 if (g.y_linear && g.r_linear) {
@@ -197,16 +201,27 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
-    if (big_tiles >= 192 && d.Cout >= 96) {
-        g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (d.Cout + 127) / 128;
+    const double flops = 2.0 * (double)M * d.Cout * g.K;
+    static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
+    // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
+    // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
+    const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64);
+    int variant = 64;
+    if (big_tiles >= 512 && d.Cout % 128 == 0) variant = 1288;
+    else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
+    if (force_tile) variant = force_tile;
+    auto launch = [&](auto kernel, int bm, int bn, int threads, int cls) {
+        vpho::ProfScope prof(cls, s, flops);
+        g.tiles_m = (int)((M + bm - 1) / bm); g.tiles_n = (d.Cout + bn - 1) / bn;
         g.ntiles = g.tiles_m * g.tiles_n;
-        int grid = (g.ntiles + 7) / 8 * 8;
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), dim3(grid), dim3(256), 0, s, g);
-    } else {
-        g.tiles_m = (int)((M + 63) / 64); g.tiles_n = (d.Cout + 63) / 64;
-        g.ntiles = g.tiles_m * g.tiles_n;
-        int grid = (g.ntiles + 7) / 8 * 8;
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(threads), 0, s, g);
+    };
+    switch (variant) {
+        case 128:  launch(conv_igemm_kernel<128, 128, 2, 2>, 128, 128, 256, vpho::PROF_CONV128); break;
+        case 1288: launch(conv_igemm_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128); break;
+        case 12864: launch(conv_igemm_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128); break;
+        case 1264: launch(conv_igemm_kernel<128, 64, 2, 2>, 128, 64, 256, vpho::PROF_CONV128); break;
+        default:   launch(conv_igemm_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64); break;
     }
     return vpho::check_launch("conv_igemm_kernel");
 }

@@ -231,12 +231,18 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const NormArgs a) {
     }
     if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
 }
-__global__ void norm_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += partial[i];
-        *out = s;
+// fixed-order (deterministic) tree sum of the per-block partials
+__global__ __launch_bounds__(256) void norm_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *out = red[0];
 }
 
 // dense output (scipy RkDenseOutput): y_old + h * (K^T P) . [x, x^2, x^3, x^4]
@@ -342,7 +348,10 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(256), lds, c.s, a);
+    {
+        vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
+        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(256), lds, c.s, a);
+    }
     return vpho::check_launch("score_head_kernel");
 }
 
@@ -364,7 +373,7 @@ int reduce_norm(Ctx& c, NormArgs na, double* value) {
     const int nb = (int)std::min<long long>(1024, (c.n_el + 255) / 256);
     na.n_el = c.n_el; na.partial = c.ws.partial;
     hipLaunchKernelGGL(norm_partial_kernel, dim3(nb), dim3(256), 0, c.s, na);
-    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(64), 0, c.s, c.ws.partial, nb, c.ws.result);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, c.s, c.ws.partial, nb, c.ws.result);
     if (int e = vpho::check_launch("norm kernels")) return e;
     double* h = pinned_slot();
     VPHO_REQUIRE(h != nullptr, "hipHostMalloc failed");

@@ -1,0 +1,78 @@
+"""Evaluation loop of the hot path: per-rank batches, per-image metric rows, ONE fixed-layout all-gather.
+
+Counterpart of the reference's ``Trainer.evaluate`` / ``postprocess`` (lib/engine/train_diff_hand_obj.py:202-357,578-602)
+for synthetic batches.  The reference gathers pickled nested dicts with ``gather_for_metrics(use_gather_object=True)``
+(:333-335); here every rank fills a ``(n_images, ROW)`` fp32 tensor on its GPU and the ranks exchange it with a single
+``torch.distributed.all_gather_into_tensor`` (RCCL over xGMI with backend 'nccl', gloo on CPU for tests).
+The forward pass itself needs no collective: the image batch is the only sharded dimension.
+"""
+import torch
+import torch.distributed as dist
+
+# row layout: [global image index, MJE(regression), MJE(first hypothesis), MJE(aggregated), MVE(aggregated),
+#              |agg - regression| mean joint distance (mm), object translation norm (m), is_right]
+ROW = 8
+
+
+def mje_mm(pd, gt):
+    """TesterHand MJE (test.py:657-668): mean over joints of the L2 distance, millimetres."""
+    return (pd - gt).norm(dim=-1).mean(dim=-1) * 1000.0
+
+
+def postprocess(out, root_joint, is_right):
+    """train_diff_hand_obj.py:578-602: un-flip left hands along x and add the root joint (hand outputs only)."""
+    sgn = torch.where(is_right.bool(), 1.0, -1.0).to(out['agg_hand_joint'].dtype)[:, None, None]
+    res = {}
+    for k in ('reg_hand_joint', 'agg_hand_joint', 'reg_hand_vert', 'agg_hand_vert'):
+        v = out[k].clone()
+        v[..., 0] = v[..., 0] * sgn[..., 0]
+        res[k] = v + root_joint[:, None]
+    first = out['diff_final_hand_joint'][:, 0].clone()
+    first[..., 0] = first[..., 0] * sgn[..., 0]
+    res['first_hand_joint'] = first + root_joint[:, None]
+    return res
+
+
+def metric_rows(out, data, gt_joint, gt_vert, first_index):
+    """(bs, ROW) fp32 on the model's device."""
+    pp = postprocess(out, data['root_joint'], data['is_right'])
+    bs = gt_joint.shape[0]
+    rows = torch.empty((bs, ROW), device=gt_joint.device, dtype=torch.float32)
+    rows[:, 0] = torch.arange(first_index, first_index + bs, device=rows.device, dtype=torch.float32)
+    rows[:, 1] = mje_mm(pp['reg_hand_joint'], gt_joint)
+    rows[:, 2] = mje_mm(pp['first_hand_joint'], gt_joint)
+    rows[:, 3] = mje_mm(pp['agg_hand_joint'], gt_joint)
+    rows[:, 4] = mje_mm(pp['agg_hand_vert'], gt_vert)
+    rows[:, 5] = mje_mm(pp['agg_hand_joint'], pp['reg_hand_joint'])
+    rows[:, 6] = out['agg_obj_6d'][:, 6:].float().norm(dim=-1)
+    rows[:, 7] = data['is_right'].float()
+    return rows
+
+
+def gather_rows(rows):
+    """All ranks' rows, concatenated in rank order: (world * n, ROW).  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    out = torch.empty((world * rows.shape[0], rows.shape[1]), device=rows.device, dtype=rows.dtype)
+    dist.all_gather_into_tensor(out, rows.contiguous())
+    return out
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for strong-scaling splits of one global batch."""
+    per = (n_items + world - 1) // world
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)
+
+
+def summarize(rows):
+    """Table like train_diff_hand_obj.py:336-357 for right / left / both hands."""
+    res = {}
+    for name, mask in (('right', rows[:, 7] > 0.5), ('left', rows[:, 7] < 0.5), ('both', torch.ones_like(rows[:, 7], dtype=torch.bool))):
+        sel = rows[mask]
+        if sel.shape[0] == 0:
+            continue
+        res[name] = dict(n=int(sel.shape[0]), MJE_reg=float(sel[:, 1].mean()), MJE_first=float(sel[:, 2].mean()),
+                         MJE_agg=float(sel[:, 3].mean()), MVE_agg=float(sel[:, 4].mean()))
+    return res

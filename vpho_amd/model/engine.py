@@ -15,8 +15,13 @@ PHY_TOPK = 5          # aggregation.py:1246
 
 
 def _signature(model):
-    return (tuple(int(t._version) for t in model.state_dict(keep_vars=True).values()),
-            str(next(model.parameters()).device))
+    """Cheap change detector for the packed weights: in-place version counters + storage addresses of all tensors."""
+    import itertools
+    v = p = 0
+    for t in itertools.chain(model.parameters(), model.buffers()):
+        v += t._version
+        p ^= t.data_ptr()
+    return v, p, str(next(model.parameters()).device)
 
 
 class Engine:
@@ -213,7 +218,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ sampling
     def _prior(self, rows, dim, T0):
         """sde.py:26-28: CPU default generator, scaled by sigma(T0); drawn while the feature kernels are still running."""
-        return torch.randn(rows, dim) * (0.01 * (50 / 0.01) ** T0)
+        # same generator stream as torch.randn(rows, dim), drawn straight into pinned memory (one DMA to the GPU)
+        return torch.empty((rows, dim), pin_memory=True).normal_().mul_(0.01 * (50 / 0.01) ** T0)
 
     # ------------------------------------------------------------------------------------------------ aggregation
     def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj):
@@ -278,10 +284,11 @@ class Engine:
             sig = 0.01 * (50 / 0.01) ** T0
             init_h = (self._prior(bs * S, 96, T0) if noise_hand is None else noise_hand.float().cpu() * sig)
             init_o = (self._prior(bs * S, 9, T0) if noise_obj is None else noise_obj.float().cpu() * sig)
+            init_h, init_o = init_h.to(self.dev, non_blocking=True), init_o.to(self.dev, non_blocking=True)
             out = dict(reg_hand_vert=f['reg_hand_vert'], reg_hand_joint=f['reg_hand_joint'], hand_heatmap=f['hand_heatmap'],
                        obj_heatmap=f['obj_heatmap'], force_local=f['force_local'])
             # hand hypotheses
-            xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h.to(self.dev), S, T0, steps, xs_f64=False, x_f64=False)
+            xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h, S, T0, steps, xs_f64=False, x_f64=False)
             inproc = torch.empty((bs * S * steps, 58), device=self.dev)
             ops.rot6d_to_axis_angle(xs_h.view(bs * S * steps, 96), 16, out=inproc)
             ops.append_betas(f['mano_shape'], inproc, S * steps)
@@ -298,7 +305,7 @@ class Engine:
             out['diff_final_hand_vert'] = fv.view(bs, S, 778, 3)
             out['diff_final_hand_joint'] = fj.view(bs, S, 21, 3)
             # object hypotheses (stay fp64, quirk Q5)
-            xs_o, x_o, st_o = self.score_obj.sample(f['encoding_obj'], init_o.to(self.dev), S, T0, steps, xs_f64=True, x_f64=True)
+            xs_o, x_o, st_o = self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
             out['diff_inprocess_obj_6d'] = xs_o.view(bs, S, steps, 9)
             out['diff_final_obj_6d'] = x_o.view(bs, S, 9)
             for name, st in (('hand', st_h), ('obj', st_o)):

@@ -482,3 +482,17 @@ class Aggregation:
         out = _new((bs, 58), cand)
         _call('vpho_hand_phys_fuse_f32', _f32(cand), I(n_cand), _i32(idx), I(bs), I(idx.shape[-1]), _f32(out))
         return out
+
+
+# ----------------------------------------------------------------------------------------------- profiling hooks
+PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2}
+
+
+def prof_enable(name, on=True):
+    _check(lib.vpho_prof_enable(I(PROF_CLASSES[name]), I(1 if on else 0)))
+
+
+def prof_collect(name):
+    ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+    _check(lib.vpho_prof_collect(I(PROF_CLASSES[name]), C.byref(ms), C.byref(n), C.byref(fl)))
+    return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
