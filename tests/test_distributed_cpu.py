@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 gloo process group, the single all-gather of fixed-layout metric rows, sharding."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vpho_amd import evaluate as E
+    n = 5
+    rows = torch.zeros((n, E.ROW))
+    rows[:, 0] = torch.arange(rank * n, rank * n + n)
+    rows[:, 3] = 10.0 * (rank + 1)
+    rows[:, 7] = rank % 2
+    g = E.gather_rows(rows)
+    q.put((rank, g.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    from vpho_amd import evaluate as E
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        g = got[r]
+        assert g.shape == (10, E.ROW)
+        assert torch.equal(g[:, 0], torch.arange(10, dtype=torch.float32))      # rank order, every image exactly once
+        assert torch.equal(g[:5, 3], torch.full((5,), 10.0)) and torch.equal(g[5:, 3], torch.full((5,), 20.0))
+    s = E.summarize(got[0])
+    assert s['both']['n'] == 10 and s['right']['n'] == 5 and s['left']['n'] == 5
+    assert s['both']['MJE_agg'] == pytest.approx(15.0)
+
+
+def test_gather_rows_without_process_group_is_identity():
+    from vpho_amd import evaluate as E
+    rows = torch.randn(3, E.ROW)
+    assert E.gather_rows(rows) is rows
+
+
+@pytest.mark.parametrize('n,world', [(64, 8), (64, 3), (5, 8), (0, 4)])
+def test_shard_range_partitions_exactly(n, world):
+    from vpho_amd.evaluate import shard_range
+    seen = []
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        assert 0 <= lo <= hi <= n
+        seen += list(range(lo, hi))
+    assert seen == list(range(n))
+
+
+def test_metric_rows_and_postprocess_cpu():
+    """postprocess un-flips left hands and adds the root (train_diff_hand_obj.py:578-602); MJE in millimetres."""
+    from vpho_amd import evaluate as E
+    bs = 4
+    g = torch.Generator().manual_seed(0)
+    out = dict(reg_hand_joint=torch.randn(bs, 21, 3, generator=g) * 0.05, agg_hand_joint=torch.randn(bs, 21, 3, generator=g) * 0.05,
+               reg_hand_vert=torch.randn(bs, 778, 3, generator=g) * 0.05, agg_hand_vert=torch.randn(bs, 778, 3, generator=g) * 0.05,
+               diff_final_hand_joint=torch.randn(bs, 6, 21, 3, generator=g) * 0.05, agg_obj_6d=torch.randn(bs, 9, generator=g).double())
+    data = dict(root_joint=torch.randn(bs, 3, generator=g), is_right=torch.tensor([True, False, True, False]))
+    pp = E.postprocess(out, data['root_joint'], data['is_right'])
+    exp = out['agg_hand_joint'].clone()
+    exp[1, :, 0] *= -1
+    exp[3, :, 0] *= -1
+    assert torch.allclose(pp['agg_hand_joint'], exp + data['root_joint'][:, None])
+    rows = E.metric_rows(out, data, pp['agg_hand_joint'], pp['agg_hand_vert'], first_index=8)
+    assert rows.shape == (bs, E.ROW)
+    assert torch.equal(rows[:, 0], torch.tensor([8., 9., 10., 11.]))
+    assert torch.allclose(rows[:, 3], torch.zeros(bs), atol=1e-4) and torch.allclose(rows[:, 4], torch.zeros(bs), atol=1e-4)
+    assert torch.all(rows[:, 1] > 1.0)
