@@ -5,7 +5,8 @@
 //   block (row tile of 128 hypotheses, head n): H^T[256 x 128] = W1p[n] (256x256, "A") x P2^T ("B") on fp32 MFMA with the
 //   hidden unit on the accumulator ROW (registers) and the hypothesis on the COLUMN (lane), so that the second
 //   ParallelLinear (256 -> 3) is a register-local dot product followed by ONE cross-half shuffle; the (R x 8192) hidden
-//   activation never leaves the CU.  Each wave owns 32 hypotheses x all 256 hidden units (8 MFMA row tiles).
+//   activation never leaves the CU.  8 waves: each owns 32 hypotheses x 128 hidden units (4 MFMA row tiles); the two
+//   hidden halves of a hypothesis are combined through LDS.
 // Roofline: fp32 MFMA; algorithmic flop per evaluation in the restructured formulation =
 //   R * (2*Dp*256 + 2*256*256 + nheads*(2*256*256 + 2*256*3)) (+ once per image 2*1024*NH, once per eval 2*128*NH).
 //
@@ -24,9 +25,12 @@ constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
 // --------------------------------------------------------------------------------------------- time embedding
 // ct[o] = b1[o] + sum_k relu(t_b[k] + sum_i t_w[k][i] * gfp(t)[i]) * w1_t[k][o]        (denoiser.py:29-31,71-72)
-__global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weights w, float t, int NH, float* __restrict__ ct) {
+struct TimeList { float t[8]; };
+__global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weights w, TimeList tl, int NH, float* __restrict__ ct_all) {
     __shared__ float emb[128], tf[128];
     const int tid = threadIdx.x;
+    const float t = tl.t[blockIdx.y];
+    float* ct = ct_all + (long long)blockIdx.y * NH;
     if (tid < 64) {
         // x[:, None] * W[None, :] * 2 * np.pi : three fp32 multiplications, left to right
         float a = t * w.t_W[tid];
@@ -67,18 +71,20 @@ struct HeadArgs {
     int rhs_mode;
 };
 
-__global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [2][256*HB_LD] weights | [2][128*HB_LD] activations | [256][4] {ct, w2_0, w2_1, w2_2}
+    // [2][256*HB_LD] weights | [2][128*HB_LD] activations | [256][4] {ct, w2_0, w2_1, w2_2} | [2][128][4] partial outputs
     float* Wb = smem;
     float* Pb = smem + 2 * 256 * HB_LD;
     float* Eb = Pb + 2 * 128 * HB_LD;
+    float* Ob = Eb + 256 * 4;
     const int n = blockIdx.y, r0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int kq = tid & 7, lrow = tid >> 3;
+    const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
+    const int kq = tid & 7, lrow = tid >> 3;            // 64 tile rows per load pass
     const float* Wg = a.w1p + (long long)n * 256 * 256;
 
-    {   // epilogue table
+    if (tid < 256) {   // epilogue table
         f32x4 e;
         e[0] = a.ct[n * 256 + tid];
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(a.w2 + (long long)(n * 256 + tid) * 4);
@@ -86,13 +92,13 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
     }
 
-    f32x4 rw[8], rp[4];
+    f32x4 rw[4], rp[2];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + 32 * j) * 256 + k0 + 4 * kq);
+        for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + 64 * j) * 256 + k0 + 4 * kq);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + lrow + 32 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int r = r0 + lrow + 64 * j;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < a.R) v = *reinterpret_cast<const f32x4*>(a.p2 + (long long)r * 256 + k0 + 4 * kq);
             rp[j] = v;
@@ -100,14 +106,14 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + 32 * j) * HB_LD + 4 * kq) = rw[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + 64 * j) * HB_LD + 4 * kq) = rw[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + 32 * j) * HB_LD + 4 * kq) = rp[j];
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + 64 * j) * HB_LD + 4 * kq) = rp[j];
     };
 
-    f32x16 acc[8];
+    f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -118,34 +124,35 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < NK) load_tiles((kt + 1) * HB_K);
-        const float* As = Wb + buf * 256 * HB_LD + li * HB_LD + 4 * lh;
-        const float* Bs = Pb + buf * 128 * HB_LD + (wave * 32 + li) * HB_LD + 4 * lh;
+        const float* As = Wb + buf * 256 * HB_LD + (hh * 128 + li) * HB_LD + 4 * lh;
+        const float* Bs = Pb + buf * 128 * HB_LD + (rg * 32 + li) * HB_LD + 4 * lh;
 #pragma unroll
         for (int kk = 0; kk < HB_K / 8; ++kk) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
-            f32x4 av[8];
+            f32x4 av[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_LD + kk * 8);
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_LD + kk * 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b[q], acc[i], 0, 0, 0);
         }
         if (kt + 1 < NK) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: hidden unit j = 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
-    const int row = r0 + wave * 32 + li;
+    // epilogue: hidden unit j = 128*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
+    const int lrow_out = rg * 32 + li;
+    const int row = r0 + lrow_out;
     const bool live = row < a.R;
     const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int j = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int j = 128 * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
             const f32x4 t = *reinterpret_cast<const f32x4*>(Eb + j * 4);
             float h = acc[i][e] + cim[j] + t[0];
             h = h > 0.f ? h : 0.f;
@@ -155,17 +162,26 @@ __global__ __launch_bounds__(256) void score_head_kernel(const HeadArgs a) {
     o0 += __shfl_xor(o0, 32);
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
-    if (live && lh == 0) {
-        float o[3] = {o0 + a.b2[n * 3 + 0], o1 + a.b2[n * 3 + 1], o2 + a.b2[n * 3 + 2]};
-        int nans = 0;
+    if (lh == 0) {
+        float* ob = Ob + (hh * 128 + lrow_out) * 4;
+        ob[0] = o0; ob[1] = o1; ob[2] = o2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int orow = r0 + tid;
+        if (orow < a.R) {
+            const float* p0 = Ob + tid * 4;
+            const float* p1 = Ob + (128 + tid) * 4;
+            int nans = 0;
 #pragma unroll
-        for (int dd = 0; dd < 3; ++dd) {
-            float s = o[dd] / a.inv_std_den;
-            if (s != s) { s = 0.f; ++nans; }
-            if (a.rhs_mode) s = 0.f - a.coef * s;
-            a.out[(long long)row * a.D + n * 3 + dd] = s;
+            for (int dd = 0; dd < 3; ++dd) {
+                float sv = ((p0[dd] + p1[dd]) + a.b2[n * 3 + dd]) / a.inv_std_den;
+                if (sv != sv) { sv = 0.f; ++nans; }
+                if (a.rhs_mode) sv = 0.f - a.coef * sv;
+                a.out[(long long)orow * a.D + n * 3 + dd] = sv;
+            }
+            if (nans) atomicAdd(a.nan_count, nans);
         }
-        if (nans) atomicAdd(a.nan_count, nans);
     }
 }
 
@@ -290,7 +306,7 @@ Workspace carve(const vpho_score_weights& w, int bs, int S, char* base) {
     Workspace ws;
     auto take = [&](long long b) { char* p = base ? base + off : nullptr; off += align_up(b); return p; };
     ws.cimg = (float*)take(bs * NH * 4);
-    ws.ct = (float*)take(NH * 4);
+    ws.ct = (float*)take(8 * NH * 4);
     ws.X = (float*)take(R * w.Dp * 4);
     ws.P1 = (float*)take(R * 256 * 4);
     ws.P2 = (float*)take(R * 256 * 4);
@@ -333,16 +349,27 @@ int prepare_cimg(Ctx& c, const float* feat_img) {
 }
 
 // X (R x Dp, fp32) -> out (R x D)
-int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out) {
-    hipLaunchKernelGGL(time_embed_kernel, dim3((c.NH + 255) / 256), dim3(256), 0, c.s, *c.w, t, c.NH, c.ws.ct);
-    if (int e = vpho::check_launch("time_embed_kernel")) return e;
+// time embeddings of up to 8 evaluation times in one launch -> ct slots 0..n-1
+int embed_times(Ctx& c, const float* ts, int n) {
+    TimeList tl;
+    for (int i = 0; i < 8; ++i) tl.t[i] = i < n ? ts[i] : 0.f;
+    hipLaunchKernelGGL(time_embed_kernel, dim3((c.NH + 255) / 256, n), dim3(256), 0, c.s, *c.w, tl, c.NH, c.ws.ct);
+    return vpho::check_launch("time_embed_kernel");
+}
+
+// ct_slot < 0: embed t now into slot 0; otherwise slot ct_slot was filled by embed_times for exactly this t
+int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out, int ct_slot = -1) {
+    if (ct_slot < 0) {
+        if (int e = embed_times(c, &t, 1)) return e;
+        ct_slot = 0;
+    }
     if (int e = linear(X, (int)c.R, c.w->Dp, c.w->pe0_w, c.w->pe0_b, 256, 0.f, c.ws.P1, c.s)) return e;
     if (int e = linear(c.ws.P1, (int)c.R, 256, c.w->pe2_w, c.w->pe2_b, 256, 0.f, c.ws.P2, c.s)) return e;
     HeadArgs a;
-    a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct; a.w2 = c.w->w2; a.b2 = c.w->b2;
+    a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct + (long long)ct_slot * c.NH; a.w2 = c.w->w2; a.b2 = c.w->b2;
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
     a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
-    const size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4) * sizeof(float);
+    const size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4 + 2 * 128 * 4) * sizeof(float);
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -350,17 +377,17 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     }
     {
         vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
-        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(256), lds, c.s, a);
+        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(512), lds, c.s, a);
     }
     return vpho::check_launch("score_head_kernel");
 }
 
 // rhs(t, .) of the probability-flow ODE: 0 - f32(0.5 g(t)^2) * score     (score_based_model.py:74-83)
-int eval_rhs(Ctx& c, const float* X, double t, float* out) {
+int eval_rhs(Ctx& c, const float* X, double t, float* out, int ct_slot = -1) {
     const float tf = (float)t;
     const double g = (double)sigma_f32(tf) * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
     const float coef = (float)(0.5 * g * g);
-    return eval_net(c, X, tf, 1, coef, out);
+    return eval_net(c, X, tf, 1, coef, out, ct_slot);
 }
 
 double* pinned_slot() {
@@ -509,13 +536,19 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
             if (direction * (t_new - tf) > 0) t_new = tf;
             h = t_new - t;
             h_abs = std::fabs(h);
+            {   // the six stage times of this attempt are known up front: one embedding launch
+                float ts[6];
+                for (int s = 1; s < 6; ++s) ts[s - 1] = (float)(t + RK_C[s] * h);
+                ts[5] = (float)(t + h);
+                if (int e = embed_times(c, ts, 6)) return e;
+            }
             for (int s = 1; s < 6; ++s) {
                 LinComb lc;
                 memset(&lc, 0, sizeof(lc));
                 lc.n = s; lc.h = h;
                 for (int j = 0; j < s; ++j) lc.c[j] = RK_A[s][j];
                 hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
-                if (int e = eval_rhs(c, c.ws.X, t + RK_C[s] * h, Kp(s))) return e;
+                if (int e = eval_rhs(c, c.ws.X, t + RK_C[s] * h, Kp(s), s - 1)) return e;
             }
             {
                 LinComb lc;
@@ -523,7 +556,7 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
                 lc.n = 6; lc.h = h;
                 for (int j = 0; j < 6; ++j) lc.c[j] = RK_B[j];
                 hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, ynew);
-                if (int e = eval_rhs(c, c.ws.X, t + h, Kp(6))) return e;
+                if (int e = eval_rhs(c, c.ws.X, t + h, Kp(6), 5)) return e;
             }
             st->nfev += 6;
             NormArgs na;
