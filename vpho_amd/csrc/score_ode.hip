@@ -81,7 +81,8 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     const int n = blockIdx.y, r0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
-    const int kq = tid & 7, lrow = tid >> 3;            // 64 tile rows per load pass
+    constexpr int KQ = HB_K / 4, RPP = 512 / KQ;        // 16-byte pieces per tile row; tile rows per load pass
+    const int kq = tid % KQ, lrow = tid / KQ;
     const float* Wg = a.w1p + (long long)n * 256 * 256;
 
     if (tid < 256) {   // epilogue table
@@ -92,13 +93,13 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
     }
 
-    f32x4 rw[4], rp[2];
+    f32x4 rw[256 / RPP], rp[128 / RPP];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + 64 * j) * 256 + k0 + 4 * kq);
+        for (int j = 0; j < 256 / RPP; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + RPP * j) * 256 + k0 + 4 * kq);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = r0 + lrow + 64 * j;
+        for (int j = 0; j < 128 / RPP; ++j) {
+            const int r = r0 + lrow + RPP * j;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < a.R) v = *reinterpret_cast<const f32x4*>(a.p2 + (long long)r * 256 + k0 + 4 * kq);
             rp[j] = v;
@@ -106,9 +107,9 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + 64 * j) * HB_LD + 4 * kq) = rw[j];
+        for (int j = 0; j < 256 / RPP; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + RPP * j) * HB_LD + 4 * kq) = rw[j];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + 64 * j) * HB_LD + 4 * kq) = rp[j];
+        for (int j = 0; j < 128 / RPP; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + RPP * j) * HB_LD + 4 * kq) = rp[j];
     };
 
     f32x16 acc[4];
