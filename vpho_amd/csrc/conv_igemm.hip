@@ -22,7 +22,7 @@ constexpr int LDS_LD = BK + 4;
 struct Geo {
     vpho_conv_desc d;
     int M, K, tiles_m, tiles_n, ntiles;
-    int y_linear, r_linear;
+    int y_linear, r_linear, vec_epilogue;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -146,27 +146,78 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     }
 
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    auto offsets = [&](int row, long long& yo, long long& ro) {
+        if (g.y_linear && g.r_linear) {
+            yo = (long long)row * d.y_sx;
+            ro = (long long)row * d.r_sx;
+        } else {
+            int n = row / ohw, rem = row - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
+            ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+        }
+    };
+    if (g.vec_epilogue) {
+        // Stage the accumulator tile through the (now idle) LDS so that every lane moves 16 contiguous bytes of one
+        // output pixel: residual read, bias, activation and store all run on 16-B accesses (512 B per 32 lanes).
+        constexpr int C_LD = BN + 4;
+        float* Cs = smem;                                    // BM x (BN+4) floats <= 2*(BM+BN)*LDS_LD
+        static_assert(BM * C_LD <= 2 * (BM + BN) * LDS_LD, "epilogue tile does not fit the staging LDS");
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    Cs[r * C_LD + wn * (BN / WN) + j * 32 + li] = acc[i][j][e];
+                }
+        __syncthreads();
+        constexpr int V_PER_ROW = BN / 4, ITERS = BM * V_PER_ROW / NT;
+        f32x4 v[ITERS], rv[ITERS];
+        long long yo[ITERS];
+        bool ok[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
+            const int row = m0 + r, col = n0 + 4 * c4;
+            ok[it] = row < g.M && col < d.Cout;
+            v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
+            long long ro = 0;
+            yo[it] = 0;
+            if (ok[it]) { offsets(row, yo[it], ro); yo[it] += col; ro += col; }
+            rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d.res && ok[it]) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (!ok[it]) continue;
+            const int idx = tid + it * NT;
+            const int c4 = idx % V_PER_ROW;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n0 + 4 * c4);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+            *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
+        }
+        return;
+    }
+    const int row_base = m0 + wm * (BM / WM) + 4 * lh, col_base = n0 + wn * (BN / WN) + li;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + li;
+        const int col = col_base + j * 32;
         if (col >= d.Cout) continue;
         const float bv = d.bias ? d.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
                 if (row >= g.M) continue;
-                long long yo, ro = 0;
-                if (g.y_linear && g.r_linear) {
-                    yo = (long long)row * d.y_sx;
-                    ro = (long long)row * d.r_sx;
-                } else {
-                    int n = row / ohw, rem = row - n * ohw;
-                    int oy = rem / d.OW, ox = rem - oy * d.OW;
-                    yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
-                    ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
-                }
+                long long yo, ro;
+                offsets(row, yo, ro);
                 float v = acc[i][j][e] + bv;
                 if (d.res) v += d.res[ro + col];
                 v = v > 0.f ? v : v * d.out_slope;
@@ -199,6 +250,11 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.K = d.KH * d.KW * d.Cin;
     g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
     g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
+    // 16-byte epilogue when every output pixel's channel run (and the residual's) is 16-byte addressable
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    g.vec_epilogue = (d.Cout % 4 == 0 && al16(d.y) && d.y_sx % 4 == 0 && d.y_sy % 4 == 0 && d.y_sn % 4 == 0 &&
+                      (!d.bias || al16(d.bias)) &&
+                      (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
     const double flops = 2.0 * (double)M * d.Cout * g.K;
