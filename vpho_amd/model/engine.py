@@ -4,6 +4,8 @@
 replays the reference's data flow (VPHO.py:112-304, aggregation.py:1167-1353) as a sequence of C-ABI calls on the current
 HIP stream.  Torch is used for allocation, views and dtype/flag conversion only.
 """
+import threading
+
 import torch
 
 from .. import ops
@@ -105,6 +107,7 @@ class Engine:
         ycb = {n: dict(kpt3d=sd[f'head_obj.point_{n}'], verts_sampled=sd[f'head_obj.vert_{n}'], CoM=sd[f'head_obj.CoM_{n}'][0]) for n in names}
         self.agg = ops.Aggregation(dict(ycb=ycb, anchor=model.assets['anchor']), model.anchor_skeleton, dev)
         self.last_info = {}
+        self._obj_stream = None
 
     def stale(self, model):
         return _signature(model) != self.sig
@@ -287,6 +290,25 @@ class Engine:
             init_h, init_o = init_h.to(self.dev, non_blocking=True), init_o.to(self.dev, non_blocking=True)
             out = dict(reg_hand_vert=f['reg_hand_vert'], reg_hand_joint=f['reg_hand_joint'], hand_heatmap=f['hand_heatmap'],
                        obj_heatmap=f['obj_heatmap'], force_local=f['force_local'])
+            # The object sampler (9-d, 3 heads: ~150 workgroups per launch) cannot fill the chip on its own, so it runs
+            # concurrently with the hand sampler on a second HIP stream, driven by its own host thread (each sampler
+            # blocks on one 8-byte error norm per RK attempt; ctypes releases the GIL during the call).
+            main = torch.cuda.current_stream()
+            if self._obj_stream is None:
+                self._obj_stream = torch.cuda.Stream(device=self.dev)
+            obj_stream = self._obj_stream
+            obj_stream.wait_stream(main)
+            box = {}
+
+            def run_obj():
+                try:
+                    with torch.cuda.device(self.dev), torch.cuda.stream(obj_stream):
+                        box['res'] = self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
+                except BaseException as e:          # re-raised on the caller's thread
+                    box['err'] = e
+
+            th = threading.Thread(target=run_obj, name='vpho-obj-sampler')
+            th.start()
             # hand hypotheses
             xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h, S, T0, steps, xs_f64=False, x_f64=False)
             inproc = torch.empty((bs * S * steps, 58), device=self.dev)
@@ -305,7 +327,13 @@ class Engine:
             out['diff_final_hand_vert'] = fv.view(bs, S, 778, 3)
             out['diff_final_hand_joint'] = fj.view(bs, S, 21, 3)
             # object hypotheses (stay fp64, quirk Q5)
-            xs_o, x_o, st_o = self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
+            th.join()
+            if 'err' in box:
+                raise box['err']
+            xs_o, x_o, st_o = box['res']
+            main.wait_stream(obj_stream)
+            for t in (xs_o, x_o):
+                t.record_stream(main)
             out['diff_inprocess_obj_6d'] = xs_o.view(bs, S, steps, 9)
             out['diff_final_obj_6d'] = x_o.view(bs, S, 9)
             for name, st in (('hand', st_h), ('obj', st_o)):
