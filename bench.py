@@ -97,8 +97,9 @@ def main():
     if args.warmup:
         E.gather_rows(E.metric_rows(out, batches[0], gt_joint, gt_vert, 0))
     barrier()
-    ops.prof_enable('conv_igemm_128x128', not args.no_kernel_timing)
-    ops.prof_enable('score_head', not args.no_kernel_timing)
+    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head')
+    for c in timed_classes:
+        ops.prof_enable(c, not args.no_kernel_timing)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = model(batches[i % 2], mode='predict')
@@ -107,10 +108,11 @@ def main():
     all_rows = E.gather_rows(torch.cat(rows, 0))          # the ONE collective of the evaluation
     barrier()
     dt = time.perf_counter() - t0
-    ops.prof_enable('conv_igemm_128x128', False)
-    ops.prof_enable('score_head', False)
-    conv = ops.prof_collect('conv_igemm_128x128')
-    head = ops.prof_collect('score_head')
+    prof = {}
+    for c in timed_classes:
+        ops.prof_enable(c, False)
+        prof[c] = ops.prof_collect(c)
+    conv, head = prof['conv_igemm_128x128'], prof['score_head']
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -132,8 +134,14 @@ def main():
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128> (fp32 MFMA implicit GEMM)', 'achieved': conv_tf,
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves)', 'achieved': conv_tf,
+                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS,
+                         'traffic': pmc_traffic('conv_igemm_kernel<128, 128, 4, 2>'),
+                         'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
+                         'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),
+                                               'kernel_ms_per_step': v['total_ms'] / max(args.steps, 1),
+                                               'launches_per_step': v['launches'] / max(args.steps, 1)}
+                                           for k, v in prof.items() if k not in ('conv_igemm_128x128', 'score_head')},
                          'launches_per_step': conv['launches'] / max(args.steps, 1),
                          'avg_launch_us': conv['total_ms'] * 1e3 / max(conv['launches'], 1),
                          'flop_per_launch_avg': conv['flops'] / max(conv['launches'], 1),
@@ -151,6 +159,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; profiles/r01_pmc_hbm_traffic.json, produced by scripts/pmc_summary.py); None when absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]['hbm_bytes_per_launch']
+    except Exception:
+        return None
 
 
 def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):

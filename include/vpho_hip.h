@@ -22,10 +22,11 @@ const char* vpho_last_error(void);
 int vpho_abi_version(void);
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
- * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head).  vpho_prof_collect waits for the
- * recorded events and returns the summed kernel time, the launch count and the algorithmic flop (2*M*N*K) issued. */
+ * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile).
+ * vpho_prof_collect waits for the recorded events and returns the summed kernel time, the launch count, the algorithmic
+ * flop (2*M*N*K) and the algorithmic bytes (operands once) issued. */
 int vpho_prof_enable(int kernel_class, int on);
-int vpho_prof_collect(int kernel_class, double* total_ms, long long* launches, double* total_flops);
+int vpho_prof_collect(int kernel_class, double* total_ms, long long* launches, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Convolution / linear layers as one implicit-GEMM kernel on fp32 MFMA (v_mfma_f32_32x32x2_f32).

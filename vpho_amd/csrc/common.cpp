@@ -15,14 +15,15 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
-struct ProfState { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; };
+struct ProfState { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0, bytes = 0; };
 static ProfState g_prof[PROF_NCLASS];
 static std::mutex g_prof_mu;
 bool prof_on(int cls) { return g_prof[cls].on; }
-void prof_record(int cls, hipEvent_t a, hipEvent_t b, double flops) {
+void prof_record(int cls, hipEvent_t a, hipEvent_t b, double flops, double bytes) {
     std::lock_guard<std::mutex> l(g_prof_mu);
     g_prof[cls].ev.emplace_back(a, b);
     g_prof[cls].flops += flops;
+    g_prof[cls].bytes += bytes;
 }
 }  // namespace vpho
 
@@ -32,8 +33,8 @@ extern "C" int vpho_prof_enable(int cls, int on) {
     return 0;
 }
 
-extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches, double* total_flops) {
-    VPHO_REQUIRE(cls >= 0 && cls < vpho::PROF_NCLASS && total_ms && launches && total_flops, "vpho_prof_collect: bad argument");
+extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches, double* total_flops, double* total_bytes) {
+    VPHO_REQUIRE(cls >= 0 && cls < vpho::PROF_NCLASS && total_ms && launches && total_flops && total_bytes, "vpho_prof_collect: bad argument");
     std::lock_guard<std::mutex> l(vpho::g_prof_mu);
     auto& st = vpho::g_prof[cls];
     double ms = 0;
@@ -45,8 +46,8 @@ extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches,
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    *total_ms = ms; *launches = (long long)st.ev.size(); *total_flops = st.flops;
-    st.ev.clear(); st.flops = 0;
+    *total_ms = ms; *launches = (long long)st.ev.size(); *total_flops = st.flops; *total_bytes = st.bytes;
+    st.ev.clear(); st.flops = 0; st.bytes = 0;
     return 0;
 }
 

@@ -14,15 +14,15 @@ inline int check_launch(const char* what) {
 }
 
 // Opt-in per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
-enum ProfClass { PROF_CONV128 = 0, PROF_CONV64 = 1, PROF_SCORE_HEAD = 2, PROF_NCLASS = 3 };
+enum ProfClass { PROF_CONV128 = 0, PROF_CONV64 = 1, PROF_SCORE_HEAD = 2, PROF_CONV128x64 = 3, PROF_NCLASS = 4 };
 bool prof_on(int cls);
-void prof_record(int cls, hipEvent_t start, hipEvent_t stop, double flops);
+void prof_record(int cls, hipEvent_t start, hipEvent_t stop, double flops, double bytes);
 struct ProfScope {
-    int cls; hipStream_t s; double flops; bool on; hipEvent_t e0, e1;
-    ProfScope(int c, hipStream_t st, double f) : cls(c), s(st), flops(f), on(prof_on(c)) {
+    int cls; hipStream_t s; double flops, bytes; bool on; hipEvent_t e0, e1;
+    ProfScope(int c, hipStream_t st, double f, double b = 0) : cls(c), s(st), flops(f), bytes(b), on(prof_on(c)) {
         if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(e1, s); prof_record(cls, e0, e1, flops); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(e1, s); prof_record(cls, e0, e1, flops, bytes); } }
 };
 }  // namespace vpho
 

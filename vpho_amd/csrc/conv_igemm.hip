@@ -23,6 +23,7 @@ struct Geo {
     vpho_conv_desc d;
     int M, K, tiles_m, tiles_n, ntiles;
     int y_linear, r_linear, vec_epilogue;
+    int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -47,8 +48,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     const int wm = wave / WN, wn = wave % WN;
     const int kq = tid & 7, lrow = tid >> 3;
 
-    // per-thread A rows (output pixels) -> input coordinates
-    int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
+    // per-thread A rows (output pixels): element offset of the window origin + window origin coordinates
+    long long a_off[A_LD];
+    int a_iy0[A_LD], a_ix0[A_LD];
     const int ohw = d.OH * d.OW;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
@@ -56,32 +58,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
         if (m < g.M) {
             int n = m / ohw, rem = m - n * ohw;
             int oy = rem / d.OW, ox = rem - oy * d.OW;
-            a_base[j] = n * d.H;
             a_iy0[j] = oy * d.stride - d.pad_y;
             a_ix0[j] = ox * d.stride - d.pad_x;
+            a_off[j] = ((long long)(n * d.H + a_iy0[j]) * d.W + a_ix0[j]) * d.x_ld;
         } else {
-            a_base[j] = -1; a_iy0[j] = 0; a_ix0[j] = 0;
+            a_off[j] = 0; a_iy0[j] = -(1 << 28); a_ix0[j] = 0;          // never in bounds
         }
     }
+    long long b_off[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int n = n0 + lrow + ROWS * j;
+        b_off[j] = n < d.Cout ? (long long)n * g.K + 4 * kq : -1;
+    }
+    // (r, s, c) of this thread's 16-byte piece of the NEXT tile to load; advanced by BK channels per tile without divisions
+    int ld_c, ld_r, ld_s;
+    {
+        const int kg = 4 * kq, rs = kg / d.Cin;
+        ld_c = kg - rs * d.Cin; ld_r = rs / d.KW; ld_s = rs - ld_r * d.KW;
+    }
 
-    f32x4 ra[A_LD], rb[B_LD];
-    auto load_tiles = [&](int k0) {
-        const int kg = k0 + 4 * kq;
-        const bool kin = kg < g.K;
-        int rs = 0, c = 0, r = 0, s = 0;
-        if (kin) { rs = kg / d.Cin; c = kg - rs * d.Cin; r = rs / d.KW; s = rs - r * d.KW; }
+    // two register stages: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one step earlier)
+    // is written to LDS, so every global load has two K-steps of MFMA time to land
+    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+    auto load_next = [&](f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
+        const bool kin = ld_r < d.KH;
+        const int tap = (ld_r * d.W + ld_s) * d.x_ld + ld_c;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (d.in_scale != nullptr && kin) {
-            sc = *reinterpret_cast<const f32x4*>(d.in_scale + c);
-            sh = *reinterpret_cast<const f32x4*>(d.in_shift + c);
+            sc = *reinterpret_cast<const f32x4*>(d.in_scale + ld_c);
+            sh = *reinterpret_cast<const f32x4*>(d.in_shift + ld_c);
         }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
-            if (kin && a_base[j] >= 0 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) {
-                const float* p = d.x + ((long long)(a_base[j] + iy) * d.W + ix) * d.x_ld + c;
-                v = *reinterpret_cast<const f32x4*>(p);
+            const unsigned iy = (unsigned)(a_iy0[j] + ld_r), ix = (unsigned)(a_ix0[j] + ld_s);
+            if (kin && iy < (unsigned)d.H && ix < (unsigned)d.W) {
+                v = *reinterpret_cast<const f32x4*>(d.x + a_off[j] + tap);
                 if (d.in_scale != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -95,12 +108,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int n = n0 + lrow + ROWS * j;
-            if (kin && n < d.Cout) v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * g.K + kg);
+            if (kin && b_off[j] >= 0) v = *reinterpret_cast<const f32x4*>(d.w + b_off[j]);
             rb[j] = v;
+            b_off[j] += b_off[j] >= 0 ? BK : 0;
         }
+        ld_c += BK;
+        while (ld_c >= d.Cin) { ld_c -= d.Cin; if (++ld_s == d.KW) { ld_s = 0; ++ld_r; } }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD]) {
         float* As = smem + buf * (BM + BN) * LDS_LD;
         float* Bs = As + BM * LDS_LD;
 #pragma unroll
@@ -118,31 +133,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    auto step = [&](int kt, f32x4 (&ld_a)[A_LD], f32x4 (&ld_b)[B_LD], const f32x4 (&st_a)[A_LD], const f32x4 (&st_b)[B_LD]) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        if (kt + 2 < nk && !(g.dbg & 1)) load_next(ld_a, ld_b);
         const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + li) * LDS_LD + 4 * lh;
         const float* Bs = smem + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * (BN / WN) + li) * LDS_LD + 4 * lh;
+        // fragment double buffer: the LDS reads of k-group kk+1 are in flight while the MFMAs of group kk issue
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + kk * 8);
+                for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + kk * 8);
+                for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + (kk + 1) * 8);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i][q], b[kk & 1][j][q], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < nk && !(g.dbg & 4)) store_tiles(buf ^ 1, st_a, st_b);
+        if (!(g.dbg & 2)) __syncthreads();
+    };
+    load_next(ra0, rb0);
+    store_tiles(0, ra0, rb0);
+    if (nk > 1) load_next(ra1, rb1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, ra0, rb0, ra1, rb1);                       // loads tile kt+2 -> stage 0, stores stage 1 (tile kt+1)
+        if (kt + 1 < nk) step(kt + 1, ra1, rb1, ra0, rb0);  // loads tile kt+3 -> stage 1, stores stage 0 (tile kt+2)
     }
 
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -255,9 +282,13 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.vec_epilogue = (d.Cout % 4 == 0 && al16(d.y) && d.y_sx % 4 == 0 && d.y_sy % 4 == 0 && d.y_sn % 4 == 0 &&
                       (!d.bias || al16(d.bias)) &&
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
+    static const int dbg = getenv("VPHO_CONV_DBG") ? atoi(getenv("VPHO_CONV_DBG")) : 0;
+    g.dbg = dbg;
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
     const double flops = 2.0 * (double)M * d.Cout * g.K;
+    // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
+    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + (double)M * d.Cout * (d.res ? 2 : 1) + d.Cout);
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
@@ -267,7 +298,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
     if (force_tile) variant = force_tile;
     auto launch = [&](auto kernel, int bm, int bn, int threads, int cls) {
-        vpho::ProfScope prof(cls, s, flops);
+        vpho::ProfScope prof(cls, s, flops, bytes);
         g.tiles_m = (int)((M + bm - 1) / bm); g.tiles_n = (d.Cout + bn - 1) / bn;
         g.ntiles = g.tiles_m * g.tiles_n;
         hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(threads), 0, s, g);
@@ -275,8 +306,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288: launch(conv_igemm_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128); break;
-        case 12864: launch(conv_igemm_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128); break;
-        case 1264: launch(conv_igemm_kernel<128, 64, 2, 2>, 128, 64, 256, vpho::PROF_CONV128); break;
+        case 12864: launch(conv_igemm_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128x64); break;
+        case 1264: launch(conv_igemm_kernel<128, 64, 2, 2>, 128, 64, 256, vpho::PROF_CONV128x64); break;
         default:   launch(conv_igemm_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64); break;
     }
     return vpho::check_launch("conv_igemm_kernel");

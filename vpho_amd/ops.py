@@ -485,7 +485,7 @@ class Aggregation:
 
 
 # ----------------------------------------------------------------------------------------------- profiling hooks
-PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2}
+PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3}
 
 
 def prof_enable(name, on=True):
@@ -493,6 +493,6 @@ def prof_enable(name, on=True):
 
 
 def prof_collect(name):
-    ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
-    _check(lib.vpho_prof_collect(I(PROF_CLASSES[name]), C.byref(ms), C.byref(n), C.byref(fl)))
-    return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
+    ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+    _check(lib.vpho_prof_collect(I(PROF_CLASSES[name]), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+    return dict(total_ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
