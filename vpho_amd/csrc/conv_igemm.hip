@@ -26,13 +26,17 @@ struct Geo {
     int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores
 };
 
-template <int BM, int BN, int WM, int WN>
+// VEC = number of consecutive 16-byte pieces (of one tile row) a thread moves per pass: 2 halves the per-K-step address
+// arithmetic and bounds checks (needs Cin % 8 == 0 so that a 32-byte piece never straddles two filter taps)
+template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     constexpr int NT = 64 * WM * WN;                  // threads per block; waves arranged WM x WN
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    constexpr int ROWS = NT / 8;                      // tile rows covered by one pass of 16-byte loads
-    constexpr int A_LD = BM / ROWS, B_LD = BN / ROWS;
-    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile too small for the wave layout");
+    constexpr int KQN = 8 / VEC;                      // threads per tile row
+    constexpr int ROWS = NT / KQN;                    // tile rows covered by one pass
+    constexpr int A_LD = (BM + ROWS - 1) / ROWS, B_LD = (BN + ROWS - 1) / ROWS;
+    constexpr bool A_PART = BM < ROWS, B_PART = BN < ROWS;   // fewer tile rows than one pass covers: extra threads idle
+    static_assert(TM >= 1 && TN >= 1, "tile too small for the wave layout");
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
 
     const vpho_conv_desc& d = g.d;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid & 7, lrow = tid >> 3;
+    const int kq = tid % KQN, lrow = tid / KQN;
 
     // per-thread A rows (output pixels): element offset of the window origin + window origin coordinates
     long long a_off[A_LD];
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         int m = m0 + lrow + ROWS * j;
-        if (m < g.M) {
+        if (m < g.M && !(A_PART && lrow >= BM)) {
             int n = m / ohw, rem = m - n * ohw;
             int oy = rem / d.OW, ox = rem - oy * d.OW;
             a_iy0[j] = oy * d.stride - d.pad_y;
@@ -69,59 +73,80 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int n = n0 + lrow + ROWS * j;
-        b_off[j] = n < d.Cout ? (long long)n * g.K + 4 * kq : -1;
+        b_off[j] = (n < d.Cout && !(B_PART && lrow >= BN)) ? (long long)n * g.K + 4 * VEC * kq : -1;
     }
     // (r, s, c) of this thread's 16-byte piece of the NEXT tile to load; advanced by BK channels per tile without divisions
     int ld_c, ld_r, ld_s;
     {
-        const int kg = 4 * kq, rs = kg / d.Cin;
+        const int kg = 4 * VEC * kq, rs = kg / d.Cin;
         ld_c = kg - rs * d.Cin; ld_r = rs / d.KW; ld_s = rs - ld_r * d.KW;
     }
 
     // two register stages: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one step earlier)
     // is written to LDS, so every global load has two K-steps of MFMA time to land
-    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
-    auto load_next = [&](f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD]) {
+    f32x4 ra0[A_LD * VEC], rb0[B_LD * VEC], ra1[A_LD * VEC], rb1[B_LD * VEC];
+    auto load_next = [&](f32x4 (&ra)[A_LD * VEC], f32x4 (&rb)[B_LD * VEC]) {
         const bool kin = ld_r < d.KH;
         const int tap = (ld_r * d.W + ld_s) * d.x_ld + ld_c;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc[VEC], sh[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { sc[u] = f32x4{1.f, 1.f, 1.f, 1.f}; sh[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (d.in_scale != nullptr && kin) {
-            sc = *reinterpret_cast<const f32x4*>(d.in_scale + ld_c);
-            sh = *reinterpret_cast<const f32x4*>(d.in_shift + ld_c);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                sc[u] = *reinterpret_cast<const f32x4*>(d.in_scale + ld_c + 4 * u);
+                sh[u] = *reinterpret_cast<const f32x4*>(d.in_shift + ld_c + 4 * u);
+            }
         }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const unsigned iy = (unsigned)(a_iy0[j] + ld_r), ix = (unsigned)(a_ix0[j] + ld_s);
-            if (kin && iy < (unsigned)d.H && ix < (unsigned)d.W) {
-                v = *reinterpret_cast<const f32x4*>(d.x + a_off[j] + tap);
-                if (d.in_scale != nullptr) {
+            const bool inb = kin && iy < (unsigned)d.H && ix < (unsigned)d.W;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = v[e] * sc[e] + sh[e];
-                        v[e] = t > 0.f ? t : t * d.in_slope;
+            for (int u = 0; u < VEC; ++u) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (inb) {
+                    v = *reinterpret_cast<const f32x4*>(d.x + a_off[j] + tap + 4 * u);
+                    if (d.in_scale != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = v[e] * sc[u][e] + sh[u][e];
+                            v[e] = t > 0.f ? t : t * d.in_slope;
+                        }
                     }
                 }
+                ra[j * VEC + u] = v;
             }
-            ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kin && b_off[j] >= 0) v = *reinterpret_cast<const f32x4*>(d.w + b_off[j]);
-            rb[j] = v;
+            const bool inb = kin && b_off[j] >= 0;
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (inb) v = *reinterpret_cast<const f32x4*>(d.w + b_off[j] + 4 * u);
+                rb[j * VEC + u] = v;
+            }
             b_off[j] += b_off[j] >= 0 ? BK : 0;
         }
         ld_c += BK;
         while (ld_c >= d.Cin) { ld_c -= d.Cin; if (++ld_s == d.KW) { ld_s = 0; ++ld_r; } }
     };
-    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD]) {
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_LD * VEC], const f32x4 (&rb)[B_LD * VEC]) {
         float* As = smem + buf * (BM + BN) * LDS_LD;
         float* Bs = As + BM * LDS_LD;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(As + (lrow + ROWS * j) * LDS_LD + 4 * kq) = ra[j];
+        for (int j = 0; j < A_LD; ++j) {
+            if (A_PART && lrow >= BM) continue;
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + ROWS * j) * LDS_LD + 4 * kq) = rb[j];
+            for (int u = 0; u < VEC; ++u) *reinterpret_cast<f32x4*>(As + (lrow + ROWS * j) * LDS_LD + 4 * (VEC * kq + u)) = ra[j * VEC + u];
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            if (B_PART && lrow >= BN) continue;
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) *reinterpret_cast<f32x4*>(Bs + (lrow + ROWS * j) * LDS_LD + 4 * (VEC * kq + u)) = rb[j * VEC + u];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -133,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
-    auto step = [&](int kt, f32x4 (&ld_a)[A_LD], f32x4 (&ld_b)[B_LD], const f32x4 (&st_a)[A_LD], const f32x4 (&st_b)[B_LD]) {
+    auto step = [&](int kt, f32x4 (&ld_a)[A_LD * VEC], f32x4 (&ld_b)[B_LD * VEC], const f32x4 (&st_a)[A_LD * VEC], const f32x4 (&st_b)[B_LD * VEC]) {
         const int buf = kt & 1;
         if (kt + 2 < nk && !(g.dbg & 1)) load_next(ld_a, ld_b);
         const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + li) * LDS_LD + 4 * lh;
@@ -303,12 +328,21 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         g.ntiles = g.tiles_m * g.tiles_n;
         hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(threads), 0, s, g);
     };
+    const bool v2 = d.Cin % 8 == 0;
     switch (variant) {
-        case 128:  launch(conv_igemm_kernel<128, 128, 2, 2>, 128, 128, 256, vpho::PROF_CONV128); break;
-        case 1288: launch(conv_igemm_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128); break;
-        case 12864: launch(conv_igemm_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128x64); break;
-        case 1264: launch(conv_igemm_kernel<128, 64, 2, 2>, 128, 64, 256, vpho::PROF_CONV128x64); break;
-        default:   launch(conv_igemm_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64); break;
+        case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
+        case 1288:
+            if (v2) launch(conv_igemm_kernel<128, 128, 4, 2, 2>, 128, 128, 512, vpho::PROF_CONV128);
+            else    launch(conv_igemm_kernel<128, 128, 4, 2, 1>, 128, 128, 512, vpho::PROF_CONV128);
+            break;
+        case 12864:
+            if (v2) launch(conv_igemm_kernel<128, 64, 4, 2, 2>, 128, 64, 512, vpho::PROF_CONV128x64);
+            else    launch(conv_igemm_kernel<128, 64, 4, 2, 1>, 128, 64, 512, vpho::PROF_CONV128x64);
+            break;
+        default:
+            if (v2) launch(conv_igemm_kernel<64, 64, 2, 2, 2>, 64, 64, 256, vpho::PROF_CONV64);
+            else    launch(conv_igemm_kernel<64, 64, 2, 2, 1>, 64, 64, 256, vpho::PROF_CONV64);
+            break;
     }
     return vpho::check_launch("conv_igemm_kernel");
 }

@@ -55,6 +55,111 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weight
     }
 }
 
+// --------------------------------------------------------------------------------------------- fused pose encoder
+// P2 = relu(relu(X W0^T + b0) W2^T + b2)   (denoiser.py:60-65,74): both Linear layers of `pose_encoder` in one launch.
+// Block = 32 hypotheses x all 256 hidden units, 4 waves (wave w owns hidden columns 64w..64w+63 = two 32x32 MFMA tiles);
+// the 32x256 intermediate stays in LDS, weights stream through a double-buffered [256][32] LDS chunk.
+struct PoseEncArgs {
+    const float* X; int Dp;            // [R][Dp]
+    const float *w0, *b0, *w2, *b2;    // [256][Dp], [256], [256][256], [256]
+    float* out; int R;                 // [R][256]
+};
+constexpr int PE_ROWS = 32, PE_LD = 36, PE_H_LD = 260;
+__global__ __launch_bounds__(256) void pose_encoder_kernel(const PoseEncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K1 = (a.Dp + 31) / 32 * 32, X_LD = K1 + 4;
+    float* Ws = smem;                              // [2][256][PE_LD]
+    float* H1 = Ws + 2 * 256 * PE_LD;              // [32][PE_H_LD]
+    float* Xs = H1 + PE_ROWS * PE_H_LD;            // [32][X_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int kq = tid & 7, lrow = tid >> 3;       // 32 weight rows per load pass
+    const int r0 = blockIdx.x * PE_ROWS;
+
+    for (int i = tid; i < PE_ROWS * (K1 / 4); i += 256) {
+        const int r = i / (K1 / 4), c = (i - r * (K1 / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < a.R && c < a.Dp) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(r0 + r) * a.Dp + c);
+        *reinterpret_cast<f32x4*>(Xs + r * X_LD + c) = v;
+    }
+
+    f32x4 rw[8];
+    auto load_w = [&](const float* W, int ldw, int kmax, int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + 4 * kq < kmax) v = *reinterpret_cast<const f32x4*>(W + (long long)(lrow + 32 * j) * ldw + k0 + 4 * kq);
+            rw[j] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Ws + buf * 256 * PE_LD + (lrow + 32 * j) * PE_LD + 4 * kq) = rw[j];
+    };
+    auto zero = [](f32x16 (&acc)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    };
+    // one GEMM stage: acc += A[32 x K] (LDS, row stride a_ld) * W[256 x K]^T (global, streamed)
+    auto gemm = [&](const float* A_lds, int a_ld, const float* W, int ldw, int kmax, int nchunk, f32x16 (&acc)[2]) {
+        load_w(W, ldw, kmax, 0);
+        store_w(0);
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < nchunk) load_w(W, ldw, kmax, (ch + 1) * 32);
+            const float* As = A_lds + li * a_ld + ch * 32 + 4 * lh;
+            const float* Bs = Ws + buf * 256 * PE_LD + (wave * 64 + li) * PE_LD + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(As + kk * 8);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + 32 * PE_LD + kk * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc[1], 0, 0, 0);
+                }
+            }
+            if (ch + 1 < nchunk) store_w(buf ^ 1);
+            __syncthreads();
+        }
+    };
+
+    f32x16 acc[2];
+    zero(acc);
+    gemm(Xs, X_LD, a.w0, a.Dp, a.Dp, K1 / 32, acc);
+    // h1 = relu(acc + b0) -> LDS [row][hidden]; C layout: hidden unit on the lane, hypothesis row on the register
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wave * 64 + j * 32 + li;
+        const float bv = a.b0[col];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = acc[j][e] + bv;
+            H1[row * PE_H_LD + col] = v > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    zero(acc);
+    gemm(H1, PE_H_LD, a.w2, 256, 256, 8, acc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wave * 64 + j * 32 + li;
+        const float bv = a.b2[col];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row < a.R) {
+                const float v = acc[j][e] + bv;
+                a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------- fused score head
 struct HeadArgs {
     const float* w1p;    // [NH][256]
@@ -364,8 +469,21 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         if (int e = embed_times(c, &t, 1)) return e;
         ct_slot = 0;
     }
-    if (int e = linear(X, (int)c.R, c.w->Dp, c.w->pe0_w, c.w->pe0_b, 256, 0.f, c.ws.P1, c.s)) return e;
-    if (int e = linear(c.ws.P1, (int)c.R, 256, c.w->pe2_w, c.w->pe2_b, 256, 0.f, c.ws.P2, c.s)) return e;
+    {
+        PoseEncArgs pa;
+        pa.X = X; pa.Dp = c.w->Dp; pa.w0 = c.w->pe0_w; pa.b0 = c.w->pe0_b; pa.w2 = c.w->pe2_w; pa.b2 = c.w->pe2_b;
+        pa.out = c.ws.P2; pa.R = (int)c.R;
+        const int K1 = (pa.Dp + 31) / 32 * 32;
+        const size_t pe_lds = (size_t)(2 * 256 * PE_LD + PE_ROWS * PE_H_LD + PE_ROWS * (K1 + 4)) * sizeof(float);
+        static bool pe_opt_in = false;
+        if (!pe_opt_in) {
+            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            pe_opt_in = true;
+        }
+        VPHO_REQUIRE(pe_lds <= 150 * 1024, "pose encoder: input dimension %d too large for the LDS tile", pa.Dp);
+        hipLaunchKernelGGL(pose_encoder_kernel, dim3((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS)), dim3(256), pe_lds, c.s, pa);
+        if (int e = vpho::check_launch("pose_encoder_kernel")) return e;
+    }
     HeadArgs a;
     a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct + (long long)ct_slot * c.NH; a.w2 = c.w->w2; a.b2 = c.w->b2;
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
