@@ -140,3 +140,17 @@ def test_topk_larger_than_candidates_raises(model_cpu, assets):
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
         torch.cuda.synchronize()
+
+
+def test_quaternion_mean_of_identical_rotations_is_finite(assets):
+    """k identical quaternions give a rank-1 moment matrix (three zero eigenvalues); the Jacobi solver must not produce
+    0/0.  Exercised through the hand-physics fuse (all candidates share the proximal joints, aggregation.py:1319-1321)."""
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    g = torch.Generator().manual_seed(3)
+    cand = torch.randn(1, 1, 58, generator=g).repeat(4, 7, 1).cuda().contiguous()       # 7 identical candidates
+    idx = torch.tensor([[[0, 1, 2, 3, 4]] * 5] * 4, dtype=torch.int32).cuda()
+    out = agg.hand_phys_fuse(cand, idx)
+    assert torch.isfinite(out).all()
+    assert (out - cand[:, 0]).abs().max().item() < 2e-5          # mean of identical rotations is that rotation

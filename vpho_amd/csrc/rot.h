@@ -116,7 +116,9 @@ __device__ inline void sym4_top_eigenvector(T A[4][4], T* v) {
         if (off < (T)1e-40) break;
         for (int p = 0; p < 3; ++p) {
             for (int q = p + 1; q < 4; ++q) {
-                if (t_abs(A[p][q]) < (T)1e-300) continue;
+                // exactly (or denormally) zero off-diagonal: nothing to rotate.  Matters for rank-deficient moment matrices
+                // (k identical quaternions): a second sweep would otherwise evaluate 0/0 between two zero eigenvalues.
+                if (!(t_abs(A[p][q]) > (sizeof(T) == 4 ? (T)1e-30 : (T)1e-290))) continue;
                 const T theta = (A[q][q] - A[p][p]) / ((T)2 * A[p][q]);
                 const T t = (theta >= 0 ? (T)1 : (T)-1) / (t_abs(theta) + t_sqrt(theta * theta + (T)1));
                 const T c = (T)1 / t_sqrt(t * t + (T)1), s = t * c;
