@@ -137,7 +137,9 @@ def main():
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'vpho_net.forward(mode=predict) README eval config (BASELINE.json configs[1])',
+            'config': {'workload': 'vpho_net.forward(mode=predict), ' + ('README eval config (BASELINE.json configs[1])' if
+                                    (args.bs, args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj) == (64, 100, 50, 30, 10)
+                                    else 'non-default config (see the keys below)'),
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',

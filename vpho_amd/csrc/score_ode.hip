@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/vpho_hip.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -488,7 +489,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct + (long long)ct_slot * c.NH; a.w2 = c.w->w2; a.b2 = c.w->b2;
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
     a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
-    const size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+    size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+    if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
