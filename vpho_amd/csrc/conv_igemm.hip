@@ -279,6 +279,201 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (no prologue affine): tiles are filled by `global_load_lds_dwordx4` (16 B per lane, no VGPR round
+// trip, no ds_write).  One wave instruction writes 64 x 16 B = 8 tile rows of 128 B linearly, so the LDS rows are
+// unpadded; bank conflicts are avoided by XOR-swizzling the 16-byte chunk index of row r with (r >> 1) & 7 -- applied to
+// the per-lane SOURCE address (the LDS destination is lane-linear by construction) and again when the MFMA fragments are
+// read.  Out-of-image taps / K and M tails read from a 256-byte zero page instead of being masked.
+__device__ __attribute__((aligned(256))) float g_zero_page[64];
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo g) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int ROWS = NT / 8;                      // tile rows per pass: every wave fills 8 consecutive rows
+    constexpr int A_LD = BM / ROWS, B_LD = BN / ROWS;
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && ROWS % 16 == 0, "tile/wave layout");
+    constexpr int TILE = (BM + BN) * BK;              // floats per stage (unpadded)
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+
+    const vpho_conv_desc& d = g.d;
+    const int per_xcd = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= g.ntiles) return;
+    const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = wave * 8 + (lane >> 3);                        // tile row filled by this lane (per pass: + ROWS*j)
+    const int kq = (lane & 7) ^ ((lrow >> 1) & 7);                  // logical 16-B chunk this lane must FETCH (swizzle)
+
+    long long a_off[A_LD];
+    int a_iy0[A_LD], a_ix0[A_LD];
+    const int ohw = d.OH * d.OW;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        int m = m0 + lrow + ROWS * j;
+        if (m < g.M) {
+            int n = m / ohw, rem = m - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            a_iy0[j] = oy * d.stride - d.pad_y;
+            a_ix0[j] = ox * d.stride - d.pad_x;
+            a_off[j] = ((long long)(n * d.H + a_iy0[j]) * d.W + a_ix0[j]) * d.x_ld;
+        } else {
+            a_off[j] = 0; a_iy0[j] = -(1 << 28); a_ix0[j] = 0;
+        }
+    }
+    long long b_off[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int n = n0 + lrow + ROWS * j;
+        b_off[j] = n < d.Cout ? (long long)n * g.K + 4 * kq : -1;
+    }
+    int ld_c, ld_r, ld_s;
+    {
+        const int kg = 4 * kq, rs = kg / d.Cin;
+        ld_c = kg - rs * d.Cin; ld_r = rs / d.KW; ld_s = rs - ld_r * d.KW;
+    }
+    const float* zero = g_zero_page;
+    auto fill = [&](int buf) {
+        float* As = smem + buf * TILE + wave * 8 * BK;              // wave-uniform destination of this wave's 8 rows
+        float* Bs = smem + buf * TILE + BM * BK + wave * 8 * BK;
+        const bool kin = ld_r < d.KH;
+        const int tap = (ld_r * d.W + ld_s) * d.x_ld + ld_c;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const unsigned iy = (unsigned)(a_iy0[j] + ld_r), ix = (unsigned)(a_ix0[j] + ld_s);
+            const float* src = (kin && iy < (unsigned)d.H && ix < (unsigned)d.W) ? d.x + a_off[j] + tap : zero;
+            __builtin_amdgcn_global_load_lds(src, As + ROWS * j * BK, 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const float* src = (kin && b_off[j] >= 0) ? d.w + b_off[j] : zero;
+            __builtin_amdgcn_global_load_lds(src, Bs + ROWS * j * BK, 16, 0, 0);
+            b_off[j] += b_off[j] >= 0 ? BK : 0;
+        }
+        ld_c += BK;
+        while (ld_c >= d.Cin) { ld_c -= d.Cin; if (++ld_s == d.KW) { ld_s = 0; ++ld_r; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    const int sw = (li >> 1) & 7;                                   // (row >> 1) & 7 of every fragment row of this lane
+    fill(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fill(buf ^ 1);
+        const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * BK;
+        const float* Bs = smem + buf * TILE + BM * BK + (wn * (BN / WN) + li) * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int ch = ((2 * kk + lh) ^ sw) * 4;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + ch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + ch);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    auto offsets = [&](int row, long long& yo, long long& ro) {
+        if (g.y_linear && g.r_linear) {
+            yo = (long long)row * d.y_sx;
+            ro = (long long)row * d.r_sx;
+        } else {
+            int n = row / ohw, rem = row - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
+            ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+        }
+    };
+    if (g.vec_epilogue) {
+        constexpr int C_LD = BN;                                    // ds_write_b32 halves are separate bank groups: no pad needed
+        float* Cs = smem;
+        static_assert(BM * C_LD <= 2 * TILE, "epilogue tile does not fit the staging LDS");
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    Cs[r * C_LD + wn * (BN / WN) + j * 32 + li] = acc[i][j][e];
+                }
+        __syncthreads();
+        constexpr int V_PER_ROW = BN / 4, ITERS = BM * V_PER_ROW / NT;
+        f32x4 v[ITERS], rv[ITERS];
+        long long yo[ITERS];
+        bool ok[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
+            const int row = m0 + r, col = n0 + 4 * c4;
+            ok[it] = row < g.M && col < d.Cout;
+            v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
+            long long ro = 0;
+            yo[it] = 0;
+            if (ok[it]) { offsets(row, yo[it], ro); yo[it] += col; ro += col; }
+            rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d.res && ok[it]) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (!ok[it]) continue;
+            const int idx = tid + it * NT;
+            const int c4 = idx % V_PER_ROW;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n0 + 4 * c4);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+            *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
+        }
+        return;
+    }
+    const int row_base = m0 + wm * (BM / WM) + 4 * lh, col_base = n0 + wn * (BN / WN) + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + j * 32;
+        if (col >= d.Cout) continue;
+        const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
+                if (row >= g.M) continue;
+                long long yo, ro;
+                offsets(row, yo, ro);
+                float v = acc[i][j][e] + bv;
+                if (d.res) v += d.res[ro + col];
+                v = v > 0.f ? v : v * d.out_slope;
+                d.y[yo + col] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
@@ -319,7 +514,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
     const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64);
     int variant = 64;
-    if (big_tiles >= 512 && d.Cout % 128 == 0) variant = 1288;
+    if (big_tiles >= 256 && d.Cout % 128 == 0) variant = 1288;
     else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
     if (force_tile) variant = force_tile;
     auto launch = [&](auto kernel, int bm, int bn, int threads, int cls) {
@@ -328,20 +523,21 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         g.ntiles = g.tiles_m * g.tiles_n;
         hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(threads), 0, s, g);
     };
-    const bool v2 = d.Cin % 8 == 0;
+    static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
+    const bool glds = d.in_scale == nullptr && !no_glds;
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288:
-            if (v2) launch(conv_igemm_kernel<128, 128, 4, 2, 2>, 128, 128, 512, vpho::PROF_CONV128);
-            else    launch(conv_igemm_kernel<128, 128, 4, 2, 1>, 128, 128, 512, vpho::PROF_CONV128);
+            if (glds) launch(conv_igemm_glds_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128);
+            else      launch(conv_igemm_kernel<128, 128, 4, 2, 1>, 128, 128, 512, vpho::PROF_CONV128);
             break;
         case 12864:
-            if (v2) launch(conv_igemm_kernel<128, 64, 4, 2, 2>, 128, 64, 512, vpho::PROF_CONV128x64);
-            else    launch(conv_igemm_kernel<128, 64, 4, 2, 1>, 128, 64, 512, vpho::PROF_CONV128x64);
+            if (glds) launch(conv_igemm_glds_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128x64);
+            else      launch(conv_igemm_kernel<128, 64, 4, 2, 1>, 128, 64, 512, vpho::PROF_CONV128x64);
             break;
         default:
-            if (v2) launch(conv_igemm_kernel<64, 64, 2, 2, 2>, 64, 64, 256, vpho::PROF_CONV64);
-            else    launch(conv_igemm_kernel<64, 64, 2, 2, 1>, 64, 64, 256, vpho::PROF_CONV64);
+            if (glds) launch(conv_igemm_glds_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64);
+            else      launch(conv_igemm_kernel<64, 64, 2, 2, 1>, 64, 64, 256, vpho::PROF_CONV64);
             break;
     }
     return vpho::check_launch("conv_igemm_kernel");
