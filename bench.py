@@ -95,9 +95,14 @@ def main():
     if args.warmup:
         E.gather_rows(E.metric_rows(out, batches[0], gt_joint, gt_vert, 0))
     barrier()
+    step_events = []
+
     def run_steps(k):
         rows, nfev = [], []
         for i in range(k):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
             out = model(batches[i % 2], mode='predict')
             rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs))
             nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
@@ -106,8 +111,15 @@ def main():
     # ---- timed region: K steps, no instrumentation -----------------------------------------------------------------
     t0 = time.perf_counter()
     all_rows, nfev = run_steps(args.steps)
+    ev_end = torch.cuda.Event(enable_timing=True)
+    ev_end.record()
     barrier()
     dt = time.perf_counter() - t0
+    ev_all = step_events[:args.steps] + [ev_end]
+    step_ms_seq = [a.elapsed_time(b) for a, b in zip(ev_all[:-1], ev_all[1:])]
+    step_ms = sorted(step_ms_seq)
+    if os.environ.get('VPHO_BENCH_VERBOSE') and rank == 0:
+        print('per-step ms:', ' '.join(f'{t:.1f}' for t in step_ms_seq), file=sys.stderr)
     # ---- roofline leg: the same K steps again with HIP events recorded around every launch of the timed kernel
     # classes on their launch streams (kept out of the timed region: ~500 event pairs per step perturb it by 10-15 %)
     timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head')
@@ -135,7 +147,7 @@ def main():
         result = {
             'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'vpho_net.forward(mode=predict), ' + ('README eval config (BASELINE.json configs[1])' if
                                     (args.bs, args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj) == (64, 100, 50, 30, 10)
@@ -144,9 +156,9 @@ def main():
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves)', 'achieved': conv_tf,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': pmc_traffic('conv_igemm_kernel<128, 128, 4, 2>'),
+                         'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
                          'timing': 'HIP events around every launch, in a separate instrumented repeat of the K steps',
                          'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
                          'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),

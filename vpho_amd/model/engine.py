@@ -4,6 +4,7 @@
 replays the reference's data flow (VPHO.py:112-304, aggregation.py:1167-1353) as a sequence of C-ABI calls on the current
 HIP stream.  Torch is used for allocation, views and dtype/flag conversion only.
 """
+import os
 import threading
 
 import torch
@@ -307,8 +308,10 @@ class Engine:
                 except BaseException as e:          # re-raised on the caller's thread
                     box['err'] = e
 
-            th = threading.Thread(target=run_obj, name='vpho-obj-sampler')
-            th.start()
+            concurrent = os.environ.get('VPHO_SERIAL_SAMPLERS', '0') != '1'
+            th = threading.Thread(target=run_obj, name='vpho-obj-sampler') if concurrent else None
+            if th is not None:
+                th.start()
             # hand hypotheses
             xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h, S, T0, steps, xs_f64=False, x_f64=False)
             inproc = torch.empty((bs * S * steps, 58), device=self.dev)
@@ -327,7 +330,10 @@ class Engine:
             out['diff_final_hand_vert'] = fv.view(bs, S, 778, 3)
             out['diff_final_hand_joint'] = fj.view(bs, S, 21, 3)
             # object hypotheses (stay fp64, quirk Q5)
-            th.join()
+            if th is not None:
+                th.join()
+            else:
+                run_obj()
             if 'err' in box:
                 raise box['err']
             xs_o, x_o, st_o = box['res']
