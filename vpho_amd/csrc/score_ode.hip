@@ -60,8 +60,13 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weight
 // P2 = relu(relu(X W0^T + b0) W2^T + b2)   (denoiser.py:60-65,74): both Linear layers of `pose_encoder` in one launch.
 // Block = 32 hypotheses x all 256 hidden units, 4 waves (wave w owns hidden columns 64w..64w+63 = two 32x32 MFMA tiles);
 // the 32x256 intermediate stays in LDS, weights stream through a double-buffered [256][32] LDS chunk.
+struct LinComb { double c[7]; int n; double h; };
+
+// Input rows either come from X ([R][Dp] fp32) or are formed on the fly as the RK stage state
+// x = (float)(y + h * sum_j c_j K_j)  (scipy rk_step: y + dy, then ode_func's .float(), score_based_model.py:76)
 struct PoseEncArgs {
     const float* X; int Dp;            // [R][Dp]
+    const double* y; const float* Kst; long long n_el; int D; LinComb lc; double* ynew; int use_lc;
     const float *w0, *b0, *w2, *b2;    // [256][Dp], [256], [256][256], [256]
     float* out; int R;                 // [R][256]
 };
@@ -79,7 +84,22 @@ __global__ __launch_bounds__(256) void pose_encoder_kernel(const PoseEncArgs a) 
     for (int i = tid; i < PE_ROWS * (K1 / 4); i += 256) {
         const int r = i / (K1 / 4), c = (i - r * (K1 / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r0 + r < a.R && c < a.Dp) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(r0 + r) * a.Dp + c);
+        if (r0 + r < a.R && c < a.Dp) {
+            if (!a.use_lc) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(r0 + r) * a.Dp + c);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c + u < a.D) {
+                        const long long e = (long long)(r0 + r) * a.D + c + u;
+                        double sacc = 0.0;
+                        for (int j = 0; j < a.lc.n; ++j) sacc += (double)a.Kst[j * a.n_el + e] * a.lc.c[j];
+                        const double xv = a.y[e] + sacc * a.lc.h;
+                        v[u] = (float)xv;
+                        if (a.ynew) a.ynew[e] = xv;
+                    }
+                }
+            }
+        }
         *reinterpret_cast<f32x4*>(Xs + r * X_LD + c) = v;
     }
 
@@ -293,8 +313,6 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------- RK stage algebra
-struct LinComb { double c[7]; int n; double h; };
-
 // X[r][0..Dp) = (float)(y + h * sum_j c_j K_j), pad columns zero; optionally also stores the fp64 sum to ynew
 __global__ void stage_input_kernel(const double* __restrict__ y, const float* __restrict__ K, long long n_el, int D, int Dp,
                                    LinComb lc, float* __restrict__ X, double* __restrict__ ynew) {
@@ -368,23 +386,29 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
     if (threadIdx.x == 0) *out = red[0];
 }
 
-// dense output (scipy RkDenseOutput): y_old + h * (K^T P) . [x, x^2, x^3, x^4]
-struct DenseArgs { double P[7][4]; double p[4]; double h; };
+// dense output (scipy RkDenseOutput): y_old + h * (K^T P) . [x, x^2, x^3, x^4] for every t_eval stamp inside the step
+constexpr int DENSE_MAX = 48;
+struct DenseArgs { double P[7][4]; double p[DENSE_MAX][4]; int idx[DENSE_MAX]; int n; double h; };
 __global__ void dense_kernel(const double* __restrict__ y_old, const float* __restrict__ K, long long n_el, int D,
-                             DenseArgs da, void* __restrict__ xs, int is_f64, int num_steps, int idx) {
+                             DenseArgs da, void* __restrict__ xs, int is_f64, int num_steps) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
-    double acc = 0.0;
+    double q[4];
     for (int m = 0; m < 4; ++m) {
-        double q = 0.0;
-        for (int j = 0; j < 7; ++j) q += (double)K[j * n_el + i] * da.P[j][m];
-        acc += q * da.p[m];
+        double s = 0.0;
+        for (int j = 0; j < 7; ++j) s += (double)K[j * n_el + i] * da.P[j][m];
+        q[m] = s;
     }
-    const double v = da.h * acc + y_old[i];
+    const double y0 = y_old[i];
     const long long r = i / D;
     const int c = (int)(i - r * D);
-    const long long o = (r * num_steps + idx) * D + c;
-    if (is_f64) reinterpret_cast<double*>(xs)[o] = v; else reinterpret_cast<float*>(xs)[o] = (float)v;
+    for (int st = 0; st < da.n; ++st) {
+        double acc = 0.0;
+        for (int m = 0; m < 4; ++m) acc += q[m] * da.p[st][m];
+        const double v = da.h * acc + y0;
+        const long long o = (r * num_steps + da.idx[st]) * D + c;
+        if (is_f64) reinterpret_cast<double*>(xs)[o] = v; else reinterpret_cast<float*>(xs)[o] = (float)v;
+    }
 }
 
 // x = y + (0 - g^2 * grad) * step  (fp32 product, fp64 add; score_based_model.py:95-104)
@@ -465,15 +489,18 @@ int embed_times(Ctx& c, const float* ts, int n) {
 }
 
 // ct_slot < 0: embed t now into slot 0; otherwise slot ct_slot was filled by embed_times for exactly this t
-int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out, int ct_slot = -1) {
+int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out, int ct_slot = -1,
+             const LinComb* lc = nullptr, const double* y = nullptr, double* ynew = nullptr) {
     if (ct_slot < 0) {
         if (int e = embed_times(c, &t, 1)) return e;
         ct_slot = 0;
     }
     {
         PoseEncArgs pa;
+        memset(&pa, 0, sizeof(pa));
         pa.X = X; pa.Dp = c.w->Dp; pa.w0 = c.w->pe0_w; pa.b0 = c.w->pe0_b; pa.w2 = c.w->pe2_w; pa.b2 = c.w->pe2_b;
         pa.out = c.ws.P2; pa.R = (int)c.R;
+        if (lc) { pa.use_lc = 1; pa.lc = *lc; pa.y = y; pa.Kst = c.ws.K; pa.n_el = c.n_el; pa.D = c.w->D; pa.ynew = ynew; }
         const int K1 = (pa.Dp + 31) / 32 * 32;
         const size_t pe_lds = (size_t)(2 * 256 * PE_LD + PE_ROWS * PE_H_LD + PE_ROWS * (K1 + 4)) * sizeof(float);
         static bool pe_opt_in = false;
@@ -504,11 +531,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
 }
 
 // rhs(t, .) of the probability-flow ODE: 0 - f32(0.5 g(t)^2) * score     (score_based_model.py:74-83)
-int eval_rhs(Ctx& c, const float* X, double t, float* out, int ct_slot = -1) {
+int eval_rhs(Ctx& c, const float* X, double t, float* out, int ct_slot = -1, const LinComb* lc = nullptr,
+             const double* y = nullptr, double* ynew = nullptr) {
     const float tf = (float)t;
     const double g = (double)sigma_f32(tf) * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
     const float coef = (float)(0.5 * g * g);
-    return eval_net(c, X, tf, 1, coef, out, ct_slot);
+    return eval_net(c, X, tf, 1, coef, out, ct_slot, lc, y, ynew);
 }
 
 double* pinned_slot() {
@@ -668,16 +696,14 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
                 memset(&lc, 0, sizeof(lc));
                 lc.n = s; lc.h = h;
                 for (int j = 0; j < s; ++j) lc.c[j] = RK_A[s][j];
-                hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
-                if (int e = eval_rhs(c, c.ws.X, t + RK_C[s] * h, Kp(s), s - 1)) return e;
+                if (int e = eval_rhs(c, nullptr, t + RK_C[s] * h, Kp(s), s - 1, &lc, y, nullptr)) return e;   // stage state formed in the pose encoder
             }
             {
                 LinComb lc;
                 memset(&lc, 0, sizeof(lc));
                 lc.n = 6; lc.h = h;
                 for (int j = 0; j < 6; ++j) lc.c[j] = RK_B[j];
-                hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, ynew);
-                if (int e = eval_rhs(c, c.ws.X, t + h, Kp(6), 5)) return e;
+                if (int e = eval_rhs(c, nullptr, t + h, Kp(6), 5, &lc, y, ynew)) return e;                    // also stores y_new (fp64)
             }
             st->nfev += 6;
             NormArgs na;
@@ -704,11 +730,15 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
         while (next_idx < num_steps && te[next_idx] >= t_new) {
             DenseArgs da;
             for (int j = 0; j < 7; ++j) for (int m = 0; m < 4; ++m) da.P[j][m] = RK_P[j][m];
-            const double x = (te[next_idx] - t) / h;
-            da.p[0] = x; da.p[1] = x * x; da.p[2] = da.p[1] * x; da.p[3] = da.p[2] * x;
             da.h = h;
-            hipLaunchKernelGGL(dense_kernel, dim3(nbE), dim3(256), 0, c.s, y, K, n_el, D, da, xs_out, xs_is_f64, num_steps, next_idx);
-            ++next_idx;
+            da.n = 0;
+            while (da.n < DENSE_MAX && next_idx < num_steps && te[next_idx] >= t_new) {
+                const double x = (te[next_idx] - t) / h;
+                double* pp = da.p[da.n];
+                pp[0] = x; pp[1] = x * x; pp[2] = pp[1] * x; pp[3] = pp[2] * x;
+                da.idx[da.n++] = next_idx++;
+            }
+            hipLaunchKernelGGL(dense_kernel, dim3(nbE), dim3(256), 0, c.s, y, K, n_el, D, da, xs_out, xs_is_f64, num_steps);
         }
         // accept: y <- y_new, f <- f_new (first-same-as-last)
         std::swap(y, ynew);

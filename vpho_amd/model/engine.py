@@ -109,6 +109,7 @@ class Engine:
         self.agg = ops.Aggregation(dict(ycb=ycb, anchor=model.assets['anchor']), model.anchor_skeleton, dev)
         self.last_info = {}
         self._obj_stream = None
+        self._pin = {}
 
     def stale(self, model):
         return _signature(model) != self.sig
@@ -221,9 +222,13 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ sampling
     def _prior(self, rows, dim, T0):
-        """sde.py:26-28: CPU default generator, scaled by sigma(T0); drawn while the feature kernels are still running."""
-        # same generator stream as torch.randn(rows, dim), drawn straight into pinned memory (one DMA to the GPU)
-        return torch.empty((rows, dim), pin_memory=True).normal_().mul_(0.01 * (50 / 0.01) ** T0)
+        """sde.py:26-28: CPU default generator, scaled by sigma(T0); drawn while the feature kernels are still running.
+        Same generator stream as torch.randn(rows, dim), filled straight into a persistent pinned buffer (two per shape,
+        alternated, so the previous step's asynchronous upload is never overwritten)."""
+        key = (rows, dim)
+        slot = self._pin.setdefault(key, dict(bufs=[torch.empty((rows, dim), pin_memory=True) for _ in range(2)], i=0))
+        slot['i'] ^= 1
+        return slot['bufs'][slot['i']].normal_().mul_(0.01 * (50 / 0.01) ** T0)
 
     # ------------------------------------------------------------------------------------------------ aggregation
     def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj):
