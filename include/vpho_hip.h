@@ -210,6 +210,13 @@ int vpho_hand_phys_score_f32(const float* force_point, const float* force_global
                              int bs, int n_cand, float* finger_score, void* stream);
 int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int bs, int k, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Evaluation metrics on the device: TesterHand.criterion_MJE_PAMJE (lib/engine/test.py:657-680) with
+ * rigid_align_AtoB (lib/utils/transform_fn.py:43-66).  pd, gt: [n_img][n_pts][3] fp32 (metres); outputs per image the
+ * mean point error, the mean error after similarity (Procrustes) alignment of pd onto gt, optionally every point's error. */
+int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
+                          float* per_point, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,7 +72,8 @@ def install_stubs(assets):
     ycb = {k: dict(kpt3d=v['kpt3d'], verts_sampled=v['verts_sampled'], verts=v['verts'], CoM=v['CoM'],
                    shift=np.eye(4)) for k, v in assets['ycb'].items()}
     _stub('lib.dataset')
-    _stub('lib.dataset.base', YCB_MESHES=ycb)
+    _stub('lib.dataset.base', YCB_MESHES=ycb, YCB_CLASSES={i + 1: n for i, n in enumerate(ycb)},
+          YCB_ID={n: i + 1 for i, n in enumerate(ycb)})
 
 
 def write_assets(root, assets):
@@ -114,6 +115,7 @@ def main():
     from lib.utils.transform_fn import average_quaternion as ref_avgq
     from lib.utils.physics_fn import VERT2ANCHOR
     import lib.model.score_based_model as ref_sbm
+    from lib.engine.test import TesterHand
 
     torch.manual_seed(0)
     ref = ref_vpho.vpho_net().eval()
@@ -218,6 +220,16 @@ def main():
     P['hand_phys_pose_in'] = rec['hand_phys_pose_in'].numpy()
     P['cfg'] = np.array([c['bs'], c['sample_num'], c['sampling_steps'], c['topk_hand'], c['topk_obj']])
     P['sample_T0'] = np.array(c['sample_T0'])
+    # ---- TesterHand (lib/engine/test.py:585-680) on seeded joints / vertices -------------------------------------------
+    rng = np.random.default_rng(31)
+    gtj, gtv = rng.normal(size=(6, 21, 3)).astype(np.float32) * 0.05, rng.normal(size=(6, 778, 3)).astype(np.float32) * 0.05
+    pdj = (gtj + rng.normal(size=gtj.shape) * 0.01).astype(np.float32)
+    pdv = (gtv + rng.normal(size=gtv.shape) * 0.01).astype(np.float32)
+    res = TesterHand()({'is_right': np.array([True, False, True, True, False, False]), 'gt_joint': gtj, 'pd_joint': pdj,
+                        'gt_vert': gtv, 'pd_vert': pdv})
+    for k in ('MJE', 'PA_MJE', 'MVE', 'PAMVE'):
+        G['tester_' + k] = np.asarray(res[k]['both'], dtype=np.float64)
+    G['tester_JE'] = np.stack([res[f'MJE_{i}']['both'] for i in range(21)], -1).astype(np.float64)
     np.savez_compressed(os.path.join(HERE, 'golden_blocks.npz'), **G)
     np.savez_compressed(os.path.join(HERE, 'golden_predict.npz'), **P)
     for n in ('golden_blocks.npz', 'golden_predict.npz'):

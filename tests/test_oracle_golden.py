@@ -128,3 +128,17 @@ def test_predict_topk_indices_cfg1(predict_run):
     assert np.array_equal(a['rot_topk'].numpy(), P['obj_heat_topk_rot'])
     assert np.array_equal(a['heat_topk'].numpy(), P['obj_heat_topk_final'])
     assert np.array_equal(a['phys_topk'].numpy(), P['obj_phys_topk'])
+
+
+def test_hand_metrics_against_tester_hand():
+    """oracle/metrics.py vs the reference's TesterHand (test.py:585-680) on the same seeded joints / vertices."""
+    from oracle import metrics as OM
+    rng = np.random.default_rng(31)
+    gtj, gtv = rng.normal(size=(6, 21, 3)).astype(np.float32) * 0.05, rng.normal(size=(6, 778, 3)).astype(np.float32) * 0.05
+    pdj = (gtj + rng.normal(size=gtj.shape) * 0.01).astype(np.float32)
+    pdv = (gtv + rng.normal(size=gtv.shape) * 0.01).astype(np.float32)
+    for i in range(6):
+        mje, pa, je = OM.mje_pamje(gtj[i], pdj[i])
+        mve, pav, _ = OM.mje_pamje(gtv[i], pdv[i])
+        close([mje, pa, mve, pav], [G['tester_MJE'][i], G['tester_PA_MJE'][i], G['tester_MVE'][i], G['tester_PAMVE'][i]], 1e-5, 1e-7)
+        close(je, G['tester_JE'][i], 1e-5, 1e-7)

@@ -197,18 +197,21 @@ struct HeadArgs {
     int rhs_mode;
 };
 
+__device__ __attribute__((aligned(256))) float g_head_zero_page[64];
+
 __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [2][256*HB_LD] weights | [2][128*HB_LD] activations | [256][4] {ct, w2_0, w2_1, w2_2} | [2][128][4] partial outputs
-    float* Wb = smem;
-    float* Pb = smem + 2 * 256 * HB_LD;
-    float* Eb = Pb + 2 * 128 * HB_LD;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    // [2] stages x ([256][32] weights | [128][32] activations), unpadded rows filled by global_load_lds with the 16-B chunk
+    // index XOR-swizzled by (row >> 1) & 7 (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2} and
+    // [2][128][4] partial outputs
+    constexpr int STAGE = (256 + 128) * HB_K;
+    float* Eb = smem + 2 * STAGE;
     float* Ob = Eb + 256 * 4;
     const int n = blockIdx.y, r0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
-    constexpr int KQ = HB_K / 4, RPP = 512 / KQ;        // 16-byte pieces per tile row; tile rows per load pass
-    const int kq = tid % KQ, lrow = tid / KQ;
+    const int lrow = wave * 8 + (lane >> 3);            // tile row this lane fills (per pass: + 64*j)
+    const int kq = (lane & 7) ^ ((lrow >> 1) & 7);      // logical 16-B chunk this lane fetches
     const float* Wg = a.w1p + (long long)n * 256 * 256;
 
     if (tid < 256) {   // epilogue table
@@ -219,23 +222,24 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
     }
 
-    f32x4 rw[256 / RPP], rp[128 / RPP];
-    auto load_tiles = [&](int k0) {
+    const float* wsrc[4];
+    const float* psrc[2];
+    int pstep[2];
 #pragma unroll
-        for (int j = 0; j < 256 / RPP; ++j) rw[j] = *reinterpret_cast<const f32x4*>(Wg + (lrow + RPP * j) * 256 + k0 + 4 * kq);
+    for (int j = 0; j < 4; ++j) wsrc[j] = Wg + (lrow + 64 * j) * 256 + 4 * kq;
 #pragma unroll
-        for (int j = 0; j < 128 / RPP; ++j) {
-            const int r = r0 + lrow + RPP * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < a.R) v = *reinterpret_cast<const f32x4*>(a.p2 + (long long)r * 256 + k0 + 4 * kq);
-            rp[j] = v;
-        }
-    };
-    auto store_tiles = [&](int buf) {
+    for (int j = 0; j < 2; ++j) {
+        const int r = r0 + lrow + 64 * j;
+        psrc[j] = r < a.R ? a.p2 + (long long)r * 256 + 4 * kq : g_head_zero_page;
+        pstep[j] = r < a.R ? HB_K : 0;
+    }
+    auto fill = [&](int buf) {
+        float* Ws = smem + buf * STAGE + wave * 8 * HB_K;
+        float* Ps = smem + buf * STAGE + 256 * HB_K + wave * 8 * HB_K;
 #pragma unroll
-        for (int j = 0; j < 256 / RPP; ++j) *reinterpret_cast<f32x4*>(Wb + buf * 256 * HB_LD + (lrow + RPP * j) * HB_LD + 4 * kq) = rw[j];
+        for (int j = 0; j < 4; ++j) { __builtin_amdgcn_global_load_lds(wsrc[j], Ws + 64 * j * HB_K, 16, 0, 0); wsrc[j] += HB_K; }
 #pragma unroll
-        for (int j = 0; j < 128 / RPP; ++j) *reinterpret_cast<f32x4*>(Pb + buf * 128 * HB_LD + (lrow + RPP * j) * HB_LD + 4 * kq) = rp[j];
+        for (int j = 0; j < 2; ++j) { __builtin_amdgcn_global_load_lds(psrc[j], Ps + 64 * j * HB_K, 16, 0, 0); psrc[j] += pstep[j]; }
     };
 
     f32x16 acc[4];
@@ -244,28 +248,28 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
+    const int sw = (li >> 1) & 7;
+    fill(0);
     __syncthreads();
     constexpr int NK = 256 / HB_K;
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < NK) load_tiles((kt + 1) * HB_K);
-        const float* As = Wb + buf * 256 * HB_LD + (hh * 128 + li) * HB_LD + 4 * lh;
-        const float* Bs = Pb + buf * 128 * HB_LD + (rg * 32 + li) * HB_LD + 4 * lh;
+        if (kt + 1 < NK) fill(buf ^ 1);
+        const float* As = smem + buf * STAGE + (hh * 128 + li) * HB_K;
+        const float* Bs = smem + buf * STAGE + 256 * HB_K + (rg * 32 + li) * HB_K;
 #pragma unroll
         for (int kk = 0; kk < HB_K / 8; ++kk) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+            const int ch = ((2 * kk + lh) ^ sw) * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + ch);
             f32x4 av[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_LD + kk * 8);
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_K + ch);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b[q], acc[i], 0, 0, 0);
         }
-        if (kt + 1 < NK) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
@@ -516,7 +520,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct + (long long)ct_slot * c.NH; a.w2 = c.w->w2; a.b2 = c.w->b2;
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
     a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
-    size_t lds = (size_t)(2 * 256 * HB_LD + 2 * 128 * HB_LD + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+    size_t lds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 2 * 128 * 4) * sizeof(float);
     if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {

@@ -10,8 +10,9 @@ import torch
 import torch.distributed as dist
 
 # row layout: [global image index, MJE(regression), MJE(first hypothesis), MJE(aggregated), MVE(aggregated),
-#              |agg - regression| mean joint distance (mm), object translation norm (m), is_right]
-ROW = 8
+#              |agg - regression| mean joint distance (mm), object translation norm (m), is_right,
+#              PA-MJE(regression), PA-MJE(aggregated), PA-MVE(aggregated), 0]
+ROW = 12
 
 
 def mje_mm(pd, gt):
@@ -46,6 +47,13 @@ def metric_rows(out, data, gt_joint, gt_vert, first_index):
     rows[:, 5] = mje_mm(pp['agg_hand_joint'], pp['reg_hand_joint'])
     rows[:, 6] = out['agg_obj_6d'][:, 6:].float().norm(dim=-1)
     rows[:, 7] = data['is_right'].float()
+    rows[:, 8:] = 0.0
+    if gt_joint.is_cuda:                 # Procrustes-aligned metrics by the HIP kernel (test.py:657-680 on the device)
+        from . import ops
+        c = lambda t: t.float().contiguous()
+        rows[:, 8] = ops.hand_metrics(c(pp['reg_hand_joint']), c(gt_joint))[1] * 1000.0
+        rows[:, 9] = ops.hand_metrics(c(pp['agg_hand_joint']), c(gt_joint))[1] * 1000.0
+        rows[:, 10] = ops.hand_metrics(c(pp['agg_hand_vert']), c(gt_vert))[1] * 1000.0
     return rows
 
 
@@ -74,5 +82,6 @@ def summarize(rows):
         if sel.shape[0] == 0:
             continue
         res[name] = dict(n=int(sel.shape[0]), MJE_reg=float(sel[:, 1].mean()), MJE_first=float(sel[:, 2].mean()),
-                         MJE_agg=float(sel[:, 3].mean()), MVE_agg=float(sel[:, 4].mean()))
+                         MJE_agg=float(sel[:, 3].mean()), MVE_agg=float(sel[:, 4].mean()), PA_MJE_reg=float(sel[:, 8].mean()),
+                         PA_MJE_agg=float(sel[:, 9].mean()), PA_MVE_agg=float(sel[:, 10].mean()))
     return res

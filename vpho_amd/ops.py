@@ -484,6 +484,18 @@ class Aggregation:
         return out
 
 
+# ----------------------------------------------------------------------------------------------- metrics
+def hand_metrics(pd, gt, per_point=False):
+    """pd, gt (n,P,3) fp32 metres -> mean error (n,), Procrustes-aligned mean error (n,), [per-point errors (n,P)]
+    (test.py:657-680)."""
+    n, P, _ = pd.shape
+    assert gt.shape == pd.shape
+    me, pa = _new((n,), pd), _new((n,), pd)
+    pp = _new((n, P), pd) if per_point else None
+    _call('vpho_hand_metrics_f32', _f32(pd), _f32(gt), I(n), I(P), _f32(me), _f32(pa), _f32(pp))
+    return (me, pa, pp) if per_point else (me, pa)
+
+
 # ----------------------------------------------------------------------------------------------- profiling hooks
 PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3}
 
