@@ -1,0 +1,74 @@
+"""Same entry point as the reference's force_optim.py:7-9 (ForceOptimizer(cfg).optimize_batch()): pseudo-force label
+optimisation over hand-object pairs.  No data set in this build -> synthetic pairs (seeded MANO poses through the HIP FK,
+random contact maps); pairs are sharded over the ranks of one node (one process per GPU), no collective on the data path.
+
+    python force_optim.py --pairs 10000 [--batch_size 64]            # or torch.distributed.run --nproc-per-node N ...
+Prints one JSON line per run (rank 0): pairs/s over all ranks, final mean losses."""
+import argparse
+import json
+import os
+import sys
+import time
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--pairs', type=int, default=10000)
+    p.add_argument('--batch_size', type=int, default=64)
+    p.add_argument('--iters', type=int, default=3000)
+    p.add_argument('--phase1', type=int, default=300)
+    args = p.parse_args()
+    sys.argv = sys.argv[:1]
+    import torch
+    import torch.distributed as dist
+    from vpho_amd import ops
+    from vpho_amd.assets import load_assets, ANCHOR_SKELETON
+    from vpho_amd.evaluate import shard_range
+
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assets = load_assets('asset')
+    n_batches = (args.pairs + args.batch_size - 1) // args.batch_size
+    lo, hi = shard_range(n_batches, rank, world)
+    n = (hi - lo) * args.batch_size
+    g = torch.Generator().manual_seed(1000 + rank)
+    mano = ops.Mano(assets['mano'], dev)
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, dev)
+    pose = (torch.randn(n, 48, generator=g) * 0.3).to(dev)
+    ctx = mano.shape((torch.randn(n, 10, generator=g) * 0.5).to(dev))
+    verts, _ = mano.fk(pose, ctx, 1, True)
+    verts = (verts + torch.tensor([0.0, 0.0, 0.7], device=dev)).contiguous()
+    grav = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    com = (torch.tensor([0.05, 0.0, 0.7]) + torch.randn(n, 3, generator=g) * 0.02).to(dev)
+    fc = torch.rand(n, 32, generator=g).to(dev)
+    grasped = (torch.rand(n, generator=g) < 0.8).to(torch.uint8).to(dev)
+    agg.force_optimize(verts[:args.batch_size], grav[:args.batch_size], com[:args.batch_size], fc[:args.batch_size], grasped[:args.batch_size],
+                       args.batch_size, iters=10, phase1=5)                       # warm-up
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    out = agg.force_optimize(verts, grav, com, fc, grasped, args.batch_size, iters=args.iters, phase1=args.phase1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    tot = torch.tensor([float(n)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot)
+    if rank == 0:
+        losses = out['losses'].mean(0).tolist()
+        print(json.dumps({'metric': 'pseudo-force optimisation pairs/s (3000 AdamW iterations per pair)', 'value': float(tot.item() / dt.item()),
+                          'unit': 'pairs/s', 'n_gpus': world, 'pairs': int(tot.item()), 'batch_size': args.batch_size, 'iters': args.iters,
+                          'seconds': float(dt.item()), 'mean_losses_force_gravity_moment_dist': losses, 'data': 'synthetic'}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

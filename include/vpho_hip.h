@@ -217,6 +217,21 @@ int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int b
 int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
                           float* per_point, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pseudo-force label optimisation (force_optim.py / lib/engine/force_optimization.py:110-207).
+ * vpho_anchor_frames_f32: ForceAnchor.__call__ (lib/utils/physics_fn.py:224-257) -> pts [n][32][3], frames [n][32][3][3]
+ * (frame[j][i] = component j of axis i), computed ONCE (the reference recomputes them in each of its 3000 iterations).
+ * vpho_force_optimize_f32: the whole AdamW loop (two optimisers: `phase1_iters` steps on the cone weights against the
+ * gravity-alignment loss, then scale+weights against force-balance + moment + contact-distribution losses) as one
+ * persistent workgroup per batch of B <= 64 samples (the batch-mean force loss couples the samples of a batch, :146).
+ * Inputs are laid out [n_batches*B]...; gravity/com [..][3] in the flipped (right-hand) frame; outputs force_local /
+ * force_global [..][32][3] (zero where !is_grasped, :199-202), final scale [..][32], weight [..][32][8],
+ * losses [n_batches][4] = (force, gravity, moment, distribution) of the last iteration. */
+int vpho_anchor_frames_f32(const vpho_anchor_tables* t, const float* verts, long long n_hands, float* pts, float* frames, void* stream);
+int vpho_force_optimize_f32(const float* pts, const float* frames, const float* gravity, const float* com, const float* force_contact,
+                            const unsigned char* is_grasped, int n_batches, int B, int iters, int phase1_iters, float lr,
+                            float* force_local, float* force_global, float* scale, float* weight, float* losses, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

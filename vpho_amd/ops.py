@@ -466,6 +466,24 @@ class Aggregation:
         _call('vpho_force_anchor_f32', C.byref(self.anchor), _f32(verts), _f32(root), _f32(force_local_), LL(n), I(hands_per_image), _f32(fp), _f32(fg))
         return fp, fg
 
+    def anchor_frames(self, verts):
+        """ForceAnchor.__call__ (physics_fn.py:224-257): verts (n,778,3) -> points (n,32,3), frames (n,32,3,3)"""
+        n = verts.shape[0]
+        pts, frames = _new((n, 32, 3), verts), _new((n, 32, 3, 3), verts)
+        _call('vpho_anchor_frames_f32', C.byref(self.anchor), _f32(verts), LL(n), _f32(pts), _f32(frames))
+        return pts, frames
+
+    def force_optimize(self, verts, gravity, com, force_contact, is_grasped, batch_size, iters=3000, phase1=300, lr=1e-3):
+        """ForceOptimizer.optimize_batch inner loop (force_optimization.py:110-207) for n = n_batches*batch_size samples."""
+        n = verts.shape[0]
+        assert n % batch_size == 0, 'pad the last batch: the batch-mean force loss couples the samples of a batch'
+        pts, frames = self.anchor_frames(verts)
+        fl, fg = _new((n, 32, 3), verts), _new((n, 32, 3), verts)
+        scale, weight, losses = _new((n, 32), verts), _new((n, 32, 8), verts), _new((n // batch_size, 4), verts)
+        _call('vpho_force_optimize_f32', _f32(pts), _f32(frames), _f32(gravity), _f32(com), _f32(force_contact), _u8(is_grasped),
+              I(n // batch_size), I(batch_size), I(iters), I(phase1), F(lr), _f32(fl), _f32(fg), _f32(scale), _f32(weight), _f32(losses))
+        return dict(force_local=fl, force_global=fg, scale=scale, weight=weight, losses=losses, force_point=pts, frames=frames)
+
     def hand_phys_candidates(self, agg_pose, betas, topk_pose):
         bs, k = topk_pose.shape[:2]
         out = _new((bs, k + 1, 58), agg_pose)
