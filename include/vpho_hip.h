@@ -232,6 +232,21 @@ int vpho_force_optimize_f32(const float* pts, const float* frames, const float* 
                             const unsigned char* is_grasped, int n_batches, int B, int iters, int phase1_iters, float lr,
                             float* force_local, float* force_global, float* scale, float* weight, float* losses, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hand-object contact detection (lib/utils/physics_fn.py:47-117,201-221; caller
+ * lib/dataset/base.py:841-912).  vpho_contact_detect_f32 is one direction of detect_hand_and_object_contact: for each of
+ * n samples, every query point (with unit normal) finds its nearest target point, gates on the signed distance along the
+ * normal in (normal_lo, normal_hi) and the tangential distance < vertical_thresh, and gets the double-sigmoid weight
+ * normalised to 1 at distance 0; nn_index (optional) = nearest target index where in contact, else -1.  Call it hand->object
+ * for hand_contact_map and object->hand for obj_contact_map / obj_contact_to_hand_vert.
+ * vpho_force_contact_f32 pools a hand contact map (rows of `ld` >= 778 floats) onto the 32 CPF anchors and applies the
+ * check_is_grasped rule. */
+int vpho_contact_detect_f32(const float* query, const float* query_normals, const float* target, int n, int n_query, int n_target,
+                            float normal_lo, float normal_hi, float vertical_thresh, float decay_lo, float decay_hi,
+                            float* weight, int* nn_index, void* stream);
+int vpho_force_contact_f32(const vpho_anchor_tables* t, const float* hand_contact, int ld, int n, float thresh,
+                           float* force_contact, unsigned char* is_grasped, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,18 @@ def main():
     P['hand_phys_pose_in'] = rec['hand_phys_pose_in'].numpy()
     P['cfg'] = np.array([c['bs'], c['sample_num'], c['sampling_steps'], c['topk_hand'], c['topk_obj']])
     P['sample_T0'] = np.array(c['sample_T0'])
+    # ---- contact detection (lib/utils/physics_fn.py:47-117,201-221) on a synthetic hand next to a box -------------------
+    from lib.utils.physics_fn import detect_hand_and_object_contact
+    rng = np.random.default_rng(41)
+    hv = (assets['mano']['v_template'] + rng.normal(size=(778, 3)) * 0.001).astype(np.float64)
+    hn = rng.normal(size=(778, 3)); hn /= np.linalg.norm(hn, axis=-1, keepdims=True)
+    ov = (assets['ycb']['003_cracker_box']['verts'] * 0.6 + np.array([0.06, 0.0, 0.0])).astype(np.float64)
+    on = rng.normal(size=ov.shape); on /= np.linalg.norm(on, axis=-1, keepdims=True)
+    hc, oc, o2h = detect_hand_and_object_contact(hv, hn, ov, on, normal_distance_thresh=[-0.01, 0.01], vertical_distance_thresh=0.005)
+    G['contact_hand'], G['contact_obj'], G['contact_o2h'] = hc, oc, o2h
+    fcg = VERT2ANCHOR.get_force_contact(hc)
+    G['contact_force'] = fcg
+    G['contact_is_grasped'] = np.array(bool(VERT2ANCHOR.check_is_grasped(fcg)))
     # ---- TesterHand (lib/engine/test.py:585-680) on seeded joints / vertices -------------------------------------------
     rng = np.random.default_rng(31)
     gtj, gtv = rng.normal(size=(6, 21, 3)).astype(np.float32) * 0.05, rng.normal(size=(6, 778, 3)).astype(np.float32) * 0.05

@@ -142,3 +142,26 @@ def test_hand_metrics_against_tester_hand():
         mve, pav, _ = OM.mje_pamje(gtv[i], pdv[i])
         close([mje, pa, mve, pav], [G['tester_MJE'][i], G['tester_PA_MJE'][i], G['tester_MVE'][i], G['tester_PAMVE'][i]], 1e-5, 1e-7)
         close(je, G['tester_JE'][i], 1e-5, 1e-7)
+
+
+def _contact_inputs(assets):
+    rng = np.random.default_rng(41)
+    hv = (assets['mano']['v_template'] + rng.normal(size=(778, 3)) * 0.001).astype(np.float64)
+    hn = rng.normal(size=(778, 3)); hn /= np.linalg.norm(hn, axis=-1, keepdims=True)
+    ov = (assets['ycb']['003_cracker_box']['verts'] * 0.6 + np.array([0.06, 0.0, 0.0])).astype(np.float64)
+    on = rng.normal(size=ov.shape); on /= np.linalg.norm(on, axis=-1, keepdims=True)
+    return hv, hn, ov, on
+
+
+def test_contact_detection_against_reference(assets):
+    """oracle/contact.py vs lib/utils/physics_fn.py:47-117 (sklearn ball tree), get_force_contact and check_is_grasped."""
+    from oracle import contact as OC
+    hv, hn, ov, on = _contact_inputs(assets)
+    hc, oc, o2h = OC.detect(hv, hn, ov, on, normal_thresh=(-0.01, 0.01), vertical_thresh=0.005)
+    assert (G['contact_hand'] > 0).sum() > 5 and (G['contact_obj'] > 0).sum() > 5          # the fixture is not degenerate
+    close(hc, G['contact_hand'], 1e-9, 1e-12)
+    close(oc, G['contact_obj'], 1e-9, 1e-12)
+    assert np.array_equal(o2h, G['contact_o2h'])
+    fc = OC.force_contact(assets['anchor'], hc)
+    close(fc, G['contact_force'], 1e-6, 1e-9)
+    assert OC.is_grasped(fc) == bool(G['contact_is_grasped'])

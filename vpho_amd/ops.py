@@ -466,6 +466,26 @@ class Aggregation:
         _call('vpho_force_anchor_f32', C.byref(self.anchor), _f32(verts), _f32(root), _f32(force_local_), LL(n), I(hands_per_image), _f32(fp), _f32(fg))
         return fp, fg
 
+    def contact_detect(self, hand_verts, hand_normals, obj_verts, obj_normals, normal_thresh=(-0.015, 0.01), vertical_thresh=0.01,
+                       decay=(-0.005, 0.005)):
+        """detect_hand_and_object_contact (physics_fn.py:47-117) for n samples: (n,Nh,3), (n,Nh,3), (n,No,3), (n,No,3) ->
+        hand_contact (n,Nh), obj_contact (n,No), obj_contact_to_hand_vert (n,No) int32"""
+        n, nh, _ = hand_verts.shape
+        no = obj_verts.shape[1]
+        hc, oc = _new((n, nh), hand_verts), _new((n, no), hand_verts)
+        o2h = _new((n, no), hand_verts, torch.int32)
+        args = (F(normal_thresh[0]), F(normal_thresh[1]), F(vertical_thresh), F(decay[0]), F(decay[1]))
+        _call('vpho_contact_detect_f32', _f32(hand_verts), _f32(hand_normals), _f32(obj_verts), I(n), I(nh), I(no), *args, _f32(hc), None)
+        _call('vpho_contact_detect_f32', _f32(obj_verts), _f32(obj_normals), _f32(hand_verts), I(n), I(no), I(nh), *args, _f32(oc), _i32(o2h))
+        return hc, oc, o2h
+
+    def force_contact(self, hand_contact, thresh=0.0):
+        """ForceAnchor.get_force_contact + check_is_grasped (physics_fn.py:201-221): (n, >=778) -> (n,32), (n,) uint8"""
+        n, ld = hand_contact.shape
+        fc, gr = _new((n, 32), hand_contact), _new((n,), hand_contact, torch.uint8)
+        _call('vpho_force_contact_f32', C.byref(self.anchor), _f32(hand_contact), I(ld), I(n), F(thresh), _f32(fc), _u8(gr))
+        return fc, gr
+
     def anchor_frames(self, verts):
         """ForceAnchor.__call__ (physics_fn.py:224-257): verts (n,778,3) -> points (n,32,3), frames (n,32,3,3)"""
         n = verts.shape[0]
