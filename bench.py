@@ -55,11 +55,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # rehearsal aid for a 1-GPU box: VPHO_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (timings meaningless)
+    rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = \
         args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj, args.sample_T0

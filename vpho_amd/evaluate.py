@@ -63,7 +63,12 @@ def gather_rows(rows):
         return rows
     world = dist.get_world_size()
     out = torch.empty((world * rows.shape[0], rows.shape[1]), device=rows.device, dtype=rows.dtype)
-    dist.all_gather_into_tensor(out, rows.contiguous())
+    if dist.get_backend() == 'gloo' and rows.is_cuda:       # CPU rehearsal backend: stage through host memory
+        host = torch.empty(out.shape, dtype=rows.dtype)
+        dist.all_gather_into_tensor(host, rows.cpu().contiguous())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, rows.contiguous())
     return out
 
 
