@@ -37,6 +37,7 @@ def parse():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
     p.add_argument('--cpu_images', type=int, default=2)
+    p.add_argument('--pipeline', type=int, default=2, help='evaluation batches kept in flight (1 = sequential loop)')
     return p.parse_args()
 
 
@@ -100,18 +101,36 @@ def main():
         E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, 0)
     if args.warmup:
         E.gather_rows(E.metric_rows(out, batches[0], gt_joint, gt_vert, 0))
+        if args.pipeline > 1:
+            torch.cuda.synchronize()
     barrier()
     step_events = []
 
-    def run_steps(k):
+    pipe = E.PipelinedPredictor(model, args.pipeline) if args.pipeline > 1 else None
+
+    def run_steps(k, pipelined=True):
         rows, nfev = [], []
-        for i in range(k):
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            step_events.append(ev)
-            out = model(batches[i % 2], mode='predict')
-            rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs))
-            nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
+        if pipe is not None and pipelined:
+            def post(out, batch, engine, i=0):
+                return None
+            futs = []
+            for i in range(k):
+                first = (rank * k + i) * args.bs
+                futs.append(pipe.submit(batches[i % 2], lambda out, batch, engine, first=first: (
+                    E.metric_rows(out, batch, gt_joint, gt_vert, first),
+                    (engine.last_info['hand_ode']['nfev'], engine.last_info['obj_ode']['nfev']))))
+            for f in futs:
+                r, n = f.result()
+                rows.append(r)
+                nfev.append(n)
+        else:
+            for i in range(k):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                step_events.append(ev)
+                out = model(batches[i % 2], mode='predict')
+                rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs))
+                nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
         return E.gather_rows(torch.cat(rows, 0)), nfev     # the ONE collective of the evaluation
 
     # ---- timed region: K steps, no instrumentation -----------------------------------------------------------------
@@ -121,7 +140,13 @@ def main():
     ev_end.record()
     barrier()
     dt = time.perf_counter() - t0
-    ev_all = step_events[:args.steps] + [ev_end]
+    if pipe is not None:                                   # per-step latencies: a short sequential run after the timed region
+        step_events.clear()
+        run_steps(min(args.steps, 5), pipelined=False)
+        ev_end = torch.cuda.Event(enable_timing=True)
+        ev_end.record()
+        torch.cuda.synchronize()
+    ev_all = step_events + [ev_end]
     step_ms_seq = [a.elapsed_time(b) for a, b in zip(ev_all[:-1], ev_all[1:])]
     step_ms = sorted(step_ms_seq)
     if os.environ.get('VPHO_BENCH_VERBOSE') and rank == 0:
@@ -133,7 +158,7 @@ def main():
     if not args.no_kernel_timing:
         for c in timed_classes:
             ops.prof_enable(c, True)
-        run_steps(args.steps)
+        run_steps(args.steps, pipelined=False)
         barrier()
         for c in timed_classes:
             ops.prof_enable(c, False)
@@ -160,6 +185,7 @@ def main():
                                     else 'non-default config (see the keys below)'),
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
+                       'pipeline_depth': args.pipeline,
                        'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,

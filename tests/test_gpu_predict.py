@@ -154,3 +154,30 @@ def test_quaternion_mean_of_identical_rotations_is_finite(assets):
     out = agg.hand_phys_fuse(cand, idx)
     assert torch.isfinite(out).all()
     assert (out - cand[:, 0]).abs().max().item() < 2e-5          # mean of identical rotations is that rotation
+
+
+def test_pipelined_evaluator_equals_sequential_loop(model_cpu, assets):
+    """Two batches in flight on two streams / host threads give bit-identical outputs, and a seeded pipelined run draws the same
+    CPU prior as the sequential `model(batch)` loop (hand then object, batch after batch)."""
+    import copy
+    from vpho_amd import evaluate as E
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.synth import synth_batch
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 6, 4, 8, 3, 0.2
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        batches = [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(3, assets, seed=400 + i).items()} for i in range(4)]
+        torch.manual_seed(77)
+        seq = [m(b, mode='predict') for b in batches]
+        torch.cuda.synchronize()
+        pipe = E.PipelinedPredictor(m, depth=2)
+        torch.manual_seed(77)
+        futs = [pipe.submit(b) for b in batches]
+        par = [f.result() for f in futs]
+        pipe.close()
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+    for a, b in zip(seq, par):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

@@ -64,15 +64,21 @@ class Trainer:
         cfg, bs = self.cfg, self.cfg.eval_batch_size
         rows = []
         t0 = time.perf_counter()
-        gt = None
-        for i in range(cfg.num_batches):
-            batch = synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank)
-            batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-            out = self.model(batch, mode='predict')
-            if gt is None:                                             # synthetic ground truth: regression of the first batch
-                gt = (out['reg_hand_joint'] + batch['root_joint'][:, None], out['reg_hand_vert'] + batch['root_joint'][:, None])
+        # two batches in flight (independent images; see evaluate.PipelinedPredictor); batch 0 also provides the synthetic
+        # ground truth (its own regression output), so it is evaluated first
+        pipe = E.PipelinedPredictor(self.model, depth=2)
+        make = lambda i: {k: (v.to(self.device) if torch.is_tensor(v) else v)
+                          for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
+        b0 = make(0)
+        out0 = pipe.submit(b0).result()
+        gt = (out0['reg_hand_joint'] + b0['root_joint'][:, None], out0['reg_hand_vert'] + b0['root_joint'][:, None])
+        rows.append(E.metric_rows(out0, b0, gt[0], gt[1], self.rank * cfg.num_batches * bs))
+        futs = []
+        for i in range(1, cfg.num_batches):
             first = (self.rank * cfg.num_batches + i) * bs
-            rows.append(E.metric_rows(out, batch, gt[0], gt[1], first))
+            futs.append(pipe.submit(make(i), lambda out, batch, eng, first=first: E.metric_rows(out, batch, gt[0], gt[1], first)))
+        rows += [f.result() for f in futs]
+        pipe.close()
         rows = E.gather_rows(torch.cat(rows, 0))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
