@@ -26,7 +26,7 @@ FEATURE_GFLOP_PER_IMAGE = 37.09
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--bs', type=int, default=64)
     p.add_argument('--sample_num', type=int, default=100)

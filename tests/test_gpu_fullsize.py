@@ -128,3 +128,52 @@ def test_conv_linearity_at_full_size():
     lhs = f(0.7 * x - 1.3 * y)
     rhs = 0.7 * f(x) - 1.3 * f(y)
     assert (lhs - rhs).abs().max().item() < 2e-4 * rhs.abs().max().item()
+
+
+@pytest.mark.parametrize('bs', [5, 70])
+def test_cross_module_large_batch_matches_oracle(model_cpu, sd, bs):
+    """CrossModule attends over the BATCH axis (quirk Q3): bs=70 exceeds the LDS-resident K/V tile of the attention kernel and
+    takes its in-place K/V path; both paths against the oracle."""
+    import copy
+    from oracle import nets as N
+    from vpho_amd.model.engine import Engine
+    g = torch.Generator().manual_seed(bs)
+    xh, xo = torch.randn(bs, 256, 8, 8, generator=g) * 0.2, torch.randn(bs, 256, 8, 8, generator=g) * 0.2
+    grav = torch.nn.functional.normalize(torch.randn(bs, 1, 3, generator=g), dim=-1)
+    is_left = torch.rand(bs, generator=g) < 0.5
+    gflip = grav.clone()
+    gflip[is_left, ..., 0] *= -1
+    ref_h, ref_o, _ = N.cross_module(sd, 'cross_hand', xh, xo, gflip)
+    eng = Engine(copy.deepcopy(model_cpu).cuda().eval())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    tok = eng._cross(eng.cross['hand'], nhwc(xh), nhwc(xo), grav.view(bs, 3).cuda().contiguous(), is_left.to(torch.uint8).cuda())
+    tok = tok.view(bs, 65, 512).cpu()
+    assert (tok[:, :32] - ref_h).abs().max().item() < 1e-4
+    assert (tok[:, 32:64] - ref_o).abs().max().item() < 1e-4
+
+
+def test_stress_config_cfg4_properties(model_cpu, assets):
+    """BASELINE.json configs[3]: bs=128, sample_num=256 (2S = 512 candidates = the top-k kernel's limit), sampling_steps=100."""
+    import copy
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.synth import synth_batch
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 256, 100, 30, 10, 0.65
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(128, assets, seed=9).items()}
+        torch.manual_seed(3)
+        out = m(data, mode='predict')
+        torch.cuda.synchronize()
+        info = m._engine.last_info
+        assert out['diff_final_hand_vert'].shape == (128, 256, 778, 3) and out['diff_inprocess_obj_6d'].shape == (128, 256, 100, 9)
+        for k, v in out.items():
+            assert torch.isfinite(v).all(), k
+        v, j = m._engine.mano.fk(out['agg_hand_mano'].contiguous(), info['features']['mano_ctx'], 1, True)
+        assert torch.equal(v, out['agg_hand_vert']) and torch.equal(j, out['agg_hand_joint'])
+        idx = info['agg']['hand_topk'][0].cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < 512
+        st = info['hand_ode']
+        assert st['nfev'] == 2 + 6 * (st['n_accepted'] + st['n_rejected']) + 1
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
