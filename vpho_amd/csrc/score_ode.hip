@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int HB_K = 32, HB_LD = HB_K + 4;
+constexpr int HB_K = 16, HB_LD = HB_K + 4;
 constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
 // --------------------------------------------------------------------------------------------- time embedding
@@ -210,8 +210,13 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     const int n = blockIdx.y, r0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
-    const int lrow = wave * 8 + (lane >> 3);            // tile row this lane fills (per pass: + 64*j)
-    const int kq = (lane & 7) ^ ((lrow >> 1) & 7);      // logical 16-B chunk this lane fetches
+    // one wave instruction fills 64 x 16 B = RPW whole tile rows; chunk swizzle f(row) = (row >> SW_SHIFT) & (CPR-1) keeps
+    // the 16 lanes of every ds_read_b128 group on distinct 16-B slots of a 256-B bank row (rows of 128 B: 2 per bank row,
+    // rows of 64 B: 4 per bank row)
+    constexpr int CPR = HB_K / 4, RPW = 64 / CPR, RPP = 8 * RPW, SW_SHIFT = CPR == 8 ? 1 : 2;
+    static_assert(CPR == 8 || CPR == 4, "BK must be 32 or 16");
+    const int lrow = wave * RPW + lane / CPR;           // tile row this lane fills (per pass: + RPP*j)
+    const int kq = (lane % CPR) ^ ((lrow >> SW_SHIFT) & (CPR - 1));      // logical 16-B chunk this lane fetches
     const float* Wg = a.w1p + (long long)n * 256 * 256;
 
     if (tid < 256) {   // epilogue table
@@ -222,24 +227,24 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
     }
 
-    const float* wsrc[4];
-    const float* psrc[2];
-    int pstep[2];
+    const float* wsrc[256 / RPP];
+    const float* psrc[128 / RPP];
+    int pstep[128 / RPP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wsrc[j] = Wg + (lrow + 64 * j) * 256 + 4 * kq;
+    for (int j = 0; j < 256 / RPP; ++j) wsrc[j] = Wg + (lrow + RPP * j) * 256 + 4 * kq;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = r0 + lrow + 64 * j;
+    for (int j = 0; j < 128 / RPP; ++j) {
+        const int r = r0 + lrow + RPP * j;
         psrc[j] = r < a.R ? a.p2 + (long long)r * 256 + 4 * kq : g_head_zero_page;
         pstep[j] = r < a.R ? HB_K : 0;
     }
     auto fill = [&](int buf) {
-        float* Ws = smem + buf * STAGE + wave * 8 * HB_K;
-        float* Ps = smem + buf * STAGE + 256 * HB_K + wave * 8 * HB_K;
+        float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
+        float* Ps = smem + buf * STAGE + 256 * HB_K + wave * RPW * HB_K;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { __builtin_amdgcn_global_load_lds(wsrc[j], Ws + 64 * j * HB_K, 16, 0, 0); wsrc[j] += HB_K; }
+        for (int j = 0; j < 256 / RPP; ++j) { __builtin_amdgcn_global_load_lds(wsrc[j], Ws + RPP * j * HB_K, 16, 0, 0); wsrc[j] += HB_K; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { __builtin_amdgcn_global_load_lds(psrc[j], Ps + 64 * j * HB_K, 16, 0, 0); psrc[j] += pstep[j]; }
+        for (int j = 0; j < 128 / RPP; ++j) { __builtin_amdgcn_global_load_lds(psrc[j], Ps + RPP * j * HB_K, 16, 0, 0); psrc[j] += pstep[j]; }
     };
 
     f32x16 acc[4];
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    const int sw = (li >> 1) & 7;
+    const int sw = (li >> SW_SHIFT) & (CPR - 1);
     fill(0);
     __syncthreads();
     constexpr int NK = 256 / HB_K;
