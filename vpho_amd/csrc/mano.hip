@@ -60,108 +60,152 @@ struct FkArgs {
     float* joints;                             // (n_hands, 21, 3)
 };
 
+// Block = HB hands (blockIdx.x) x up to 4 wave-chunks of 64 vertices (blockIdx.y; 13 chunks cover the 778 vertices).
+// The kinematic part runs with one thread per (hand, joint): Rodrigues, then the 16-joint chain level by level (MANO's
+// tree is root -> 5 fingers x 3 joints, so 4 levels).  The skinning part keeps HB x 3 pose-blend accumulators per
+// thread-vertex, so one pass over the 1.26 MB pose-blend table (L2) serves HB hands instead of one.
+template <int HB>
 __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
-    __shared__ float R[16][9];
-    __shared__ float G[16][12];      // global transforms (3x4 row-major)
-    __shared__ float A[16][12];      // skinning transforms
-    __shared__ float pm[135];
-    __shared__ float jt[21][3];      // 16 MANO joints + 5 tips (un-centred, MANO order)
-    __shared__ float tipv[10][3];
-    const long long hand = blockIdx.x;
-    const int img = (int)(hand / a.hands_per_image);
-    const float* pose = a.pose + hand * a.ld_pose;
-    const float* Jr = a.J + img * 48;
-    const float* vsh = a.v_shaped + (long long)img * NV * 3;
+    __shared__ float R[HB][16][9];
+    __shared__ float G[HB][16][12];                                  // global transforms (3x4 row-major)
+    __shared__ __attribute__((aligned(16))) float A[HB][16][12];     // skinning transforms
+    __shared__ __attribute__((aligned(16))) float pmT[135][HB];      // pose map R_j - I (j = 1..15), hand-minor
+    __shared__ float jt[HB][21][3];                                  // 16 MANO joints + 5 tips (un-centred, MANO order)
+    __shared__ float tipv[HB][10][3];
     const int tid = threadIdx.x;
+    const long long h0 = (long long)blockIdx.x * HB;
+    // hands past the end of the last group recompute the last hand and are never written
+    auto hand_of = [&](int h) { const long long g = h0 + h; return g < a.n_hands ? g : a.n_hands - 1; };
+    auto img_of = [&](int h) { return (int)(hand_of(h) / a.hands_per_image); };
+    const int hj_h = tid >> 4, hj_j = tid & 15;                      // (hand, joint) role of the first HB*16 threads
+    const bool hj = tid < HB * 16;
 
-    if (tid < 16) {
+    if (hj) {
         float r[9];
-        vpho::mano_rodrigues(pose + 3 * tid, r);
-        for (int k = 0; k < 9; ++k) R[tid][k] = r[k];
+        vpho::mano_rodrigues(a.pose + hand_of(hj_h) * a.ld_pose + 3 * hj_j, r);
+        for (int k = 0; k < 9; ++k) R[hj_h][hj_j][k] = r[k];
     }
     __syncthreads();
-    for (int i = tid; i < 135; i += blockDim.x) {
-        const int j = i / 9 + 1, k = i % 9;
-        pm[i] = R[j][k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+    for (int i = tid; i < HB * 135; i += 256) {
+        const int h = i / 135, k = i - h * 135;
+        const int e = k % 9;
+        pmT[k][h] = R[h][k / 9 + 1][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
     }
-    if (tid == 0) {
-        // root: [R0 | J0]; child: G[parent] * [R_i | J_i - J_parent]   (MANO joint order is parent-before-child)
-        for (int k = 0; k < 3; ++k) { for (int c = 0; c < 3; ++c) G[0][k * 4 + c] = R[0][k * 3 + c]; G[0][k * 4 + 3] = Jr[k]; }
-        for (int i = 1; i < 16; ++i) {
-            const int p = c_parent[i];
-            const float rel[3] = {Jr[i * 3 + 0] - Jr[p * 3 + 0], Jr[i * 3 + 1] - Jr[p * 3 + 1], Jr[i * 3 + 2] - Jr[p * 3 + 2]};
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) {
+    // chain: root [R0 | J0]; child G[parent] * [R_i | J_i - J_parent]; joint i sits (i-1)%3+1 levels below the root
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        if (hj && (hj_j == 0 ? 0 : (hj_j - 1) % 3 + 1) == lvl) {
+            const float* Jr = a.J + img_of(hj_h) * 48;
+            const int i = hj_j;
+            float (*Gh)[12] = G[hj_h];
+            const float* Ri = R[hj_h][i];
+            if (i == 0) {
+                for (int k = 0; k < 3; ++k) { for (int c = 0; c < 3; ++c) Gh[0][k * 4 + c] = Ri[k * 3 + c]; Gh[0][k * 4 + 3] = Jr[k]; }
+            } else {
+                const int p = c_parent[i];
+                const float rel[3] = {Jr[i * 3 + 0] - Jr[p * 3 + 0], Jr[i * 3 + 1] - Jr[p * 3 + 1], Jr[i * 3 + 2] - Jr[p * 3 + 2]};
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) {
+                        float s = 0.f;
+                        for (int k = 0; k < 3; ++k) s += Gh[p][r * 4 + k] * Ri[k * 3 + c];
+                        Gh[i][r * 4 + c] = s;
+                    }
                     float s = 0.f;
-                    for (int k = 0; k < 3; ++k) s += G[p][r * 4 + k] * R[i][k * 3 + c];
-                    G[i][r * 4 + c] = s;
+                    for (int k = 0; k < 3; ++k) s += Gh[p][r * 4 + k] * rel[k];
+                    Gh[i][r * 4 + 3] = s + Gh[p][r * 4 + 3];
                 }
-                float s = 0.f;
-                for (int k = 0; k < 3; ++k) s += G[p][r * 4 + k] * rel[k];
-                G[i][r * 4 + 3] = s + G[p][r * 4 + 3];
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < 16) {
-        const int i = tid;
+    if (hj) {
+        const float* Jr = a.J + img_of(hj_h) * 48;
+        const int i = hj_j;
         for (int r = 0; r < 3; ++r) {
             float s = 0.f;
-            for (int k = 0; k < 3; ++k) s += G[i][r * 4 + k] * Jr[i * 3 + k];
-            for (int c = 0; c < 3; ++c) A[i][r * 4 + c] = G[i][r * 4 + c];
-            A[i][r * 4 + 3] = G[i][r * 4 + 3] - s;
-            jt[i][r] = G[i][r * 4 + 3];
+            for (int k = 0; k < 3; ++k) s += G[hj_h][i][r * 4 + k] * Jr[i * 3 + k];
+            for (int c = 0; c < 3; ++c) A[hj_h][i][r * 4 + c] = G[hj_h][i][r * 4 + c];
+            A[hj_h][i][r * 4 + 3] = G[hj_h][i][r * 4 + 3] - s;
+            jt[hj_h][i][r] = G[hj_h][i][r * 4 + 3];
         }
     }
     __syncthreads();
 
-    auto skin = [&](int v, float* out3) {
+    // vp = v_shaped + posedirs . pose_map (k ascending), T = sum_j w_j A_j (j ascending), out = T [vp; 1]
+    auto skin_tail = [&](int h, int v, const float* wv, const float* blend, float* out3) {
+        const float* vsh = a.v_shaped + (long long)img_of(h) * NV * 3;
         float vp[3];
-        for (int c = 0; c < 3; ++c) {
-            float s = 0.f;
-            const float* pd = a.t.posedirs_t + v * 3 + c;          // [k][v*3+c]
-            for (int k = 0; k < 135; ++k) s += pd[(long long)k * NV * 3] * pm[k];
-            vp[c] = vsh[v * 3 + c] + s;
-        }
+        for (int c = 0; c < 3; ++c) vp[c] = vsh[v * 3 + c] + blend[c];
         float T[12];
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
         for (int j = 0; j < 16; ++j) {
-            const float w = a.t.weights[v * 16 + j];
-            for (int e = 0; e < 12; ++e) T[e] += A[j][e] * w;
+            const float w = wv[j];
+            for (int e = 0; e < 12; ++e) T[e] += A[h][j][e] * w;
         }
         for (int r = 0; r < 3; ++r) out3[r] = T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3];
     };
-    const bool ho = a.ho3d && a.ho3d[img];
-    if (tid < 10) {
-        float o[3];
-        skin(tid < 5 ? c_tips[tid] : c_tips_ho3d[tid - 5], o);
-        for (int c = 0; c < 3; ++c) tipv[tid][c] = o[c];
-        if (tid < 5) for (int c = 0; c < 3; ++c) jt[16 + tid][c] = o[c];
-    }
-    __syncthreads();
-    const float cx = jt[0][0], cy = jt[0][1], cz = jt[0][2];
     // centre on joint 0, mm (*1000) and back to metres (/1000) exactly as manopth + head_mano.py:85-86
     auto fin = [](float v, float c) { return ((v - c) * 1000.f) / 1000.f; };
-    if (tid < 21) {
-        float o[3];
-        if (!ho) {
-            const int s = c_order[tid];
-            o[0] = fin(jt[s][0], cx); o[1] = fin(jt[s][1], cy); o[2] = fin(jt[s][2], cz);
-        } else if (tid >= 16) {      // hand_fn.py:454-461: HO3D joint order with its own tip vertices
-            o[0] = fin(tipv[5 + tid - 16][0], cx); o[1] = fin(tipv[5 + tid - 16][1], cy); o[2] = fin(tipv[5 + tid - 16][2], cz);
-        } else {
-            const int s = c_order[c_to_manolayer[tid]];
-            o[0] = fin(jt[s][0], cx); o[1] = fin(jt[s][1], cy); o[2] = fin(jt[s][2], cz);
+
+    if (blockIdx.y == 0) {
+        for (int t = tid; t < HB * 10; t += 256) {
+            const int h = t / 10, tip = t - h * 10;
+            const int v = tip < 5 ? c_tips[tip] : c_tips_ho3d[tip - 5];
+            float blend[3], wv[16], o[3];
+            for (int c = 0; c < 3; ++c) {
+                float s = 0.f;
+                const float* pd = a.t.posedirs_t + v * 3 + c;          // [k][v*3+c]
+                for (int k = 0; k < 135; ++k) s += pd[(long long)k * NV * 3] * pmT[k][h];
+                blend[c] = s;
+            }
+            for (int j = 0; j < 16; ++j) wv[j] = a.t.weights[v * 16 + j];
+            skin_tail(h, v, wv, blend, o);
+            for (int c = 0; c < 3; ++c) tipv[h][tip][c] = o[c];
+            if (tip < 5) for (int c = 0; c < 3; ++c) jt[h][16 + tip][c] = o[c];
         }
-        float* jo = a.joints + (hand * 21 + tid) * 3;
-        jo[0] = o[0]; jo[1] = o[1]; jo[2] = o[2];
+        __syncthreads();
+        for (int t = tid; t < HB * 21; t += 256) {
+            const int h = t / 21, q = t - h * 21;
+            if (h0 + h >= a.n_hands) continue;
+            const bool ho = a.ho3d && a.ho3d[img_of(h)];
+            const float cx = jt[h][0][0], cy = jt[h][0][1], cz = jt[h][0][2];
+            const float* src;
+            if (!ho) src = jt[h][c_order[q]];
+            else if (q >= 16) src = tipv[h][5 + q - 16];             // hand_fn.py:454-461: HO3D joint order with its own tip vertices
+            else src = jt[h][c_order[c_to_manolayer[q]]];
+            float* jo = a.joints + ((h0 + h) * 21 + q) * 3;
+            jo[0] = fin(src[0], cx); jo[1] = fin(src[1], cy); jo[2] = fin(src[2], cz);
+        }
     }
     if (a.verts) {
-        float* vo = a.verts + hand * NV * 3;
-        for (int v = tid; v < NV; v += blockDim.x) {
-            float o[3];
-            skin(v, o);
-            vo[v * 3 + 0] = fin(o[0], cx); vo[v * 3 + 1] = fin(o[1], cy); vo[v * 3 + 2] = fin(o[2], cz);
+        const int v = (blockIdx.y * 4 + (tid >> 6)) * 64 + (tid & 63);
+        if (v < NV) {
+            float acc[HB][3];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.f;
+            const float* pd = a.t.posedirs_t + v * 3;
+#pragma unroll 3
+            for (int k = 0; k < 135; ++k) {
+                const float p0 = pd[(long long)k * NV * 3], p1 = pd[(long long)k * NV * 3 + 1], p2 = pd[(long long)k * NV * 3 + 2];
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float m = pmT[k][h];
+                    acc[h][0] += p0 * m; acc[h][1] += p1 * m; acc[h][2] += p2 * m;
+                }
+            }
+            float wv[16];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.t.weights + v * 16 + j);
+                wv[j] = w4[0]; wv[j + 1] = w4[1]; wv[j + 2] = w4[2]; wv[j + 3] = w4[3];
+            }
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                if (h0 + h >= a.n_hands) break;
+                float o[3];
+                skin_tail(h, v, wv, acc[h], o);
+                float* vo = a.verts + ((h0 + h) * NV + v) * 3;
+                vo[0] = fin(o[0], jt[h][0][0]); vo[1] = fin(o[1], jt[h][0][1]); vo[2] = fin(o[2], jt[h][0][2]);
+            }
         }
     }
 }
@@ -183,6 +227,10 @@ extern "C" int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, in
     FkArgs a;
     a.t = *t; a.pose = pose; a.ld_pose = ld_pose; a.v_shaped = v_shaped; a.J = J; a.n_hands = n_hands;
     a.hands_per_image = hands_per_image; a.ho3d = ho3d_per_image; a.verts = verts; a.joints = joints;
-    hipLaunchKernelGGL(mano_fk_kernel, dim3((unsigned)n_hands), dim3(verts ? 256 : 64), 0, (hipStream_t)stream, a);
+    // hands per block: enough reuse of the pose-blend table for big batches, enough blocks for small ones
+    const unsigned gy = verts ? 4 : 1;
+    if (n_hands >= 1024) hipLaunchKernelGGL(mano_fk_kernel<16>, dim3((unsigned)((n_hands + 15) / 16), gy), dim3(256), 0, (hipStream_t)stream, a);
+    else if (n_hands >= 128) hipLaunchKernelGGL(mano_fk_kernel<4>, dim3((unsigned)((n_hands + 3) / 4), gy), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mano_fk_kernel<1>, dim3((unsigned)n_hands, gy), dim3(256), 0, (hipStream_t)stream, a);
     return vpho::check_launch("mano_fk_kernel");
 }

@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weight
 // Block = 32 hypotheses x all 256 hidden units, 4 waves (wave w owns hidden columns 64w..64w+63 = two 32x32 MFMA tiles);
 // the 32x256 intermediate stays in LDS, weights stream through a double-buffered [256][32] LDS chunk.
 struct LinComb { double c[7]; int n; double h; };
+// the seven stage-derivative buffers K_0..K_6 by LOGICAL stage index; first-same-as-last is a pointer swap on the host
+struct KSlots { const float* p[7]; };
 
 // Input rows either come from X ([R][Dp] fp32) or are formed on the fly as the RK stage state
 // x = (float)(y + h * sum_j c_j K_j)  (scipy rk_step: y + dy, then ode_func's .float(), score_based_model.py:76)
 struct PoseEncArgs {
     const float* X; int Dp;            // [R][Dp]
-    const double* y; const float* Kst; long long n_el; int D; LinComb lc; double* ynew; int use_lc;
+    const double* y; KSlots ks; int D; LinComb lc; double* ynew; int use_lc;
     const float *w0, *b0, *w2, *b2;    // [256][Dp], [256], [256][256], [256]
     float* out; int R;                 // [R][256]
 };
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void pose_encoder_kernel(const PoseEncArgs a) 
                     if (c + u < a.D) {
                         const long long e = (long long)(r0 + r) * a.D + c + u;
                         double sacc = 0.0;
-                        for (int j = 0; j < a.lc.n; ++j) sacc += (double)a.Kst[j * a.n_el + e] * a.lc.c[j];
+                        for (int j = 0; j < a.lc.n; ++j) sacc += (double)a.ks.p[j][e] * a.lc.c[j];
                         const double xv = a.y[e] + sacc * a.lc.h;
                         v[u] = (float)xv;
                         if (a.ynew) a.ynew[e] = xv;
@@ -254,29 +256,39 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     const int sw = (li >> SW_SHIFT) & (CPR - 1);
+    constexpr int NK = 256 / HB_K, NKK = HB_K / 8;
+    // Two LDS stages.  The barrier of k-tile kt sits before its LAST 8-wide MFMA group: by then every wave has its
+    // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
+    // load has a whole k-tile of MFMA time to land before the next barrier needs it.
     fill(0);
     __syncthreads();
-    constexpr int NK = 256 / HB_K;
+    fill(1);
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < NK) fill(buf ^ 1);
         const float* As = smem + buf * STAGE + (hh * 128 + li) * HB_K;
         const float* Bs = smem + buf * STAGE + 256 * HB_K + (rg * 32 + li) * HB_K;
-#pragma unroll
-        for (int kk = 0; kk < HB_K / 8; ++kk) {
+        f32x4 b, av[4];
+        auto frags = [&](int kk) {
             const int ch = ((2 * kk + lh) ^ sw) * 4;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + ch);
-            f32x4 av[4];
+            b = *reinterpret_cast<const f32x4*>(Bs + ch);
 #pragma unroll
             for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_K + ch);
+        };
+        auto mfmas = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b[q], acc[i], 0, 0, 0);
-        }
+        };
+#pragma unroll
+        for (int kk = 0; kk < NKK - 1; ++kk) { frags(kk); mfmas(); }
+        frags(NKK - 1);
         __syncthreads();
+        if (kt + 2 < NK) fill(buf);
+        mfmas();
     }
+    __syncthreads();
 
     // epilogue: hidden unit j = 128*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
     const int lrow_out = rg * 32 + li;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
 
 // --------------------------------------------------------------------------------------------- RK stage algebra
 // X[r][0..Dp) = (float)(y + h * sum_j c_j K_j), pad columns zero; optionally also stores the fp64 sum to ynew
-__global__ void stage_input_kernel(const double* __restrict__ y, const float* __restrict__ K, long long n_el, int D, int Dp,
+__global__ void stage_input_kernel(const double* __restrict__ y, KSlots ks, long long n_el, int D, int Dp,
                                    LinComb lc, float* __restrict__ X, double* __restrict__ ynew) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long R = n_el / D;
@@ -333,7 +345,7 @@ __global__ void stage_input_kernel(const double* __restrict__ y, const float* __
     if (c >= D) { X[i] = 0.f; return; }
     const long long e = r * D + c;
     double s = 0.0;
-    for (int j = 0; j < lc.n; ++j) s += (double)K[j * n_el + e] * lc.c[j];
+    for (int j = 0; j < lc.n; ++j) s += (double)ks.p[j][e] * lc.c[j];
     const double v = y[e] + s * lc.h;
     X[i] = (float)v;
     if (ynew) ynew[e] = v;
@@ -353,7 +365,7 @@ __global__ void f32_to_state_kernel(const float* __restrict__ x, long long n_el,
 
 // mode 0: (y/scale)^2, scale = atol+|y|rtol; 1: (Ka/scale)^2; 2: ((Kb-Ka)/scale)^2; 3: RK45 error with scale from (y, ynew)
 struct NormArgs {
-    const double* y; const double* ynew; const float* Ka; const float* Kb; const float* K; long long n_el;
+    const double* y; const double* ynew; const float* Ka; const float* Kb; KSlots ks; long long n_el;
     double rtol, atol, h; double E[7]; int mode; double* partial;
 };
 __global__ __launch_bounds__(256) void norm_partial_kernel(const NormArgs a) {
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const NormArgs a) {
         double v, scale;
         if (a.mode == 3) {
             double e = 0.0;
-            for (int j = 0; j < 7; ++j) e += (double)a.K[j * a.n_el + i] * a.E[j];
+            for (int j = 0; j < 7; ++j) e += (double)a.ks.p[j][i] * a.E[j];
             v = e * a.h;
             scale = a.atol + fmax(fabs(a.y[i]), fabs(a.ynew[i])) * a.rtol;
         } else {
@@ -398,14 +410,14 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
 // dense output (scipy RkDenseOutput): y_old + h * (K^T P) . [x, x^2, x^3, x^4] for every t_eval stamp inside the step
 constexpr int DENSE_MAX = 48;
 struct DenseArgs { double P[7][4]; double p[DENSE_MAX][4]; int idx[DENSE_MAX]; int n; double h; };
-__global__ void dense_kernel(const double* __restrict__ y_old, const float* __restrict__ K, long long n_el, int D,
+__global__ void dense_kernel(const double* __restrict__ y_old, KSlots ks, long long n_el, int D,
                              DenseArgs da, void* __restrict__ xs, int is_f64, int num_steps) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
     double q[4];
     for (int m = 0; m < 4; ++m) {
         double s = 0.0;
-        for (int j = 0; j < 7; ++j) s += (double)K[j * n_el + i] * da.P[j][m];
+        for (int j = 0; j < 7; ++j) s += (double)ks.p[j][i] * da.P[j][m];
         q[m] = s;
     }
     const double y0 = y_old[i];
@@ -499,7 +511,7 @@ int embed_times(Ctx& c, const float* ts, int n) {
 
 // ct_slot < 0: embed t now into slot 0; otherwise slot ct_slot was filled by embed_times for exactly this t
 int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* out, int ct_slot = -1,
-             const LinComb* lc = nullptr, const double* y = nullptr, double* ynew = nullptr) {
+             const LinComb* lc = nullptr, const double* y = nullptr, double* ynew = nullptr, const KSlots* ks = nullptr) {
     if (ct_slot < 0) {
         if (int e = embed_times(c, &t, 1)) return e;
         ct_slot = 0;
@@ -509,7 +521,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         memset(&pa, 0, sizeof(pa));
         pa.X = X; pa.Dp = c.w->Dp; pa.w0 = c.w->pe0_w; pa.b0 = c.w->pe0_b; pa.w2 = c.w->pe2_w; pa.b2 = c.w->pe2_b;
         pa.out = c.ws.P2; pa.R = (int)c.R;
-        if (lc) { pa.use_lc = 1; pa.lc = *lc; pa.y = y; pa.Kst = c.ws.K; pa.n_el = c.n_el; pa.D = c.w->D; pa.ynew = ynew; }
+        if (lc) { pa.use_lc = 1; pa.lc = *lc; pa.y = y; pa.ks = *ks; pa.D = c.w->D; pa.ynew = ynew; }
         const int K1 = (pa.Dp + 31) / 32 * 32;
         const size_t pe_lds = (size_t)(2 * 256 * PE_LD + PE_ROWS * PE_H_LD + PE_ROWS * (K1 + 4)) * sizeof(float);
         static bool pe_opt_in = false;
@@ -541,11 +553,11 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
 
 // rhs(t, .) of the probability-flow ODE: 0 - f32(0.5 g(t)^2) * score     (score_based_model.py:74-83)
 int eval_rhs(Ctx& c, const float* X, double t, float* out, int ct_slot = -1, const LinComb* lc = nullptr,
-             const double* y = nullptr, double* ynew = nullptr) {
+             const double* y = nullptr, double* ynew = nullptr, const KSlots* ks = nullptr) {
     const float tf = (float)t;
     const double g = (double)sigma_f32(tf) * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
     const float coef = (float)(0.5 * g * g);
-    return eval_net(c, X, tf, 1, coef, out, ct_slot, lc, y, ynew);
+    return eval_net(c, X, tf, 1, coef, out, ct_slot, lc, y, ynew, ks);
 }
 
 double* pinned_slot() {
@@ -624,8 +636,9 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
     const long long n_el = c.n_el;
     const int D = w->D, Dp = w->Dp;
     const int nbX = (int)((c.R * Dp + 255) / 256), nbE = (int)((n_el + 255) / 256);
-    float* K = c.ws.K;
-    auto Kp = [&](int j) { return K + (long long)j * n_el; };
+    KSlots ks;
+    for (int j = 0; j < 7; ++j) ks.p[j] = c.ws.K + (long long)j * n_el;
+    auto Kp = [&](int j) { return const_cast<float*>(ks.p[j]); };
 
     VPHO_HIP(hipMemsetAsync(c.ws.nan_count, 0, 4, c.s));
     if (int e = prepare_cimg(c, feat_img)) return e;
@@ -671,7 +684,7 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
         LinComb lc;
         memset(&lc, 0, sizeof(lc));
         lc.n = 1; lc.c[0] = 1.0; lc.h = h0 * direction;
-        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
+        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, ks, n_el, D, Dp, lc, c.ws.X, (double*)nullptr);
         if (int e = eval_rhs(c, c.ws.X, t + h0 * direction, Kp(1))) return e;
         ++st->nfev;
         na.mode = 2; na.Ka = Kp(0); na.Kb = Kp(1);
@@ -705,19 +718,19 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
                 memset(&lc, 0, sizeof(lc));
                 lc.n = s; lc.h = h;
                 for (int j = 0; j < s; ++j) lc.c[j] = RK_A[s][j];
-                if (int e = eval_rhs(c, nullptr, t + RK_C[s] * h, Kp(s), s - 1, &lc, y, nullptr)) return e;   // stage state formed in the pose encoder
+                if (int e = eval_rhs(c, nullptr, t + RK_C[s] * h, Kp(s), s - 1, &lc, y, nullptr, &ks)) return e;   // stage state formed in the pose encoder
             }
             {
                 LinComb lc;
                 memset(&lc, 0, sizeof(lc));
                 lc.n = 6; lc.h = h;
                 for (int j = 0; j < 6; ++j) lc.c[j] = RK_B[j];
-                if (int e = eval_rhs(c, nullptr, t + h, Kp(6), 5, &lc, y, ynew)) return e;                    // also stores y_new (fp64)
+                if (int e = eval_rhs(c, nullptr, t + h, Kp(6), 5, &lc, y, ynew, &ks)) return e;                    // also stores y_new (fp64)
             }
             st->nfev += 6;
             NormArgs na;
             memset(&na, 0, sizeof(na));
-            na.mode = 3; na.y = y; na.ynew = ynew; na.K = K; na.h = h; na.rtol = rtol; na.atol = atol;
+            na.mode = 3; na.y = y; na.ynew = ynew; na.ks = ks; na.h = h; na.rtol = rtol; na.atol = atol;
             for (int j = 0; j < 7; ++j) na.E[j] = RK_E[j];
             double err;
             if (int e = reduce_norm(c, na, &err)) return e;
@@ -747,17 +760,17 @@ extern "C" int vpho_ode_sample(const vpho_score_weights* w, const float* feat_im
                 pp[0] = x; pp[1] = x * x; pp[2] = pp[1] * x; pp[3] = pp[2] * x;
                 da.idx[da.n++] = next_idx++;
             }
-            hipLaunchKernelGGL(dense_kernel, dim3(nbE), dim3(256), 0, c.s, y, K, n_el, D, da, xs_out, xs_is_f64, num_steps);
+            hipLaunchKernelGGL(dense_kernel, dim3(nbE), dim3(256), 0, c.s, y, ks, n_el, D, da, xs_out, xs_is_f64, num_steps);
         }
         // accept: y <- y_new, f <- f_new (first-same-as-last)
         std::swap(y, ynew);
-        VPHO_HIP(hipMemcpyAsync(Kp(0), Kp(6), n_el * 4, hipMemcpyDeviceToDevice, c.s));
+        std::swap(ks.p[0], ks.p[6]);
         t = t_new;
     }
     // reverse-diffusion predictor "denoise" step at t = eps
     {
         const float tfl = (float)eps;
-        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, K, n_el, D, Dp, LinComb{{0}, 0, 0.0}, c.ws.X, (double*)nullptr);
+        hipLaunchKernelGGL(stage_input_kernel, dim3(nbX), dim3(256), 0, c.s, y, ks, n_el, D, Dp, LinComb{{0}, 0, 0.0}, c.ws.X, (double*)nullptr);
         if (int e = eval_net(c, c.ws.X, tfl, 0, 0.f, c.ws.tmp)) return e;
         ++st->nfev;
         const float g = sigma_f32(tfl) * (float)std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvpho_hip.so')
+LIB_PATH = os.environ.get('VPHO_HIP_LIB') or os.path.join(_HERE, 'libvpho_hip.so')   # override: A/B kernel builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f'{LIB_PATH} is missing: build the HIP extension first (python -m vpho_amd.build or '
