@@ -204,8 +204,8 @@ __global__ void cross_tokens_kernel(const float* __restrict__ ph, const float* _
 // ------------------------------------------------------------------------------------------------ attention over S
 // qkv: (S, B, 3E) rows s*B+b; one block per (b, head); S <= 256.  out (S, B, E).  softmax(q k^T / sqrt(hd)) v.
 // K (row stride hd+1, conflict-free for "lane = key") and V are staged in LDS when they fit, otherwise read in place.
-__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, int use_lds,
-                                                  float* __restrict__ out) {
+__global__ __launch_bounds__(256) void mha_generic_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, int use_lds,
+                                                          float* __restrict__ out) {
     extern __shared__ float sm[];
     const int hd = E / nhead;
     const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
@@ -261,6 +261,104 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
                 }
             }
             if (d < hd) out[((long long)s * B + b) * E + h * hd + d] = a * inv;
+        }
+    }
+}
+
+// Same arithmetic (every sum in the same order), laid out for occupancy: one WAVE owns 4 consecutive queries of one
+// (b, head) and needs no LDS -- lane = key for the scores (each lane walks its own K row with 16-B loads, the 4 query
+// rows are wave-uniform), lane = feature for P.V (coalesced V rows, probabilities by readlane).  Grid = B * nhead *
+// ceil(S/16) blocks of 4 waves, so the 65-token x 2-head cross module fills the chip instead of 130 CUs.
+// Requires hd % 4 == 0 and hd <= 256.
+__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, float* __restrict__ out) {
+    const int hd = E / nhead;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nqc = (S + 15) / 16;
+    const int qc = blockIdx.x % nqc, bh = blockIdx.x / nqc;
+    const int b = bh / nhead, h = bh % nhead;
+    const int q0 = qc * 16 + wave * 4;
+    if (q0 >= S) return;
+    const long long rs = (long long)B * 3 * E;
+    const float* base = qkv + (long long)b * 3 * E + h * hd;
+    const float scl = 1.0f / sqrtf((float)hd);
+    const int nslot = (S + 63) / 64;
+    const float* qrow[4];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) qrow[qi] = base + (long long)min(q0 + qi, S - 1) * rs;
+
+    float p[4][4];                                   // [slot][query]
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) p[slot][qi] = -INFINITY;
+        if (slot < nslot) {
+            const int t = slot * 64 + lane;
+            const float* kr = base + E + (long long)(t < S ? t : S - 1) * rs;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < hd; d += 4) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + d);
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qrow[qi] + d);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[qi] += (q4[u] * scl) * k4[u];
+                }
+            }
+            if (t < S) {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) p[slot][qi] = a[qi];
+            }
+        }
+    }
+    float inv[4];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) mx = fmaxf(mx, p[slot][qi]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) {
+            const int t = slot * 64 + lane;
+            p[slot][qi] = t < S ? expf(p[slot][qi] - mx) : 0.f;
+            sum += p[slot][qi];
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        inv[qi] = 1.f / sum;
+    }
+    float acc[4][4];                                 // [query][feature chunk]
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[qi][c] = 0.f;
+    const float* vbase = base + 2 * E;
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        if (slot < nslot) {
+            const int tmax = min(64, S - slot * 64);
+            for (int tl = 0; tl < tmax; ++tl) {
+                const float* vr = vbase + (long long)(slot * 64 + tl) * rs;
+                float v[4], pt[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = c * 64 + lane < hd ? vr[c * 64 + lane] : 0.f;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) pt[qi] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p[slot][qi]), tl));
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[qi][c] += pt[qi] * v[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        if (q0 + qi < S) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int d = c * 64 + lane;
+                if (d < hd) out[((long long)(q0 + qi) * B + b) * E + h * hd + d] = acc[qi][c] * inv[qi];
+            }
         }
     }
 }
@@ -401,12 +499,16 @@ extern "C" int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_o
 extern "C" int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream) {
     VPHO_REQUIRE(qkv && out && S > 0 && S <= 256 && B > 0 && nhead > 0 && E % nhead == 0, "vpho_mha_f32: bad argument (sequence = batch axis, quirk Q3, must be <= 256; got %d)", S);
     const int hd = E / nhead;
+    if (hd % 4 == 0 && hd <= 256 && E % 4 == 0) {
+        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * nhead * ((S + 15) / 16))), dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out);
+        return vpho::check_launch("mha_kernel");
+    }
     size_t lds = (size_t)(S * (hd + 1) + S * hd) * sizeof(float);
     const int use_lds = lds <= 150 * 1024;
     if (!use_lds) lds = 0;
     static bool opt_in = false;
-    if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
-    hipLaunchKernelGGL(mha_kernel, dim3(B * nhead), dim3(256), lds, (hipStream_t)stream, qkv, S, B, E, nhead, use_lds, out);
+    if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
+    hipLaunchKernelGGL(mha_generic_kernel, dim3(B * nhead), dim3(256), lds, (hipStream_t)stream, qkv, S, B, E, nhead, use_lds, out);
     return vpho::check_launch("mha_kernel");
 }
 
