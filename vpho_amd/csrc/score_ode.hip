@@ -58,8 +58,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const vpho_score_weight
 
 // --------------------------------------------------------------------------------------------- fused pose encoder
 // P2 = relu(relu(X W0^T + b0) W2^T + b2)   (denoiser.py:60-65,74): both Linear layers of `pose_encoder` in one launch.
-// Block = 32 hypotheses x all 256 hidden units, 4 waves (wave w owns hidden columns 64w..64w+63 = two 32x32 MFMA tiles);
-// the 32x256 intermediate stays in LDS, weights stream through a double-buffered [256][32] LDS chunk.
+// Block = 32 hypotheses x all 256 hidden units; the 32x256 intermediate stays in LDS.
 struct LinComb { double c[7]; int n; double h; };
 // the seven stage-derivative buffers K_0..K_6 by LOGICAL stage index; first-same-as-last is a pointer swap on the host
 struct KSlots { const float* p[7]; };
@@ -72,32 +71,85 @@ struct PoseEncArgs {
     const float *w0, *b0, *w2, *b2;    // [256][Dp], [256], [256][256], [256]
     float* out; int R;                 // [R][256]
 };
-constexpr int PE_ROWS = 32, PE_LD = 36, PE_H_LD = 260;
-__global__ __launch_bounds__(256) void pose_encoder_kernel(const PoseEncArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K1 = (a.Dp + 31) / 32 * 32, X_LD = K1 + 4;
-    float* Ws = smem;                              // [2][256][PE_LD]
-    float* H1 = Ws + 2 * 256 * PE_LD;              // [32][PE_H_LD]
-    float* Xs = H1 + PE_ROWS * PE_H_LD;            // [32][X_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int kq = tid & 7, lrow = tid >> 3;       // 32 weight rows per load pass
-    const int r0 = blockIdx.x * PE_ROWS;
+constexpr int PE_ROWS = 32, PE_H_LD = 260, PE_NST = 3, PE_STAGE = 256 * 32;
+__device__ __attribute__((aligned(256))) float g_pe_zero_page[64];
 
-    for (int i = tid; i < PE_ROWS * (K1 / 4); i += 256) {
+// 8 waves; wave w owns hidden columns 32w..32w+31 (one 32x32 MFMA tile) of the block's 32 hypotheses.  Both weight
+// matrices stream as ONE sequence of [256][32] chunks (W0's ceil(Dp/32), then W2's 8) through a 3-stage LDS ring filled by
+// global_load_lds (unpadded 128-B rows, 16-B chunk index XOR (row>>1)&7 on the source address), two chunks in flight
+// across each raw s_barrier (counted vmcnt), so the weight latency hides behind the MFMAs and the first two chunks load
+// while the stage state is being formed.  Biases are staged to LDS up front: an ordinary global load consumed while a
+// direct-to-LDS load is in flight would drain the ring (vmcnt is in-order).
+__global__ __launch_bounds__(512) void pose_encoder_kernel(const PoseEncArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int K1 = (a.Dp + 31) / 32 * 32, X_LD = K1 + 4;
+    float* Ws = smem;                              // [PE_NST][256][32]
+    float* H1 = Ws + PE_NST * PE_STAGE;            // [32][PE_H_LD]
+    float* Bs = H1 + PE_ROWS * PE_H_LD;            // [2][256] biases
+    float* Xs = Bs + 512;                          // [32][X_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int r0 = blockIdx.x * PE_ROWS;
+    const int n1 = K1 / 32, nch = n1 + 8;
+
+    // ring fill: one wave instruction = 8 rows x 128 B; wave w, pass j fills rows 64j + 8w .. +7
+    const int frow = wave * 8 + (lane >> 3);                               // + 64 j
+    const int fkq = (lane & 7) ^ ((frow >> 1) & 7);                        // logical 16-B chunk (64j keeps (row>>1)&7)
+    auto issue = [&](int c) {
+        float* dst = Ws + (c % PE_NST) * PE_STAGE + wave * 8 * 32;
+        if (c < n1) {
+            const int k = c * 32 + 4 * fkq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* src = k < a.Dp ? a.w0 + (long long)(frow + 64 * j) * a.Dp + k : g_pe_zero_page;
+                __builtin_amdgcn_global_load_lds(src, dst + 64 * j * 32, 16, 0, 0);
+            }
+        } else {
+            const float* src = a.w2 + (long long)frow * 256 + (c - n1) * 32 + 4 * fkq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(src + 64 * j * 256, dst + 64 * j * 32, 16, 0, 0);
+        }
+    };
+    issue(0);
+    issue(1);
+
+    Bs[tid] = tid < 256 ? a.b0[tid] : a.b2[tid - 256];
+    for (int i = tid; i < PE_ROWS * (K1 / 4); i += 512) {
         const int r = i / (K1 / 4), c = (i - r * (K1 / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r0 + r < a.R && c < a.Dp) {
             if (!a.use_lc) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(r0 + r) * a.Dp + c);
             else {
+                // all seven stage slots are loaded up front (one memory round trip instead of lc.n dependent ones);
+                // slots >= lc.n are read from slot 0 and never enter the sum, which keeps its order j = 0..n-1
+                const long long e0 = (long long)(r0 + r) * a.D + c;
+                float kv[7][4];
+                double yv[4];
+                if ((a.D & 3) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const f32x4 k4 = *reinterpret_cast<const f32x4*>(a.ks.p[j < a.lc.n ? j : 0] + e0);
+                        kv[j][0] = k4[0]; kv[j][1] = k4[1]; kv[j][2] = k4[2]; kv[j][3] = k4[3];
+                    }
+                    const f64x2 y01 = *reinterpret_cast<const f64x2*>(a.y + e0), y23 = *reinterpret_cast<const f64x2*>(a.y + e0 + 2);
+                    yv[0] = y01[0]; yv[1] = y01[1]; yv[2] = y23[0]; yv[3] = y23[1];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long long e = c + u < a.D ? e0 + u : e0;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) kv[j][u] = a.ks.p[j < a.lc.n ? j : 0][e];
+                        yv[u] = a.y[e];
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) sacc = j < a.lc.n ? sacc + (double)kv[j][u] * a.lc.c[j] : sacc;
+                    const double xv = yv[u] + sacc * a.lc.h;
                     if (c + u < a.D) {
-                        const long long e = (long long)(r0 + r) * a.D + c + u;
-                        double sacc = 0.0;
-                        for (int j = 0; j < a.lc.n; ++j) sacc += (double)a.ks.p[j][e] * a.lc.c[j];
-                        const double xv = a.y[e] + sacc * a.lc.h;
                         v[u] = (float)xv;
-                        if (a.ynew) a.ynew[e] = xv;
+                        if (a.ynew) a.ynew[e0 + u] = xv;
                     }
                 }
             }
@@ -105,80 +157,76 @@ __global__ __launch_bounds__(256) void pose_encoder_kernel(const PoseEncArgs a) 
         *reinterpret_cast<f32x4*>(Xs + r * X_LD + c) = v;
     }
 
-    f32x4 rw[8];
-    auto load_w = [&](const float* W, int ldw, int kmax, int k0) {
+    f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + 4 * kq < kmax) v = *reinterpret_cast<const f32x4*>(W + (long long)(lrow + 32 * j) * ldw + k0 + 4 * kq);
-            rw[j] = v;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int sw = (li >> 1) & 7;
+    struct Frags { f32x4 a[4], b[4]; };
+    auto frags = [&](int c, Frags& f) {
+        const float* As = c < n1 ? Xs + li * X_LD + c * 32 + 4 * lh : H1 + li * PE_H_LD + (c - n1) * 32 + 4 * lh;
+        const float* Wc = Ws + (c % PE_NST) * PE_STAGE + (wave * 32 + li) * 32;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f.a[kk] = *reinterpret_cast<const f32x4*>(As + kk * 8);
+            f.b[kk] = *reinterpret_cast<const f32x4*>(Wc + (((2 * kk + lh) ^ sw) << 2));
         }
     };
-    auto store_w = [&](int buf) {
+    auto mfmas = [&](const Frags& f) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Ws + buf * 256 * PE_LD + (lrow + 32 * j) * PE_LD + 4 * kq) = rw[j];
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk][q], f.b[kk][q], acc, 0, 0, 0);
     };
-    auto zero = [](f32x16 (&acc)[2]) {
+    // Chunk c has landed for this wave once at most the 4 loads of chunk c+1 are outstanding; the barrier makes that true
+    // for every wave's share and retires everybody's fragment reads of stage (c-1)%3, which chunk c+2 then overwrites.
+    // The MFMAs run one phase behind the fragment reads: chunk c's ds_reads overlap chunk c-1's matrix work.
+    auto phase = [&](int c, Frags& fload, const Frags& fuse) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 2 < nch) issue(c + 2);
+        if (c != n1) {
+            frags(c, fload);
+            mfmas(fuse);
+        } else {
+            // layer boundary: h1 = relu(acc + b0) -> LDS [row][hidden] (C layout: hidden unit on the lane, hypothesis row
+            // on the register) must be complete in every wave before anyone reads it as the next A operand
+            mfmas(fuse);
+            const int col = wave * 32 + li;
+            const float bv = Bs[col];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    };
-    // one GEMM stage: acc += A[32 x K] (LDS, row stride a_ld) * W[256 x K]^T (global, streamed)
-    auto gemm = [&](const float* A_lds, int a_ld, const float* W, int ldw, int kmax, int nchunk, f32x16 (&acc)[2]) {
-        load_w(W, ldw, kmax, 0);
-        store_w(0);
-        __syncthreads();
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < nchunk) load_w(W, ldw, kmax, (ch + 1) * 32);
-            const float* As = A_lds + li * a_ld + ch * 32 + 4 * lh;
-            const float* Bs = Ws + buf * 256 * PE_LD + (wave * 64 + li) * PE_LD + 4 * lh;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(As + kk * 8);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + 32 * PE_LD + kk * 8);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc[1], 0, 0, 0);
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = acc[e] + bv;
+                H1[row * PE_H_LD + col] = v > 0.f ? v : 0.f;
+                acc[e] = 0.f;
             }
-            if (ch + 1 < nchunk) store_w(buf ^ 1);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            frags(c, fload);
         }
     };
-
-    f32x16 acc[2];
-    zero(acc);
-    gemm(Xs, X_LD, a.w0, a.Dp, a.Dp, K1 / 32, acc);
-    // h1 = relu(acc + b0) -> LDS [row][hidden]; C layout: hidden unit on the lane, hypothesis row on the register
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wave * 64 + j * 32 + li;
-        const float bv = a.b0[col];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const float v = acc[j][e] + bv;
-            H1[row * PE_H_LD + col] = v > 0.f ? v : 0.f;
-        }
+    Frags f0, f1;
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(2);
+    frags(0, f0);
+    for (int c = 1; c < nch; c += 2) {
+        phase(c, f1, f0);
+        if (c + 1 < nch) phase(c + 1, f0, f1);
     }
-    __syncthreads();
-    zero(acc);
-    gemm(H1, PE_H_LD, a.w2, 256, 256, 8, acc);
+    mfmas((nch & 1) ? f0 : f1);
+    const int col = wave * 32 + li;
+    const float bv = Bs[256 + col];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wave * 64 + j * 32 + li;
-        const float bv = a.b2[col];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (row < a.R) {
-                const float v = acc[j][e] + bv;
-                a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
-            }
+    for (int e = 0; e < 16; ++e) {
+        const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < a.R) {
+            const float v = acc[e] + bv;
+            a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
         }
     }
 }
@@ -523,14 +571,14 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         pa.out = c.ws.P2; pa.R = (int)c.R;
         if (lc) { pa.use_lc = 1; pa.lc = *lc; pa.y = y; pa.ks = *ks; pa.D = c.w->D; pa.ynew = ynew; }
         const int K1 = (pa.Dp + 31) / 32 * 32;
-        const size_t pe_lds = (size_t)(2 * 256 * PE_LD + PE_ROWS * PE_H_LD + PE_ROWS * (K1 + 4)) * sizeof(float);
+        const size_t pe_lds = (size_t)(PE_NST * PE_STAGE + PE_ROWS * PE_H_LD + 512 + PE_ROWS * (K1 + 4)) * sizeof(float);
         static bool pe_opt_in = false;
         if (!pe_opt_in) {
             VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             pe_opt_in = true;
         }
         VPHO_REQUIRE(pe_lds <= 150 * 1024, "pose encoder: input dimension %d too large for the LDS tile", pa.Dp);
-        hipLaunchKernelGGL(pose_encoder_kernel, dim3((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS)), dim3(256), pe_lds, c.s, pa);
+        hipLaunchKernelGGL(pose_encoder_kernel, dim3((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS)), dim3(512), pe_lds, c.s, pa);
         if (int e = vpho::check_launch("pose_encoder_kernel")) return e;
     }
     HeadArgs a;
