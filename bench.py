@@ -36,7 +36,7 @@ def parse():
     p.add_argument('--sample_T0', type=float, default=0.65)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
-    p.add_argument('--cpu_images', type=int, default=2)
+    p.add_argument('--cpu_images', type=int, default=4)
     p.add_argument('--pipeline', type=int, default=2, help='evaluation batches kept in flight (1 = sequential loop)')
     return p.parse_args()
 
@@ -248,6 +248,44 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     torch.cuda.synchronize()
     d = (out['agg_hand_joint'].double().cpu() - ref['agg_hand_joint'].double())
     mpjpe_delta_mm = float(d.norm(dim=-1).mean() * 1000)
+    mx = lambda a, b: float((a.double().cpu() - b.double()).abs().max())
+    # The aggregation is a chain of top-k selections: with random weights many hypotheses score within float rounding of
+    # each other, so a 1e-6 difference upstream can swap a selected index and move the fused pose by millimetres.  The
+    # second comparison removes that conditioning: the oracle's aggregation is fed the HIP path's own candidates.
+    from oracle.aggregation import hoi_aggregate
+    gf = model._engine.last_info['features']
+    c = lambda t: t.detach().cpu()
+    fl = c(out['diff_final_hand_mano']).reshape(-1, 58)
+    same = hoi_aggregate(assets, skeleton, cam_intrinsic=data['cam_intr_crop_flip'], root_joint_flip=data['root_joint_flip'],
+                         root_joint=data['root_joint'], is_right=data['is_right'], force_local=c(gf['force_local']),
+                         is_grasped=data['is_grasped'], hand_pose_diff=fl[:, :48].clone(), hand_pose_regression=c(gf['mano_pose']),
+                         hand_shape=fl[:, 48:], hand_heatmap=c(gf['hand_heatmap']), hand_bbox=data['bbox_hand'],
+                         hand_topk=args.topk_hand, obj_pose6d=c(out['diff_final_obj_6d']), obj_heatmap=c(gf['obj_heatmap']),
+                         obj_bbox=data['bbox_obj_rect'], obj_topk=args.topk_obj, obj_name=data['obj_name'])
+    given_same = {'max_abs_agg_hand_joint': mx(out['agg_hand_joint'], same['hand_agg_joint']),
+                  'max_abs_agg_hand_vert': mx(out['agg_hand_vert'], same['hand_agg_vert']),
+                  'max_abs_agg_obj_6d': mx(out['agg_obj_6d'], same['obj_agg_6d'])}
+    upstream = {k: mx(out[k], ref[k]) for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint',
+                                                'diff_final_hand_mano', 'diff_final_obj_6d')}
+    # where do selected indices differ, and how close were the competing scores?  (oracle values, sorted descending:
+    # a swap between ranks k and k+1 whose scores agree to ~1e-7 relative is a tie below fp32 resolution)
+    gd, od = model._engine.last_info['agg'], same['dbg']
+    mism, gap, per_image = 0, 0.0, torch.zeros(n, dtype=torch.long)
+    for lvl in range(4):
+        gi, oi, ov = c(gd['hand_topk'][lvl]).long(), od['hand']['topk'][lvl].long(), od['hand']['val'][lvl]
+        # per-finger levels are (bs,5,k) here and (bs,k,5) in the oracle
+        gi = gi.reshape(n, 5, -1).transpose(1, 2) if oi.dim() == 3 else gi.reshape(oi.shape)
+        ne = gi != oi
+        mism += int(ne.sum())
+        per_image += ne.reshape(n, -1).sum(1)
+        if ne.any():
+            nxt = torch.minimum((ov - ov.roll(-1, 1)).abs(), (ov - ov.roll(1, 1)).abs()) / ov.abs().clamp_min(1e-30)
+            gap = max(gap, float(nxt[ne].max()))
+    dj = (c(out['agg_hand_joint']).double() - same['hand_agg_joint'].double()).abs().amax(dim=(1, 2))
+    obj_eq = all(bool((c(gd[k]).long().reshape(od[k].shape) == od[k].long()).all()) for k in ('transl_topk', 'rot_topk', 'phys_topk', 'heat_topk'))
+    ties = {'object_topk_indices_equal': obj_eq, 'hand_cascade_index_mismatches': mism, 'max_rel_score_gap_at_mismatch': gap,
+            'images_without_mismatch': int((per_image == 0).sum()),
+            'max_abs_agg_hand_joint_on_those': float(dj[per_image == 0].max()) if (per_image == 0).any() else None}
     return {'cpu_baseline': {'value': n / t_cpu, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
                              'sample': f'{n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
                                        f'(torch-CPU + host RK45), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
@@ -257,6 +295,9 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                        'max_abs_agg_obj_6d': float((out['agg_obj_6d'].double().cpu() - ref['agg_obj_6d'].double()).abs().max()),
                        'nfev_equal': [model._engine.last_info['hand_ode']['nfev'] == info['hand_ode']['nfev'],
                                       model._engine.last_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
+                       'upstream_max_abs': upstream,
+                       'aggregation_given_identical_candidates': given_same,
+                       'near_tie_report': ties,
                        'sample': f'{n} images, identical inputs and prior draws'}}
 
 
