@@ -98,9 +98,9 @@ def main():
 
     for i in range(args.warmup):                           # warm-up runs the complete step (incl. the metric rows)
         out = model(batches[i % 2], mode='predict')
-        E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, 0)
+        E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, 0, assets)
     if args.warmup:
-        E.gather_rows(E.metric_rows(out, batches[0], gt_joint, gt_vert, 0))
+        E.gather_rows(E.metric_rows(out, batches[0], gt_joint, gt_vert, 0, assets))
         if args.pipeline > 1:
             torch.cuda.synchronize()
     barrier()
@@ -117,7 +117,7 @@ def main():
             for i in range(k):
                 first = (rank * k + i) * args.bs
                 futs.append(pipe.submit(batches[i % 2], lambda out, batch, engine, first=first: (
-                    E.metric_rows(out, batch, gt_joint, gt_vert, first),
+                    E.metric_rows(out, batch, gt_joint, gt_vert, first, assets),
                     (engine.last_info['hand_ode']['nfev'], engine.last_info['obj_ode']['nfev']))))
             for f in futs:
                 r, n = f.result()
@@ -129,7 +129,7 @@ def main():
                 ev.record()
                 step_events.append(ev)
                 out = model(batches[i % 2], mode='predict')
-                rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs))
+                rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs, assets))
                 nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
         return E.gather_rows(torch.cat(rows, 0)), nfev     # the ONE collective of the evaluation
 

@@ -217,6 +217,29 @@ int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int b
 int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
                           float* per_point, void* stream);
 
+/* Object evaluation metrics on the device: TesterObject.__call__ (lib/engine/test.py:240-352) for a single
+ * hypothesis per image -- criterion_MCE_OCE (:354-374), criterion_MCE2 / compute_obj_metrics_dexycb (:398-414,155-193),
+ * criterion_ADD_REP (:425-458), cal_ADD01d / cal_REP5 (:505-519), criterion_FSCORE (:460-503).
+ * Tables are the fp64 YCB_MESHES entries (lib/dataset/base.py:222-244); pd_rt / gt_rt [n_img][3][4] and cam_intr [n_img][3][3]
+ * fp64 (obj_9D_to_mat + root joint, train_diff_hand_obj.py:594-597); obj_id [n_img] indexes the tables; max_verts >= the
+ * largest per-object vertex count.  out [n_img][16] = MCE, OCE, MCE2, ADD, ADD-S, ADD<0.1d, ADD-S<0.1d, REP, REP<5px,
+ * Chamfer-L2, F-score @ 2 mm, 5 mm, 10 mm, 2 cm, 5 cm, 10 cm (metres / pixels / {0,1} / [0,1]). */
+typedef struct vpho_obj_metric_tables {
+    const double* bbox3d;          /* [n_obj][8][3] */
+    const double* verts_sampled;   /* [n_obj][n_sampled][3] */
+    const double* verts;           /* [vert_offset[n_obj]][3], objects concatenated */
+    const int* vert_offset;        /* [n_obj + 1] */
+    const double* diameter;        /* [n_obj] */
+    int n_obj, n_sampled;
+} vpho_obj_metric_tables;
+/* obj_9D_to_mat (lib/utils/transform_fn.py:85-90) with the root joint added to the translation (Trainer.postprocess,
+ * train_diff_hand_obj.py:578-597): pose9 [n][9] fp64 = [rot6d | t], root_joint [n][3] fp32 -> rt [n][3][4] fp64. */
+int vpho_obj_9d_to_rt_f64(const double* pose9, const float* root_joint, int n, double* rt, void* stream);
+long long vpho_obj_metrics_workspace_bytes(const vpho_obj_metric_tables* t, int n_img, int max_verts);
+int vpho_obj_metrics_f64(const vpho_obj_metric_tables* t, const double* pd_rt, const double* gt_rt, const double* cam_intr,
+                         const int* obj_id, int n_img, int max_verts, double* out, void* workspace, long long workspace_bytes,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Pseudo-force label optimisation (force_optim.py / lib/engine/force_optimization.py:110-207).
  * vpho_anchor_frames_f32: ForceAnchor.__call__ (lib/utils/physics_fn.py:224-257) -> pts [n][32][3], frames [n][32][3][3]

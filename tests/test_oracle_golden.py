@@ -165,3 +165,26 @@ def test_contact_detection_against_reference(assets):
     fc = OC.force_contact(assets['anchor'], hc)
     close(fc, G['contact_force'], 1e-6, 1e-9)
     assert OC.is_grasped(fc) == bool(G['contact_is_grasped'])
+
+
+def test_object_metrics_match_reference_tester(assets):
+    """oracle.metrics.object_metrics vs the reference's TesterObject (lib/engine/test.py:240-503) on the committed fixture.
+    fp64 criteria to 1e-9, fp32 ones to 1e-6; the nearest-neighbour criteria to the accuracy of the reference's own
+    torch.cdist expansion (2e-5 m; F-scores: a few of 2048 points may sit within that of a threshold)."""
+    from oracle import metrics as OM
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_objmetrics.npz'))
+    names = list(assets['ycb'].keys())
+    got = np.stack([OM.object_metrics(assets['ycb'][names[int(o)]], g['pd_rt'][i], g['gt_rt'][i], g['cam_intr'][i])
+                    for i, o in enumerate(g['obj_idx'])])
+    ref = g['metrics']
+    col = {k: i for i, k in enumerate(OM.OBJ_METRIC_NAMES)}
+    for k in ('MCE', 'OCE', 'REP'):
+        np.testing.assert_allclose(got[:, col[k]], ref[:, col[k]], rtol=1e-6, err_msg=k)       # inputs are fp32 matrices
+    for k in ('MCE2', 'ADD'):
+        np.testing.assert_allclose(got[:, col[k]], ref[:, col[k]], rtol=5e-6, err_msg=k)
+    for k in ('ADDS', 'CD'):
+        np.testing.assert_allclose(got[:, col[k]], ref[:, col[k]], atol=2e-5, err_msg=k)
+    for k in ('ADD01d', 'ADDS01d', 'REP5'):
+        np.testing.assert_array_equal(got[:, col[k]], ref[:, col[k]], err_msg=k)
+    for k in OM.OBJ_METRIC_NAMES[10:]:
+        np.testing.assert_allclose(got[:, col[k]], ref[:, col[k]], atol=3e-3, err_msg=k)

@@ -115,6 +115,10 @@ def synthetic_ycb(rng):
             return p * half
         out[name] = dict(kpt3d=kpt.astype(np.float32), verts_sampled=surf(2048).astype(np.float32),
                          CoM=(rng.normal(0, 0.004, size=3)).astype(np.float32), verts=surf(2048).astype(np.float32))
+        # evaluation tables (lib/dataset/base.py:235-244): the 8 box corners and the model diameter; no random draws
+        out[name]['bbox3d'] = np.array([[sx * half[0], sy * half[1], sz * half[2]] for sx in (-1, 1) for sy in (-1, 1)
+                                        for sz in (-1, 1)], dtype=np.float32)
+        out[name]['diameter'] = float(2.0 * np.linalg.norm(half))
     return out
 
 
@@ -154,7 +158,8 @@ def load_assets(asset_root='asset', seed=0):
         with open(os.path.join(asset_root, 'ours', 'object_mesh_info.pkl'), 'rb') as f:
             mesh = pickle.load(f)
         a['ycb'] = {k: dict(kpt3d=np.asarray(v['kpt3d'], np.float32), verts_sampled=np.asarray(v['verts_sampled'], np.float32),
-                            CoM=np.asarray(v['CoM'], np.float32), verts=np.asarray(v['verts'], np.float32))
+                            CoM=np.asarray(v['CoM'], np.float32), verts=np.asarray(v['verts'], np.float32),
+                            bbox3d=np.asarray(v['bbox3d'], np.float32), diameter=float(v['diameter']))
                     for k, v in mesh.items()}
         a['synthetic'] = False
     except Exception:

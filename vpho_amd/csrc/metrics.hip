@@ -3,6 +3,8 @@
 // evaluation loop ships 8 floats per image to the all-gather instead of copying (bs,S,778,3) candidates to the host.
 // One block per image; reductions and the 3x3 SVD (Jacobi on H^T H) in fp64.  HBM-bound: 24 B read per point.
 #include "common.h"
+#include "rot.h"
+#include <algorithm>
 #include "../../include/vpho_hip.h"
 
 namespace {
@@ -117,6 +119,195 @@ __global__ __launch_bounds__(256) void hand_metrics_kernel(const float* __restri
     if (tid == 0) { mean_err[b] = (float)me; pa_mean_err[b] = (float)pa; }
 }
 
+// obj_9D_to_mat (lib/utils/transform_fn.py:85-90) + root joint (train_diff_hand_obj.py:594-597): [rot6d | t] -> [R | t + root]
+__global__ void obj_9d_to_rt_kernel(const double* __restrict__ pose9, const float* __restrict__ root, int n, double* __restrict__ rt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double R[9];
+    vpho::rot6d_to_matrix<double>(pose9 + (long long)i * 9, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) rt[(long long)i * 12 + r * 4 + c] = R[r * 3 + c];
+        rt[(long long)i * 12 + r * 4 + 3] = (double)root[i * 3 + r] + pose9[(long long)i * 9 + 6 + r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ object metrics
+// TesterObject (lib/engine/test.py:240-503) per image and single hypothesis: MCE / OCE on the 8 model-box corners (fp64,
+// :354-374), MCE2 on the axis-aligned boxes of the transformed sampled vertices (:155-193,398-414), ADD / ADD-S / REP
+// (:425-458), their 0.1-diameter and 5-pixel hits (:505-519), Chamfer-L2 and F-score at six thresholds on the full vertex
+// set (:460-503).  Transforms are fp64 on the fp64 tables and rounded to fp32 where the reference calls .float(); the two
+// nearest-neighbour searches are exact fp32 brute force through LDS tiles (the reference's torch.cdist uses the matmul
+// expansion, which is only accurate to ~1e-7 in d^2 at camera-space magnitudes).  HBM/L2-bound: 24 B per table point.
+struct ObjWs { float *pd_s, *gt_s, *pd_f, *gt_f, *d_s, *d_p2g, *d_g2p; long long bytes; };
+
+__host__ __device__ inline long long ows_align(long long v) { return (v + 255) / 256 * 256; }
+
+inline ObjWs obj_carve(int n_img, int ns, int vmax, char* base) {
+    long long off = 0;
+    ObjWs w;
+    auto take = [&](long long b) { char* p = base ? base + off : nullptr; off += ows_align(b); return (float*)p; };
+    w.pd_s = take((long long)n_img * ns * 12); w.gt_s = take((long long)n_img * ns * 12);
+    w.pd_f = take((long long)n_img * vmax * 12); w.gt_f = take((long long)n_img * vmax * 12);
+    w.d_s = take((long long)n_img * ns * 4); w.d_p2g = take((long long)n_img * vmax * 4); w.d_g2p = take((long long)n_img * vmax * 4);
+    w.bytes = off;
+    return w;
+}
+
+__device__ inline void rt_apply(const double* rt, const double* v, double* o) {
+    for (int r = 0; r < 3; ++r) o[r] = v[0] * rt[r * 4 + 0] + v[1] * rt[r * 4 + 1] + v[2] * rt[r * 4 + 2] + rt[r * 4 + 3];
+}
+
+__global__ __launch_bounds__(256) void obj_transform_kernel(const vpho_obj_metric_tables t, const double* __restrict__ pd_rt,
+                                                            const double* __restrict__ gt_rt, const int* __restrict__ obj_id,
+                                                            int vmax, ObjWs w) {
+    const int b = blockIdx.x, o = obj_id[b];
+    const int nf = t.vert_offset[o + 1] - t.vert_offset[o];
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= t.n_sampled + nf) return;
+    const bool full = i >= t.n_sampled;
+    const int k = full ? i - t.n_sampled : i;
+    const double* v = full ? t.verts + ((long long)t.vert_offset[o] + k) * 3 : t.verts_sampled + ((long long)o * t.n_sampled + k) * 3;
+    double p[3], g[3];
+    rt_apply(pd_rt + (long long)b * 12, v, p);
+    rt_apply(gt_rt + (long long)b * 12, v, g);
+    float* po = full ? w.pd_f + ((long long)b * vmax + k) * 3 : w.pd_s + ((long long)b * t.n_sampled + k) * 3;
+    float* go = full ? w.gt_f + ((long long)b * vmax + k) * 3 : w.gt_s + ((long long)b * t.n_sampled + k) * 3;
+    for (int c = 0; c < 3; ++c) { po[c] = (float)p[c]; go[c] = (float)g[c]; }
+}
+
+// grid (image, job, chunk of 256 source points): job 0 sampled pd->gt, 1 full pd->gt, 2 full gt->pd
+__global__ __launch_bounds__(256) void obj_nn_kernel(const vpho_obj_metric_tables t, const int* __restrict__ obj_id, int vmax, ObjWs w) {
+    __shared__ float tile[256 * 3];
+    const int b = blockIdx.x, job = blockIdx.y, o = obj_id[b];
+    const int n = job == 0 ? t.n_sampled : t.vert_offset[o + 1] - t.vert_offset[o];
+    const int ld = job == 0 ? t.n_sampled : vmax;
+    const float* src = (job == 0 ? w.pd_s : job == 1 ? w.pd_f : w.gt_f) + (long long)b * ld * 3;
+    const float* dst = (job == 0 ? w.gt_s : job == 1 ? w.gt_f : w.pd_f) + (long long)b * ld * 3;
+    float* out = (job == 0 ? w.d_s : job == 1 ? w.d_p2g : w.d_g2p) + (long long)b * ld;
+    if (blockIdx.z * 256 >= n) return;
+    const int i = blockIdx.z * 256 + threadIdx.x;
+    const bool live = i < n;
+    const float x = live ? src[i * 3] : 0.f, y = live ? src[i * 3 + 1] : 0.f, z = live ? src[i * 3 + 2] : 0.f;
+    float best = INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int m = min(256, n - j0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < m * 3; q += 256) tile[q] = dst[(long long)j0 * 3 + q];
+        __syncthreads();
+        for (int j = 0; j < m; ++j) {
+            const float dx = x - tile[j * 3], dy = y - tile[j * 3 + 1], dz = z - tile[j * 3 + 2];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (live) out[i] = sqrtf(best);
+}
+
+__device__ inline float block_minmax(float v, bool is_max, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = is_max ? fmaxf(red[tid], red[tid + o]) : fminf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void obj_metrics_kernel(const vpho_obj_metric_tables t, const double* __restrict__ pd_rt,
+                                                          const double* __restrict__ gt_rt, const double* __restrict__ cam,
+                                                          const int* __restrict__ obj_id, int vmax, ObjWs w, double* __restrict__ out) {
+    __shared__ double red[256];
+    __shared__ float redf[256];
+    __shared__ double corner[2][8][3];
+    const int b = blockIdx.x, tid = threadIdx.x, o = obj_id[b];
+    const int ns = t.n_sampled, nf = t.vert_offset[o + 1] - t.vert_offset[o];
+    const double* prt = pd_rt + (long long)b * 12;
+    const double* grt = gt_rt + (long long)b * 12;
+    const double* K = cam + (long long)b * 9;
+    if (tid < 8) {
+        rt_apply(prt, t.bbox3d + ((long long)o * 8 + tid) * 3, corner[0][tid]);
+        rt_apply(grt, t.bbox3d + ((long long)o * 8 + tid) * 3, corner[1][tid]);
+    }
+    __syncthreads();
+    double mce = 0, oce = 0;
+    if (tid == 0) {
+        double cp[3] = {0, 0, 0}, cg[3] = {0, 0, 0};
+        for (int k = 0; k < 8; ++k) {
+            double d2 = 0;
+            for (int c = 0; c < 3; ++c) { const double d = corner[0][k][c] - corner[1][k][c]; d2 += d * d; cp[c] += corner[0][k][c]; cg[c] += corner[1][k][c]; }
+            mce += sqrt(d2);
+        }
+        mce /= 8;
+        double d2 = 0;
+        for (int c = 0; c < 3; ++c) { const double d = cp[c] / 8 - cg[c] / 8; d2 += d * d; }
+        oce = sqrt(d2);
+    }
+    // sampled vertices: ADD (fp32 points), REP (fp64 points re-derived from the table), ADD-S, boxes for MCE2
+    const float* ps = w.pd_s + (long long)b * ns * 3;
+    const float* gs = w.gt_s + (long long)b * ns * 3;
+    double s_add = 0, s_rep = 0, s_adds = 0;
+    float mn[2][3], mx[2][3];
+    for (int c = 0; c < 3; ++c) { mn[0][c] = mn[1][c] = INFINITY; mx[0][c] = mx[1][c] = -INFINITY; }
+    for (int i = tid; i < ns; i += 256) {
+        const float dx = ps[i * 3] - gs[i * 3], dy = ps[i * 3 + 1] - gs[i * 3 + 1], dz = ps[i * 3 + 2] - gs[i * 3 + 2];
+        s_add += (double)sqrtf((dx * dx + dy * dy) + dz * dz);
+        s_adds += (double)w.d_s[(long long)b * ns + i];
+        for (int c = 0; c < 3; ++c) {
+            mn[0][c] = fminf(mn[0][c], ps[i * 3 + c]); mx[0][c] = fmaxf(mx[0][c], ps[i * 3 + c]);
+            mn[1][c] = fminf(mn[1][c], gs[i * 3 + c]); mx[1][c] = fmaxf(mx[1][c], gs[i * 3 + c]);
+        }
+        double p[3], g[3], pp[2], gp[2];
+        const double* v = t.verts_sampled + ((long long)o * ns + i) * 3;
+        rt_apply(prt, v, p);
+        rt_apply(grt, v, g);
+        for (int r = 0; r < 2; ++r) {
+            pp[r] = (p[0] * K[r * 3] + p[1] * K[r * 3 + 1] + p[2] * K[r * 3 + 2]) / (p[2] + 1e-7);
+            gp[r] = (g[0] * K[r * 3] + g[1] * K[r * 3 + 1] + g[2] * K[r * 3 + 2]) / (g[2] + 1e-7);
+        }
+        s_rep += sqrt((pp[0] - gp[0]) * (pp[0] - gp[0]) + (pp[1] - gp[1]) * (pp[1] - gp[1]));
+    }
+    const double add = block_sum(s_add, red) / ns, rep = block_sum(s_rep, red) / ns, adds = block_sum(s_adds, red) / ns;
+    float bmn[2][3], bmx[2][3];
+    for (int k = 0; k < 2; ++k)
+        for (int c = 0; c < 3; ++c) { bmn[k][c] = block_minmax(mn[k][c], false, redf); bmx[k][c] = block_minmax(mx[k][c], true, redf); }
+    // full vertices: Chamfer distance and F-scores
+    const float th[6] = {0.002f, 0.005f, 0.010f, 0.020f, 0.050f, 0.100f};
+    double s_p = 0, s_g = 0, cp[6] = {0, 0, 0, 0, 0, 0}, cg[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < nf; i += 256) {
+        const float dp = w.d_p2g[(long long)b * vmax + i], dg = w.d_g2p[(long long)b * vmax + i];
+        s_p += (double)dp; s_g += (double)dg;
+        for (int k = 0; k < 6; ++k) { cp[k] += dp < th[k] ? 1.0 : 0.0; cg[k] += dg < th[k] ? 1.0 : 0.0; }
+    }
+    const double mp = block_sum(s_p, red) / nf, mg = block_sum(s_g, red) / nf;
+    double fs[6];
+    for (int k = 0; k < 6; ++k) {
+        const float prec = (float)(block_sum(cp[k], red) / nf), rec = (float)(block_sum(cg[k], red) / nf);
+        fs[k] = (double)((2.f * prec * rec) / ((prec + rec) + 1e-6f));
+    }
+    if (tid == 0) {
+        // corners of the two axis-aligned boxes in the reference's order (test.py:163-187)
+        const int sel[3][8] = {{0, 1, 0, 0, 1, 0, 1, 1}, {0, 0, 1, 0, 1, 1, 0, 1}, {0, 0, 0, 1, 0, 1, 1, 1}};
+        float s2 = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            float d2 = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float a = sel[c][k] ? bmx[0][c] : bmn[0][c], g = sel[c][k] ? bmx[1][c] : bmn[1][c];
+                d2 += (a - g) * (a - g);
+            }
+            s2 += sqrtf(d2);
+        }
+        const double diam = t.diameter[o];
+        double* r = out + (long long)b * 16;
+        r[0] = mce; r[1] = oce; r[2] = (double)(s2 / 8.f); r[3] = add; r[4] = adds;
+        r[5] = add <= diam * 0.1 ? 1.0 : 0.0; r[6] = adds <= diam * 0.1 ? 1.0 : 0.0; r[7] = rep; r[8] = rep < 5 ? 1.0 : 0.0;
+        r[9] = 0.5 * (mp + mg);
+        for (int k = 0; k < 6; ++k) r[10 + k] = fs[k];
+    }
+}
+
 }  // namespace
 
 extern "C" int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
@@ -124,4 +315,32 @@ extern "C" int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img
     VPHO_REQUIRE(pd && gt && mean_err && pa_mean_err && n_img > 0 && n_pts >= 3, "vpho_hand_metrics_f32: bad argument");
     hipLaunchKernelGGL(hand_metrics_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, pd, gt, n_pts, mean_err, pa_mean_err, per_point);
     return vpho::check_launch("hand_metrics_kernel");
+}
+
+extern "C" long long vpho_obj_metrics_workspace_bytes(const vpho_obj_metric_tables* t, int n_img, int max_verts) {
+    if (!t || n_img <= 0 || max_verts <= 0 || t->n_sampled <= 0) return -1;
+    return obj_carve(n_img, t->n_sampled, max_verts, nullptr).bytes;
+}
+
+extern "C" int vpho_obj_metrics_f64(const vpho_obj_metric_tables* t, const double* pd_rt, const double* gt_rt, const double* cam_intr,
+                                    const int* obj_id, int n_img, int max_verts, double* out, void* workspace, long long workspace_bytes,
+                                    void* stream) {
+    VPHO_REQUIRE(t && t->bbox3d && t->verts_sampled && t->verts && t->vert_offset && t->diameter && t->n_obj > 0 && t->n_sampled > 0,
+                 "vpho_obj_metrics_f64: bad tables");
+    VPHO_REQUIRE(pd_rt && gt_rt && cam_intr && obj_id && out && workspace && n_img > 0 && max_verts > 0, "vpho_obj_metrics_f64: bad argument");
+    const ObjWs w = obj_carve(n_img, t->n_sampled, max_verts, (char*)workspace);
+    VPHO_REQUIRE(workspace_bytes >= w.bytes, "vpho_obj_metrics_f64: workspace %lld < %lld bytes", workspace_bytes, w.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int pts = t->n_sampled + max_verts;
+    hipLaunchKernelGGL(obj_transform_kernel, dim3(n_img, (pts + 255) / 256), dim3(256), 0, s, *t, pd_rt, gt_rt, obj_id, max_verts, w);
+    const int chunks = (std::max(t->n_sampled, max_verts) + 255) / 256;
+    hipLaunchKernelGGL(obj_nn_kernel, dim3(n_img, 3, chunks), dim3(256), 0, s, *t, obj_id, max_verts, w);
+    hipLaunchKernelGGL(obj_metrics_kernel, dim3(n_img), dim3(256), 0, s, *t, pd_rt, gt_rt, cam_intr, obj_id, max_verts, w, out);
+    return vpho::check_launch("obj_metrics kernels");
+}
+
+extern "C" int vpho_obj_9d_to_rt_f64(const double* pose9, const float* root_joint, int n, double* rt, void* stream) {
+    VPHO_REQUIRE(pose9 && root_joint && rt && n > 0, "vpho_obj_9d_to_rt_f64: bad argument");
+    hipLaunchKernelGGL(obj_9d_to_rt_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose9, root_joint, n, rt);
+    return vpho::check_launch("obj_9d_to_rt_kernel");
 }

@@ -11,8 +11,11 @@ import torch.distributed as dist
 
 # row layout: [global image index, MJE(regression), MJE(first hypothesis), MJE(aggregated), MVE(aggregated),
 #              |agg - regression| mean joint distance (mm), object translation norm (m), is_right,
-#              PA-MJE(regression), PA-MJE(aggregated), PA-MVE(aggregated), 0]
-ROW = 12
+#              PA-MJE(regression), PA-MJE(aggregated), PA-MVE(aggregated), 0,
+#              then the 16 object metrics of the aggregated pose in the order of ops.OBJ_METRIC_NAMES (TesterObject,
+#              test.py:240-503: MCE, OCE, MCE2, ADD, ADD-S, ADD<0.1d, ADD-S<0.1d, REP, REP<5px, CD, F-score x6)]
+ROW = 28
+OBJ_COL = 12
 
 
 def mje_mm(pd, gt):
@@ -34,7 +37,23 @@ def postprocess(out, root_joint, is_right):
     return res
 
 
-def metric_rows(out, data, gt_joint, gt_vert, first_index):
+_OBJ_METRICS = {}
+
+
+def object_metric_block(out, data, assets):
+    """(bs,16) fp64: TesterObject on the aggregated object pose ('mean_candidate_pose', train_diff_hand_obj.py:249-258,
+    498-501) -- obj_9D_to_mat + root joint, then the device metric kernels.  Needs data['gt_obj_rt'], data['cam_intr']."""
+    from . import ops
+    dev = out['agg_obj_6d'].device
+    key = (id(assets), str(dev))
+    if key not in _OBJ_METRICS:
+        _OBJ_METRICS[key] = ops.ObjectMetrics(assets['ycb'], dev)
+    M = _OBJ_METRICS[key]
+    pd_rt = ops.obj_9d_to_rt(out['agg_obj_6d'].double().contiguous(), data['root_joint'].float().contiguous())
+    return M(pd_rt, data['gt_obj_rt'].double().contiguous(), data['cam_intr'].double().contiguous(), M.obj_ids(data['obj_name']))
+
+
+def metric_rows(out, data, gt_joint, gt_vert, first_index, assets=None):
     """(bs, ROW) fp32 on the model's device."""
     pp = postprocess(out, data['root_joint'], data['is_right'])
     bs = gt_joint.shape[0]
@@ -54,6 +73,8 @@ def metric_rows(out, data, gt_joint, gt_vert, first_index):
         rows[:, 8] = ops.hand_metrics(c(pp['reg_hand_joint']), c(gt_joint))[1] * 1000.0
         rows[:, 9] = ops.hand_metrics(c(pp['agg_hand_joint']), c(gt_joint))[1] * 1000.0
         rows[:, 10] = ops.hand_metrics(c(pp['agg_hand_vert']), c(gt_vert))[1] * 1000.0
+        if assets is not None and 'gt_obj_rt' in data:
+            rows[:, OBJ_COL:OBJ_COL + 16] = object_metric_block(out, data, assets).float()
     return rows
 
 
@@ -135,4 +156,9 @@ def summarize(rows):
         res[name] = dict(n=int(sel.shape[0]), MJE_reg=float(sel[:, 1].mean()), MJE_first=float(sel[:, 2].mean()),
                          MJE_agg=float(sel[:, 3].mean()), MVE_agg=float(sel[:, 4].mean()), PA_MJE_reg=float(sel[:, 8].mean()),
                          PA_MJE_agg=float(sel[:, 9].mean()), PA_MVE_agg=float(sel[:, 10].mean()))
+    # object table (test.py:521-584 'average_instance' column: distances in mm, hit rates / F-scores in percent, REP in pixels)
+    from .ops_names import OBJ_METRIC_NAMES
+    obj = rows[:, OBJ_COL:OBJ_COL + 16].double().mean(0)
+    res['object'] = {k: float(obj[i] * (1000.0 if k in ('MCE', 'OCE', 'MCE2', 'ADD', 'ADDS', 'CD') else (1.0 if k == 'REP' else 100.0)))
+                     for i, k in enumerate(OBJ_METRIC_NAMES)}
     return res

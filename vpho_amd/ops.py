@@ -17,6 +17,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
+lib.vpho_obj_metrics_workspace_bytes.restype = C.c_longlong
 
 
 class VphoError(RuntimeError):
@@ -532,6 +533,60 @@ def hand_metrics(pd, gt, per_point=False):
     pp = _new((n, P), pd) if per_point else None
     _call('vpho_hand_metrics_f32', _f32(pd), _f32(gt), I(n), I(P), _f32(me), _f32(pa), _f32(pp))
     return (me, pa, pp) if per_point else (me, pa)
+
+
+def obj_9d_to_rt(pose9, root_joint):
+    """(n,9) fp64 [rot6d | t], (n,3) fp32 root -> (n,3,4) fp64 [R | t + root]  (transform_fn.py:85-90, train_diff_hand_obj.py:594-597)"""
+    n = pose9.shape[0]
+    rt = _new((n, 3, 4), pose9, torch.float64)
+    _call('vpho_obj_9d_to_rt_f64', _f64(pose9), _f32(root_joint), I(n), _f64(rt))
+    return rt
+
+
+class ObjMetricTables(C.Structure):
+    _fields_ = [('bbox3d', C.c_void_p), ('verts_sampled', C.c_void_p), ('verts', C.c_void_p), ('vert_offset', C.c_void_p),
+                ('diameter', C.c_void_p), ('n_obj', I), ('n_sampled', I)]
+
+
+from .ops_names import OBJ_METRIC_NAMES  # noqa: E402,F401
+
+
+class ObjectMetrics:
+    """TesterObject (lib/engine/test.py:240-503) on the device: fp64 model tables + thin wrapper of vpho_obj_metrics_f64."""
+
+    def __init__(self, ycb, device):
+        import numpy as np
+        self.names = list(ycb.keys())
+        self.name_to_id = {n: i for i, n in enumerate(self.names)}
+        d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+        self.bbox3d = d(np.stack([np.asarray(ycb[n]['bbox3d']).reshape(8, 3) for n in self.names]))
+        self.verts_sampled = d(np.stack([np.asarray(ycb[n]['verts_sampled']).reshape(-1, 3) for n in self.names]))
+        counts = [int(np.asarray(ycb[n]['verts']).reshape(-1, 3).shape[0]) for n in self.names]
+        self.max_verts = max(counts)
+        self.verts = d(np.concatenate([np.asarray(ycb[n]['verts']).reshape(-1, 3) for n in self.names]))
+        self.vert_offset = torch.as_tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(device)
+        self.diameter = d(np.array([float(ycb[n]['diameter']) for n in self.names]))
+        self.c = ObjMetricTables(self.bbox3d.data_ptr(), self.verts_sampled.data_ptr(), self.verts.data_ptr(),
+                                 self.vert_offset.data_ptr(), self.diameter.data_ptr(), len(self.names), self.verts_sampled.shape[1])
+        self.device = device
+        self._ws = None
+
+    def obj_ids(self, names):
+        return torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+
+    def __call__(self, pd_rt, gt_rt, cam_intr, obj_id):
+        """pd_rt, gt_rt (n,3,4), cam_intr (n,3,3) fp64, obj_id (n,) int32 -> (n,16) fp64 in the order of OBJ_METRIC_NAMES."""
+        n = pd_rt.shape[0]
+        assert gt_rt.shape == (n, 3, 4) and pd_rt.shape == (n, 3, 4) and cam_intr.shape == (n, 3, 3) and obj_id.shape == (n,)
+        need = lib.vpho_obj_metrics_workspace_bytes(C.byref(self.c), I(n), I(self.max_verts))
+        if need < 0:
+            raise VphoError('vpho_obj_metrics_workspace_bytes: bad argument')
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = _new((n, 16), pd_rt, torch.float64)
+        _call('vpho_obj_metrics_f64', C.byref(self.c), _f64(pd_rt), _f64(gt_rt), _f64(cam_intr), _i32(obj_id), I(n), I(self.max_verts),
+              _f64(out), _ptr(self._ws), LL(self._ws.numel()))
+        return out
 
 
 # ----------------------------------------------------------------------------------------------- profiling hooks

@@ -101,7 +101,7 @@ def synth_batch(bs, assets, seed=206, rank=0, patch=256):
     g /= np.linalg.norm(g, axis=-1, keepdims=True)
     root_unflip = root.copy()
     root_unflip[~is_right, 0] *= -1
-    return {
+    batch = {
         'rgb': f32(r.normal(size=(bs, 3, patch, patch))),
         'bbox_hand': f32(bbox_hand), 'bbox_obj': f32(bbox_obj),
         'bbox_hand_rect': f32(rect(bbox_hand)), 'bbox_obj_rect': f32(rect(bbox_obj)),
@@ -112,3 +112,15 @@ def synth_batch(bs, assets, seed=206, rank=0, patch=256):
         'cam_intr_crop_flip': f32(Kmat),
         'obj_name': [YCB_NAMES[i] for i in r.integers(0, len(YCB_NAMES), bs)],
     }
+    # evaluation-only ground truth, drawn after everything the model consumes (keeps those draws unchanged):
+    # object pose [R | t] in camera space near the hand root, and the camera matrix TesterObject projects with
+    q = r.normal(size=(bs, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q.T
+    Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                   2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                   2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(bs, 3, 3)
+    t = root_unflip + r.normal(0, 0.03, size=(bs, 3))
+    batch['gt_obj_rt'] = f32(np.concatenate([Rm, t[:, :, None]], -1))
+    batch['cam_intr'] = f32(Kmat)
+    return batch

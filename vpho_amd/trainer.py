@@ -72,11 +72,11 @@ class Trainer:
         b0 = make(0)
         out0 = pipe.submit(b0).result()
         gt = (out0['reg_hand_joint'] + b0['root_joint'][:, None], out0['reg_hand_vert'] + b0['root_joint'][:, None])
-        rows.append(E.metric_rows(out0, b0, gt[0], gt[1], self.rank * cfg.num_batches * bs))
+        rows.append(E.metric_rows(out0, b0, gt[0], gt[1], self.rank * cfg.num_batches * bs, self.assets))
         futs = []
         for i in range(1, cfg.num_batches):
             first = (self.rank * cfg.num_batches + i) * bs
-            futs.append(pipe.submit(make(i), lambda out, batch, eng, first=first: E.metric_rows(out, batch, gt[0], gt[1], first)))
+            futs.append(pipe.submit(make(i), lambda out, batch, eng, first=first: E.metric_rows(out, batch, gt[0], gt[1], first, self.assets)))
         rows += [f.result() for f in futs]
         pipe.close()
         rows = E.gather_rows(torch.cat(rows, 0))
