@@ -3,6 +3,7 @@
 // All are coalesced along the NHWC channel axis (one thread per (pixel, channel) with channel fastest); none is
 // reshaped into a GEMM.  Roofline: HBM bytes = inputs read once + outputs written once.
 #include "common.h"
+#include <cstdint>
 #include "rot.h"
 #include "../../include/vpho_hip.h"
 
@@ -67,14 +68,28 @@ __device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& 
     l1 = s - (float)i0;
 }
 
+// V consecutive channels per thread (V = 4: 16-B accesses when every leading dimension and offset is a multiple of 4)
+template <int V>
+__device__ inline void ldv(const float* __restrict__ p, float (&o)[V]) {
+    if constexpr (V == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+    else o[0] = *p;
+}
+template <int V>
+__device__ inline void stv(float* __restrict__ p, const float (&v)[V]) {
+    if constexpr (V == 4) { f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; *reinterpret_cast<f32x4*>(p) = t; }
+    else *p = v[0];
+}
+
 // y[n,oy,ox,c_off+c] (=|+=) bilinear(x)[n,oy,ox,c]
+template <int V>
 __global__ void resize_bilinear_nhwc_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int OH, int OW,
                                             float* __restrict__ y, int ldy, int c_off, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * OH * OW * C;
+    const int CV = C / V;
+    const long long total = (long long)N * OH * OW * CV;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    long long p = i / C;
+    const int c = (int)(i % CV) * V;
+    long long p = i / CV;
     const int ox = (int)(p % OW); p /= OW;
     const int oy = (int)(p % OH);
     const long long n = p / OH;
@@ -83,34 +98,51 @@ __global__ void resize_bilinear_nhwc_kernel(const float* __restrict__ x, int N, 
     lin_src(ox, (float)W / (float)OW, W, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const float* b = x + n * H * W * (long long)ldx + c;
-    const float v = hy * (hx * b[((long long)y0 * W + x0) * ldx] + lx * b[((long long)y0 * W + x1) * ldx]) +
-                    ly * (hx * b[((long long)y1 * W + x0) * ldx] + lx * b[((long long)y1 * W + x1) * ldx]);
-    float* o = y + ((n * OH + oy) * OW + ox) * (long long)ldy + c_off + c;
-    *o = accumulate ? (*o + v) : v;
+    float a00[V], a01[V], a10[V], a11[V], o[V];
+    ldv<V>(b + ((long long)y0 * W + x0) * ldx, a00); ldv<V>(b + ((long long)y0 * W + x1) * ldx, a01);
+    ldv<V>(b + ((long long)y1 * W + x0) * ldx, a10); ldv<V>(b + ((long long)y1 * W + x1) * ldx, a11);
+    float* op = y + ((n * OH + oy) * OW + ox) * (long long)ldy + c_off + c;
+    if (accumulate) ldv<V>(op, o);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+        const float v = hy * (hx * a00[u] + lx * a01[u]) + ly * (hx * a10[u] + lx * a11[u]);
+        o[u] = accumulate ? (o[u] + v) : v;
+    }
+    stv<V>(op, o);
 }
 
 // ------------------------------------------------------------------------------------------------ RoIAlign
 // torchvision roi_align, aligned=False, sampling_ratio=-1 (adaptive), one RoI per image (batch index = roi index)
-__device__ inline float roi_bilinear(const float* __restrict__ f, int H, int W, int ld, float y, float x) {
-    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+template <int V>
+__device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, int ld, float y, float x, float (&acc)[V]) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc[u] += 0.f;
+        return;
+    }
     if (y <= 0.f) y = 0.f;
     if (x <= 0.f) x = 0.f;
     int yl = (int)y, xl = (int)x, yh, xh;
     if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
     if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
     const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
-    return hy * hx * f[((long long)yl * W + xl) * ld] + hy * lx * f[((long long)yl * W + xh) * ld] +
-           ly * hx * f[((long long)yh * W + xl) * ld] + ly * lx * f[((long long)yh * W + xh) * ld];
+    float a[V], b[V], c[V], d[V];
+    ldv<V>(f + ((long long)yl * W + xl) * ld, a); ldv<V>(f + ((long long)yl * W + xh) * ld, b);
+    ldv<V>(f + ((long long)yh * W + xl) * ld, c); ldv<V>(f + ((long long)yh * W + xh) * ld, d);
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] += hy * hx * a[u] + hy * lx * b[u] + ly * hx * c[u] + ly * lx * d[u];
 }
 
+template <int V>
 __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int H, int W, int C, const float* __restrict__ boxes,
                                       float scale, int P, const unsigned char* __restrict__ flip_w,
                                       float* __restrict__ out, int ldo, int c_off) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * P * P * C;
+    const int CV = C / V;
+    const long long total = (long long)N * P * P * CV;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    long long p = i / C;
+    const int c = (int)(i % CV) * V;
+    long long p = i / CV;
     const int pw = (int)(p % P); p /= P;
     const int ph = (int)(p % P);
     const int n = (int)(p / P);
@@ -121,16 +153,20 @@ __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float cnt = fmaxf((float)(gh * gw), 1.f);
     const float* f = feat + (long long)n * H * W * C + c;
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = 0.f;
     for (int iy = 0; iy < gh; ++iy) {
         const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
         for (int ix = 0; ix < gw; ++ix) {
             const float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
-            acc += roi_bilinear(f, H, W, C, y, x);
+            roi_bilinear<V>(f, H, W, C, y, x, acc);
         }
     }
     const int ow = (flip_w && flip_w[n]) ? P - 1 - pw : pw;
-    out[(((long long)n * P + ph) * P + ow) * ldo + c_off + c] = acc / cnt;
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = acc[u] / cnt;
+    stv<V>(out + (((long long)n * P + ph) * P + ow) * ldo + c_off + c, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ heat-map re-alignment
@@ -465,14 +501,20 @@ extern "C" int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W
                                              float* y, int ldy, int c_off, int accumulate, void* stream) {
     VPHO_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && ldx >= C && ldy >= c_off + C && c_off >= 0,
                  "vpho_resize_bilinear_nhwc_f32: bad argument");
-    LAUNCH1D(resize_bilinear_nhwc_kernel, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
+        LAUNCH1D(resize_bilinear_nhwc_kernel<4>, (long long)N * OH * OW * (C / 4), stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
+    else
+        LAUNCH1D(resize_bilinear_nhwc_kernel<1>, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
     return vpho::check_launch("resize_bilinear_nhwc_kernel");
 }
 
 extern "C" int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                        int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream) {
     VPHO_REQUIRE(feat && boxes && out && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_nhwc_f32: bad argument");
-    LAUNCH1D(roi_align_nhwc_kernel, (long long)N * out_size * out_size * C, stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
+    if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)feat | (uintptr_t)out) % 16 == 0)
+        LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
+    else
+        LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
     return vpho::check_launch("roi_align_nhwc_kernel");
 }
 
