@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# OpenMP workers that spin after every parallel CPU region burn the host's CPU quota for nothing (the GPU boxes give a rank
+# 16 CPUs; a throttled cgroup stalls the launch threads in 100 ms periods).  Must be set before torch loads libgomp.
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FEATURE_GFLOP_PER_IMAGE = 37.09
@@ -134,12 +137,14 @@ def main():
         return E.gather_rows(torch.cat(rows, 0)), nfev     # the ONE collective of the evaluation
 
     # ---- timed region: K steps, no instrumentation -----------------------------------------------------------------
+    cpu0 = sum(os.times()[:2])
     t0 = time.perf_counter()
     all_rows, nfev = run_steps(args.steps)
     ev_end = torch.cuda.Event(enable_timing=True)
     ev_end.record()
     barrier()
     dt = time.perf_counter() - t0
+    host_cpu_s = sum(os.times()[:2]) - cpu0                 # user+system CPU seconds of this process over the timed region
     if pipe is not None:                                   # per-step latencies: a short sequential run after the timed region
         step_events.clear()
         run_steps(min(args.steps, 5), pipelined=False)
@@ -173,6 +178,7 @@ def main():
     result = None
     if rank == 0:
         images = world * args.steps * args.bs
+        host_cpu = {'cpu_seconds_per_step': host_cpu_s / args.steps, 'busy_threads_equivalent': host_cpu_s / dt}
         conv_tf = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
         head_tf = head['flops'] / (head['total_ms'] * 1e-3) / 1e12 if head['total_ms'] > 0 else 0.0
         result = {
@@ -206,6 +212,7 @@ def main():
                                         'launches_per_step': head['launches'] / max(args.steps, 1)},
                          'feature_path_gflop_per_image_ref': FEATURE_GFLOP_PER_IMAGE},
             'metrics_rows_gathered': int(all_rows.shape[0]),
+            'host_cpu': host_cpu,
         }
         if world == 1 and not args.no_cpu_baseline:
             result.update(cpu_baseline_leg(args, cfg, model, sd, assets, ANCHOR_SKELETON, dev))

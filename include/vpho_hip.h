@@ -94,9 +94,12 @@ typedef struct {
 /* Full cond_ode_sampler run.  init_x: [R][D] fp32 prior draw (already scaled by sigma(T0)).
  * xs_out: [R][num_steps][D] dense output at t_eval = linspace(T0, eps, num_steps), fp64 if xs_is_f64 else fp32
  * (the reference casts the hand trajectory to fp32 right after sampling, VPHO.py:243); x_out: [R][D] final sample
- * after the denoise step, fp64 if x_is_f64 else rounded to fp32 the same way.  SYNCHRONISES `stream` once per attempted RK step (8-byte error norm D2H) --
- * the scalar step controller runs on the host exactly as scipy's.  stats_host / step_log_host are host memory
- * (step_log_host may be NULL; capacity in entries of 4 doubles). */
+ * after the denoise step, fp64 if x_is_f64 else rounded to fp32 the same way.  scipy's scalar step controller
+ * (select_initial_step, accept/reject, step-size factor, t_eval stamps) runs in one-thread kernels on a control block in the
+ * workspace; the call enqueues the expected number of attempts plus the denoise step and waits for `stream` ONCE (more
+ * attempts are added two at a time if the solve is not finished).  With the environment variable VPHO_RK_HOST=1 (or
+ * num_steps > 1024) the controller runs on the host instead and the call synchronises once per attempted step.
+ * stats_host / step_log_host are host memory (step_log_host may be NULL; capacity in entries of 4 doubles). */
 int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
                     double T0, double eps, int num_steps, double rtol, double atol,
                     void* xs_out, int xs_is_f64, void* x_out, int x_is_f64,

