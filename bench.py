@@ -110,6 +110,13 @@ def main():
     step_events = []
 
     pipe = E.PipelinedPredictor(model, args.pipeline) if args.pipeline > 1 else None
+    if pipe is not None and args.warmup:
+        # every slot of the pipelined evaluator has its own execution plan (packed weights, captured HIP graphs, sampler
+        # workspaces): the untimed warm-up has to go through each of them as well
+        for f in [pipe.submit(batches[i % 2], lambda out, batch, engine: E.metric_rows(out, batch, gt_joint, gt_vert, 0, assets))
+                  for i in range(max(args.warmup, 2 * args.pipeline))]:
+            f.result()
+        barrier()
 
     def run_steps(k, pipelined=True):
         rows, nfev = [], []
@@ -163,8 +170,11 @@ def main():
     if not args.no_kernel_timing:
         for c in timed_classes:
             ops.prof_enable(c, True)
+        graphs_were = eng.use_graphs
+        eng.use_graphs = False                             # events cannot be recorded inside a graph replay: same kernels, plain launches
         run_steps(args.steps, pipelined=False)
         barrier()
+        eng.use_graphs = graphs_were
         for c in timed_classes:
             ops.prof_enable(c, False)
             prof[c] = ops.prof_collect(c)

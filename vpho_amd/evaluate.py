@@ -115,7 +115,9 @@ class PipelinedPredictor:
                 eng = self.engines[slot]
                 out = eng.predict(batch, noise_hand=noise_h, noise_obj=noise_o)
                 res = post(out, batch, eng) if post is not None else out
-                self.streams[slot].synchronize()
+                done = torch.cuda.Event(blocking=True)      # sleep, do not spin: the slot threads share the rank's CPU quota
+                done.record(self.streams[slot])
+                done.synchronize()
                 return res
 
         return self.pool.submit(work)
