@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int HB_K = 16, HB_LD = HB_K + 4;
+constexpr int HB_K = 16;
 constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
 // --------------------------------------------------------------------------------------------- time embedding
