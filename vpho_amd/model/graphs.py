@@ -17,14 +17,27 @@ _CAPTURE_LOCK = threading.Lock()
 class GraphedCall:
     def __init__(self, fn, device, max_entries=4):
         self.fn, self.dev, self.entries, self.max_entries = fn, device, {}, max_entries
+        self.disabled = False
 
     def __call__(self, tensors, extra_key=()):
+        if self.disabled:
+            return self.fn(tensors)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + tuple(extra_key)
         e = self.entries.get(key)
         if e is None:
             while len(self.entries) >= self.max_entries:            # each entry owns a private memory pool: bound them
                 self.entries.pop(next(iter(self.entries)))
-            e = self.entries[key] = self._capture(tensors)
+            try:
+                e = self._capture(tensors)
+            except (RuntimeError, torch.AcceleratorError) as err:   # capture refused (e.g. a foreign thread touched the device):
+                from ..ops import VphoError                         # same kernels, launched one by one from here on
+                if isinstance(err, VphoError):
+                    raise
+                import warnings
+                warnings.warn(f'HIP graph capture failed ({err}); falling back to plain launches for this call site')
+                self.disabled = True
+                return self.fn(tensors)
+            self.entries[key] = e
         static, graph, out = e
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
