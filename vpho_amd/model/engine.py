@@ -137,7 +137,11 @@ class Engine:
         c2 = self._layer(c1, 'layer1_h')
         c3h, c3o = self._layer(c2, 'layer2_h'), self._layer(c2, 'layer2_o')
         c4h, c4o = self._layer(c3h, 'layer3_h'), self._layer(c3o, 'layer3_o')
-        c5h, c5o = self._layer(c4h, 'layer4_h'), self._layer(c4o, 'layer4_h')          # shared layer4 (quirk Q6)
+        # shared layer4 (quirk Q6): both branches go through the same weights, so they run as ONE batch of 2N images
+        # (twice the tiles per launch at 8x8 resolution, half the launches); convolutions are per-image, results unchanged
+        n = c4h.shape[0]
+        c5 = self._layer(torch.cat([c4h, c4o], 0), 'layer4_h')
+        c5h, c5o = c5[:n], c5[n:]
         out = []
         for br, c5, c4, c3 in (('h', c5h, c4h, c3h), ('o', c5o, c4o, c3o)):
             p = ops.conv2d_nhwc(c5, *self.fpn[f'toplayer_{br}'])
