@@ -188,3 +188,26 @@ def test_object_metrics_match_reference_tester(assets):
         np.testing.assert_array_equal(got[:, col[k]], ref[:, col[k]], err_msg=k)
     for k in OM.OBJ_METRIC_NAMES[10:]:
         np.testing.assert_allclose(got[:, col[k]], ref[:, col[k]], atol=3e-3, err_msg=k)
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_dsm_training_step_matches_reference(sd, name, D):
+    """oracle.train_score (loss, autograd gradients, AdamW step) vs the reference's own BaseDenoiser + loss_fn + torch.optim.AdamW
+    (fixture by tests/golden/make_golden_train.py): loss 1e-6 rel, gradient norms 1e-5 rel, sampled entries 1e-5 of the norm."""
+    from oracle import train_score as T
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_train_score.npz'))
+    p = f'denoiser_{name}'
+    feat, gt = torch.from_numpy(g[f'{name}_feat']), torch.from_numpy(g[f'{name}_gt'])
+    ts, zs = torch.from_numpy(g[f'{name}_t'])[:, :, None], torch.from_numpy(g[f'{name}_z'])
+    loss, grads, dfeat = T.loss_and_grads(sd, p, feat, gt, ts, zs)
+    np.testing.assert_allclose(float(loss), float(g[f'{name}_loss']), rtol=2e-6)
+    np.testing.assert_allclose(dfeat.numpy(), g[f'{name}_dfeat'], rtol=1e-4, atol=1e-6 * float(np.abs(g[f'{name}_dfeat']).max()))
+    for s in T.PARAM_SUFFIXES:
+        gr = grads[s].reshape(-1)
+        nrm = float(g[f'{name}_gnorm_{s}'])
+        np.testing.assert_allclose(float(gr.double().norm()), nrm, rtol=1e-5, err_msg=s)
+        np.testing.assert_allclose(gr[::9973].numpy(), g[f'{name}_gsample_{s}'], atol=1e-5 * nrm + 1e-12, err_msg=s)
+        w = sd[f'{p}.{s}']
+        new, _, _ = T.adamw_step(w, grads[s], torch.zeros_like(w), torch.zeros_like(w), step=1)
+        np.testing.assert_allclose(new.reshape(-1)[::9973].numpy(), g[f'{name}_psample_{s}'], rtol=2e-6, atol=1e-9, err_msg=s)
+        np.testing.assert_allclose(float((new - w).double().norm()), float(g[f'{name}_dnorm_{s}']), rtol=1e-4, err_msg=s)
