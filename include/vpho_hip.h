@@ -273,6 +273,41 @@ int vpho_contact_detect_f32(const float* query, const float* query_normals, cons
 int vpho_force_contact_f32(const vpho_anchor_tables* t, const float* hand_contact, int ld, int n, float thresh,
                            float* force_contact, unsigned char* is_grasped, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training of the score networks (first slice): the denoising-score-matching step of
+ * ScoreBasedModelAgent.get_score_loss / loss_fn (lib/model/score_based_model.py:11-42,117-128) on BaseDenoiser
+ * (lib/model/denoiser.py:68-82) -- forward with saved activations, analytic backward to every denoiser parameter and to the
+ * image encoding, AdamW (lib/engine/train_diff_hand_obj.py:49-52).  rows = repeat_num * batch, row r = rep * batch + b.
+ * The GEMMs run through vpho_conv2d_nhwc_f32 (1x1 convolutions on [rows][C] matrices); these are the pieces around them. */
+/* std = 0.01 * 5000^t (sde.py:15-18), x_t = gt_pose[b] + z * std zero-padded to Dp columns, emb = [sin, cos](t W 2 pi)
+ * (denoiser.py:29-31).  t [rows], z [rows][D], fourier_W [64] -> x_t [rows][Dp], emb [rows][128], std_out [rows] */
+int vpho_dsm_prepare_f32(const float* gt_pose, const float* t, const float* z, const float* fourier_W, int bs, int reps, int D, int Dp,
+                         float* x_t, float* emb, float* std_out, void* stream);
+/* second ParallelLinear (256 -> 3 per head, parallel_linear.py:27-35) + division by (std + 1e-7) (denoiser.py:80-81):
+ * h [rows][nheads*256], w2 [nheads][256][3], b2 [nheads][3] -> score [rows][3*nheads] */
+int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, const float* std_rows, long long rows, int nheads,
+                          float* score, void* stream);
+/* loss = mean over batch*reps of sum_d std^2 (score - target)^2, target = -z std / std^2 (score_based_model.py:33-41);
+ * dout = d loss / d (un-normalised head output) [rows][D]; loss: one double on the device; partial_ws: >= 1024 doubles */
+int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
+                      float* dout, double* loss, double* partial_ws, int partial_cap, void* stream);
+/* backward of the second ParallelLinear and of the ReLU in front of it: dpre [rows][nheads*256] (gradient at the first
+ * layer's pre-activation), dw2 [nheads][256][3], db2 [nheads][3] */
+int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,
+                          void* stream);
+/* dx = y > 0 ? dy : 0 on [rows][cols] slices with leading dimensions (gradient through nn.ReLU given its output y) */
+int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int ld_y, long long rows, int cols, float* dx, int ld_dx, void* stream);
+/* out[c] = sum_r x[r][c] (bias gradients; rows are added in order) */
+int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* stream);
+/* out[b][c] = sum_rep x[rep*bs + b][c_off + c]: the encoding is shared by the repeat_num draws of an image */
+int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream);
+/* y[c][r] = x[r][c] (operands of the weight-gradient GEMMs) */
+int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
+/* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient
+ * first (1 / world_size after a sum all-reduce) */
+int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

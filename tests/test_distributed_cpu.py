@@ -87,3 +87,48 @@ def test_metric_rows_and_postprocess_cpu():
     assert torch.equal(rows[:, 0], torch.tensor([8., 9., 10., 11.]))
     assert torch.allclose(rows[:, 3], torch.zeros(bs), atol=1e-4) and torch.allclose(rows[:, 4], torch.zeros(bs), atol=1e-4)
     assert torch.all(rows[:, 1] > 1.0)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.argv = sys.argv[:1]
+    from oracle import train_score as OT
+    from vpho_amd.assets import synthetic_assets
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_state_dict
+    from vpho_amd.train_score import allreduce_mean_scale, SUFFIXES
+    sd = synth_state_dict(vpho_net(synthetic_assets(0)), seed=1)
+    p, D, bs, reps = 'denoiser_obj', 9, 4, 2
+    g = torch.Generator().manual_seed(7)                                   # every rank draws the GLOBAL batch, then takes its shard
+    feat, gt = torch.randn(world * bs, 1024, generator=g) * 0.3, torch.randn(world * bs, D, generator=g) * 0.5
+    ts = torch.rand(reps, world * bs, generator=g) * (1 - 1e-5) + 1e-5
+    zs = torch.randn(reps, world * bs, D, generator=g)
+    sl = slice(rank * bs, (rank + 1) * bs)
+    _, grads, _ = OT.loss_and_grads(sd, p, feat[sl], gt[sl], ts[:, sl, None], zs[:, sl])
+    flat = torch.cat([grads[s].reshape(-1) for s in SUFFIXES])
+    scale = allreduce_mean_scale(flat)                                     # what ScoreTrainer.step does with its flat buffer
+    mean = flat * scale
+    _, full, _ = OT.loss_and_grads(sd, p, feat, gt, ts[:, :, None], zs)     # the same step as ONE batch of world*bs images
+    want = torch.cat([full[s].reshape(-1) for s in SUFFIXES])
+    q.put((rank, scale, float((mean - want).abs().max()), float(want.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_score_training_gradient_average_world2_gloo():
+    """Data-parallel DSM step: per-rank gradients, one SUM all-reduce of the flat buffer and the 1/world factor equal the
+    gradient of the global batch (the loss is a mean over images) -- the DDP semantics of the reference's accelerate setup."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, scale, err, mag in got:
+        assert scale == 0.5
+        assert err <= 2e-6 * mag + 1e-9, (rank, err, mag)

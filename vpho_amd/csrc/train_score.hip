@@ -1,0 +1,258 @@
+// Denoising-score-matching training step of a score network (first slice): the pieces around the GEMMs.
+// Reference: lib/model/score_based_model.py:11-42,117-128 (loss_fn / get_score_loss), lib/model/sde.py:15-18 (ve_marginal_prob),
+// lib/model/denoiser.py:19-31,68-82,176-189,244-257 (Fourier time features, BaseDenoiser.forward, ParallelLinear heads),
+// lib/engine/train_diff_hand_obj.py:49-52,169-199 (AdamW, one step per batch).
+// The matrix products (rows = repeat_num * batch, 1408 x nheads*256 first head layer and its two backward products, the
+// encoders) run on conv_igemm's fp32-MFMA GEMM; here are the per-row preparation, the 256 -> 3 second head layer and its
+// backward, the loss with its seed gradient, ReLU masks, bias gradients (deterministic column sums) and the AdamW update.
+// All HBM-bound; row-major fp32.
+#include "common.h"
+#include "../../include/vpho_hip.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr float SIG_MIN = 0.01f, SIG_MAX = 50.0f;
+inline int nblk(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+
+// rows r = rep * bs + b:  std = sigma_min (sigma_max / sigma_min)^t,  x_t = x0[b] + z * std,  emb = [sin, cos](t W 2 pi)
+__global__ void dsm_prepare_kernel(const float* __restrict__ gt, const float* __restrict__ t, const float* __restrict__ z,
+                                   const float* __restrict__ Wf, int bs, int rows, int D, int Dp,
+                                   float* __restrict__ xt, float* __restrict__ emb, float* __restrict__ stdv) {
+    const int r = blockIdx.x;
+    const int b = r % bs;
+    const float tt = t[r];
+    const float sd = SIG_MIN * powf(SIG_MAX / SIG_MIN, tt);
+    if (threadIdx.x == 0) stdv[r] = sd;
+    for (int c = threadIdx.x; c < Dp; c += blockDim.x) xt[(long long)r * Dp + c] = c < D ? gt[b * D + c] + z[(long long)r * D + c] * sd : 0.f;
+    for (int k = threadIdx.x; k < 64; k += blockDim.x) {
+        float a = tt * Wf[k];
+        a = a * 2.0f;
+        a = a * 3.14159265358979323846f;
+        emb[r * 128 + k] = sinf(a);
+        emb[r * 128 + 64 + k] = cosf(a);
+    }
+}
+
+// score[r][3n+d] = (b2[n][d] + sum_c h[r][n*256+c] * w2[n][c][d]) / (std[r] + 1e-7): one wave per (row, head)
+__global__ __launch_bounds__(256) void plinear2_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           const float* __restrict__ stdv, long long rows, int n, float* __restrict__ score) {
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= rows * n) return;
+    const long long r = item / n;
+    const int hd = (int)(item - r * n);
+    const float* hp = h + (r * n + hd) * 256;
+    const float* wp = w2 + (long long)hd * 256 * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < 256; c += 64) {
+        const float hv = hp[c];
+        s0 += hv * wp[c * 3]; s1 += hv * wp[c * 3 + 1]; s2 += hv * wp[c * 3 + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        const float den = stdv[r] + 1e-7f;
+        float* o = score + r * (3 * n) + hd * 3;
+        o[0] = (s0 + b2[hd * 3]) / den; o[1] = (s1 + b2[hd * 3 + 1]) / den; o[2] = (s2 + b2[hd * 3 + 2]) / den;
+    }
+}
+
+// per element: target = -z std / std^2, weight std^2, term = w (s - target)^2;  dscore = 2 w (s - target) * inv_count;
+// dout = dscore / (std + 1e-7) (gradient w.r.t. the un-normalised head output); per-block partial sums of the loss
+__global__ __launch_bounds__(256) void dsm_loss_kernel(const float* __restrict__ score, const float* __restrict__ z, const float* __restrict__ stdv,
+                                                       long long n_el, int D, float inv_count, float* __restrict__ dout, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_el; i += (long long)gridDim.x * 256) {
+        const float sd = stdv[i / D];
+        const float w = sd * sd;
+        const float target = (0.f - z[i]) * sd / w;
+        const float diff = score[i] - target;
+        acc += (double)(w * (diff * diff));
+        dout[i] = (2.f * w * diff * inv_count) / (sd + 1e-7f);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double scale, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = red[0] * scale;
+}
+
+// dpre[r][n*256+c] = h > 0 ? sum_d dout[r][3n+d] * w2[n][c][d] : 0   (backward of the second head layer and of the ReLU before it)
+__global__ void plinear2_bwd_input_kernel(const float* __restrict__ h, const float* __restrict__ dout, const float* __restrict__ w2,
+                                          long long rows, int n, float* __restrict__ dpre) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n * 256) return;
+    const int c = (int)(i & 255);
+    const long long rn = i >> 8;
+    const int hd = (int)(rn % n);
+    const long long r = rn / n;
+    const float* d = dout + r * (3 * n) + hd * 3;
+    const float* w = w2 + ((long long)hd * 256 + c) * 3;
+    const float g = d[0] * w[0] + d[1] * w[1] + d[2] * w[2];
+    dpre[i] = h[i] > 0.f ? g : 0.f;
+}
+// dw2[n][c][d] = sum_r h[r][n*256+c] * dout[r][3n+d];  db2[n][d] = sum_r dout[r][3n+d]: one block per head, rows strided
+// over 4 waves then combined in a fixed order
+__global__ __launch_bounds__(256) void plinear2_bwd_weight_kernel(const float* __restrict__ h, const float* __restrict__ dout, long long rows, int n,
+                                                                  float* __restrict__ dw2, float* __restrict__ db2) {
+    __shared__ float part[4][256 * 3 + 3];
+    const int hd = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float a[4][3] = {{0}};
+    float bsum[3] = {0.f, 0.f, 0.f};
+    for (long long r = wave; r < rows; r += 4) {
+        const float* d = dout + r * (3 * n) + hd * 3;
+        const float d0 = d[0], d1 = d[1], d2 = d[2];
+        const float* hp = h + (r * n + hd) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float hv = hp[q * 64 + lane];
+            a[q][0] += hv * d0; a[q][1] += hv * d1; a[q][2] += hv * d2;
+        }
+        bsum[0] += d0; bsum[1] += d1; bsum[2] += d2;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int d = 0; d < 3; ++d) part[wave][(q * 64 + lane) * 3 + d] = a[q][d];
+    if (lane == 0) for (int d = 0; d < 3; ++d) part[wave][768 + d] = bsum[d];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 771; i += 256) {
+        const float s = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+        if (i < 768) dw2[(long long)hd * 768 + i] = s; else db2[hd * 3 + (i - 768)] = s;
+    }
+}
+
+// dx = y > 0 ? dy : 0 on a [rows][cols] slice with leading dimensions (masks the gradient of a ReLU output y)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, long long rows, int cols,
+                                float* __restrict__ dx, int ld_dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long long r = i / cols;
+    const int c = (int)(i - r * cols);
+    dx[r * ld_dx + c] = y[r * ld_y + c] > 0.f ? dy[r * ld_dy + c] : 0.f;
+}
+
+// out[c] = sum_r x[r][c] (bias gradients): one thread per column walks the rows in order (coalesced across columns)
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, long long rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (long long r = 0; r < rows; ++r) s += x[r * ld + c];
+    out[c] = s;
+}
+
+// out[b][c] = sum_rep x[rep*bs + b][c_off + c]  (gradient w.r.t. the image encoding, shared by the repeat_num draws)
+__global__ void sum_repeats_kernel(const float* __restrict__ x, int ld, int c_off, int bs, int reps, int cols, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)bs * cols) return;
+    const int b = (int)(i / cols), c = (int)(i - (long long)b * cols);
+    float s = 0.f;
+    for (int r = 0; r < reps; ++r) s += x[((long long)r * bs + b) * ld + c_off + c];
+    out[i] = s;
+}
+
+// y[c][r] = x[r][c] through a padded 32x32 LDS tile
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int rows, int cols, int ldx, float* __restrict__ y, int ldy) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? x[(long long)r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) y[(long long)c * ldy + r] = tile[tx][j];
+    }
+}
+
+// torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                             float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gr = g[i] * grad_scale;
+    float w = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] = w - step_size * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" int vpho_dsm_prepare_f32(const float* gt_pose, const float* t, const float* z, const float* fourier_W, int bs, int reps, int D, int Dp,
+                                    float* x_t, float* emb, float* std_out, void* stream) {
+    VPHO_REQUIRE(gt_pose && t && z && fourier_W && x_t && emb && std_out && bs > 0 && reps > 0 && D > 0 && Dp >= D, "vpho_dsm_prepare_f32: bad argument");
+    hipLaunchKernelGGL(dsm_prepare_kernel, dim3(bs * reps), dim3(128), 0, (hipStream_t)stream, gt_pose, t, z, fourier_W, bs, bs * reps, D, Dp, x_t, emb, std_out);
+    return vpho::check_launch("dsm_prepare_kernel");
+}
+
+extern "C" int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, const float* std_rows, long long rows, int nheads,
+                                     float* score, void* stream) {
+    VPHO_REQUIRE(h && w2 && b2 && std_rows && score && rows > 0 && nheads > 0, "vpho_plinear2_fwd_f32: bad argument");
+    hipLaunchKernelGGL(plinear2_fwd_kernel, dim3(nblk(rows * nheads, 4)), dim3(256), 0, (hipStream_t)stream, h, w2, b2, std_rows, rows, nheads, score);
+    return vpho::check_launch("plinear2_fwd_kernel");
+}
+
+extern "C" int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
+                                 float* dout, double* loss, double* partial_ws, int partial_cap, void* stream) {
+    VPHO_REQUIRE(score && z && std_rows && dout && loss && partial_ws && rows > 0 && D > 0 && batch_times_reps > 0 && partial_cap >= 1, "vpho_dsm_loss_f32: bad argument");
+    const int nb = std::min(partial_cap, std::min(1024, nblk(rows * D)));
+    hipLaunchKernelGGL(dsm_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, z, std_rows, rows * D, D, 1.0f / (float)batch_times_reps, dout, partial_ws);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial_ws, nb, 1.0 / (double)batch_times_reps, loss);
+    return vpho::check_launch("dsm_loss kernels");
+}
+
+extern "C" int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,
+                                     void* stream) {
+    VPHO_REQUIRE(h && dout && w2 && dpre && dw2 && db2 && rows > 0 && nheads > 0, "vpho_plinear2_bwd_f32: bad argument");
+    hipLaunchKernelGGL(plinear2_bwd_input_kernel, dim3(nblk(rows * nheads * 256)), dim3(256), 0, (hipStream_t)stream, h, dout, w2, rows, nheads, dpre);
+    hipLaunchKernelGGL(plinear2_bwd_weight_kernel, dim3(nheads), dim3(256), 0, (hipStream_t)stream, h, dout, rows, nheads, dw2, db2);
+    return vpho::check_launch("plinear2_bwd kernels");
+}
+
+extern "C" int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int ld_y, long long rows, int cols, float* dx, int ld_dx, void* stream) {
+    VPHO_REQUIRE(dy && y && dx && rows > 0 && cols > 0 && ld_dy >= cols && ld_y >= cols && ld_dx >= cols, "vpho_relu_bwd_f32: bad argument");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(rows * cols)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, y, ld_y, rows, cols, dx, ld_dx);
+    return vpho::check_launch("relu_bwd_kernel");
+}
+
+extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* stream) {
+    VPHO_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblk(cols, 64)), dim3(64), 0, (hipStream_t)stream, x, ld, rows, cols, out);
+    return vpho::check_launch("colsum_kernel");
+}
+
+extern "C" int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream) {
+    VPHO_REQUIRE(x && out && bs > 0 && reps > 0 && cols > 0 && c_off >= 0 && ld >= c_off + cols, "vpho_sum_repeats_f32: bad argument");
+    hipLaunchKernelGGL(sum_repeats_kernel, dim3(nblk((long long)bs * cols)), dim3(256), 0, (hipStream_t)stream, x, ld, c_off, bs, reps, cols, out);
+    return vpho::check_launch("sum_repeats_kernel");
+}
+
+extern "C" int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream) {
+    VPHO_REQUIRE(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= rows, "vpho_transpose_f32: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, y, ldy);
+    return vpho::check_launch("transpose_kernel");
+}
+
+extern "C" int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    VPHO_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "vpho_adamw_f32: bad argument");
+    // bias corrections in double on the host, as torch.optim.AdamW computes them (python floats)
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)((double)lr / bc1), (float)std::sqrt(bc2), grad_scale);
+    return vpho::check_launch("adamw_kernel");
+}

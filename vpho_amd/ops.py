@@ -589,6 +589,90 @@ class ObjectMetrics:
         return out
 
 
+# ----------------------------------------------------------------------------------------------- score-network training
+def _at(t, off=0):
+    """device address of element `off` of a contiguous fp32 tensor"""
+    _ptr(t, torch.float32)
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def linear_into(x, w, bias, out, c_off, out_slope=1.0):
+    """out[:, c_off : c_off + cout] = act(x @ w.T + bias) for a wider row-major `out` (concatenation buffers)."""
+    rows, cin = x.shape
+    ld = out.shape[1]
+    conv2d_nhwc(x.view(rows, 1, 1, cin), w, bias, out_slope=out_slope, out_view=(out, ld, ld, ld, c_off))
+    return out
+
+
+def dsm_prepare(gt_pose, t, z, fourier_W, Dp):
+    """t (reps,bs), z (reps,bs,D) -> x_t (rows,Dp), emb (rows,128), std (rows,)   rows = reps*bs, row = rep*bs + b"""
+    reps, bs = t.shape
+    D = gt_pose.shape[1]
+    xt, emb, sd = _new((reps * bs, Dp), gt_pose), _new((reps * bs, 128), gt_pose), _new((reps * bs,), gt_pose)
+    _call('vpho_dsm_prepare_f32', _f32(gt_pose), _f32(t), _f32(z), _f32(fourier_W), I(bs), I(reps), I(D), I(Dp), _f32(xt), _f32(emb), _f32(sd))
+    return xt, emb, sd
+
+
+def plinear2_fwd(h, w2, b2, std_rows, nheads):
+    rows = h.shape[0]
+    score = _new((rows, 3 * nheads), h)
+    _call('vpho_plinear2_fwd_f32', _f32(h), _f32(w2), _f32(b2), _f32(std_rows), LL(rows), I(nheads), _f32(score))
+    return score
+
+
+def dsm_loss(score, z, std_rows, batch_times_reps):
+    """-> loss (0-d fp64 device tensor), dout (rows,D)"""
+    rows, D = score.shape
+    dout = torch.empty_like(score)
+    loss = _new((), score, torch.float64)
+    ws = _new((1024,), score, torch.float64)
+    _call('vpho_dsm_loss_f32', _f32(score), _f32(z), _f32(std_rows), LL(rows), I(D), I(batch_times_reps), _f32(dout), _f64(loss), _f64(ws), I(1024))
+    return loss, dout
+
+
+def plinear2_bwd(h, dout, w2, nheads):
+    rows = h.shape[0]
+    dpre, dw2, db2 = torch.empty_like(h), torch.empty_like(w2), _new((nheads, 3), h)
+    _call('vpho_plinear2_bwd_f32', _f32(h), _f32(dout), _f32(w2), LL(rows), I(nheads), _f32(dpre), _f32(dw2), _f32(db2))
+    return dpre, dw2, db2
+
+
+def relu_bwd(dy, dy_off, ld_dy, y, y_off, ld_y, rows, cols):
+    """contiguous (rows, cols) = where(y_slice > 0, dy_slice, 0); slices are given by element offset + leading dimension"""
+    dx = _new((rows, cols), dy)
+    _call('vpho_relu_bwd_f32', _at(dy, dy_off), I(ld_dy), _at(y, y_off), I(ld_y), LL(rows), I(cols), _f32(dx), I(cols))
+    return dx
+
+
+def colsum(x):
+    rows, cols = x.shape
+    out = _new((cols,), x)
+    _call('vpho_colsum_f32', _f32(x), I(cols), LL(rows), I(cols), _f32(out))
+    return out
+
+
+def sum_repeats(x, c_off, bs, reps, cols):
+    out = _new((bs, cols), x)
+    _call('vpho_sum_repeats_f32', _f32(x), I(x.shape[1]), I(c_off), I(bs), I(reps), I(cols), _f32(out))
+    return out
+
+
+def transpose(x, pad_to=4):
+    """(rows, cols) -> (cols, rows rounded up to a multiple of pad_to), the padding columns zero (GEMM operands want a
+    reduction length that is a multiple of 4)"""
+    rows, cols = x.shape
+    rp = (rows + pad_to - 1) // pad_to * pad_to
+    y = _new((cols, rp), x) if rp == rows else torch.zeros((cols, rp), device=x.device, dtype=x.dtype)
+    _call('vpho_transpose_f32', _f32(x), I(rows), I(cols), I(cols), _f32(y), I(rp))
+    return y
+
+
+def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+    """in-place torch.optim.AdamW step on one tensor"""
+    _call('vpho_adamw_f32', _f32(param), _f32(grad), _f32(m), _f32(v), LL(param.numel()), F(lr), F(beta1), F(beta2), F(eps), F(weight_decay),
+          I(step), F(grad_scale))
+
+
 # ----------------------------------------------------------------------------------------------- profiling hooks
 PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3}
 
