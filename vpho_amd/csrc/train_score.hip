@@ -141,13 +141,24 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, int ld_dy, const f
     dx[r * ld_dx + c] = y[r * ld_y + c] > 0.f ? dy[r * ld_dy + c] : 0.f;
 }
 
-// out[c] = sum_r x[r][c] (bias gradients): one thread per column walks the rows in order (coalesced across columns)
-__global__ void colsum_kernel(const float* __restrict__ x, int ld, long long rows, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] = sum_r x[r][c] (bias gradients): block = 32 columns x 8 row groups; a thread adds rows g, g+8, ... in order, the 8
+// partial sums are combined in a fixed order (deterministic, coalesced 128-B row segments)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, long long rows, int cols, float* __restrict__ out) {
+    __shared__ float part[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (long long r = 0; r < rows; ++r) s += x[r * ld + c];
-    out[c] = s;
+    if (c < cols) {
+#pragma unroll 8
+        for (long long r = g; r < rows; r += 8) s += x[r * ld + c];
+    }
+    part[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        float t = part[0][cl];
+        for (int k = 1; k < 8; ++k) t += part[k][cl];
+        out[c] = t;
+    }
 }
 
 // out[b][c] = sum_rep x[rep*bs + b][c_off + c]  (gradient w.r.t. the image encoding, shared by the repeat_num draws)
@@ -231,7 +242,7 @@ extern "C" int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int
 
 extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* stream) {
     VPHO_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblk(cols, 64)), dim3(64), 0, (hipStream_t)stream, x, ld, rows, cols, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out);
     return vpho::check_launch("colsum_kernel");
 }
 

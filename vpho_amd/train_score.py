@@ -51,17 +51,30 @@ class ScoreTrainer:
         self.v = {s: torch.zeros_like(p) for s, p in self.params.items()}
         self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.steps = 0
+        # forward + backward of a step are ~70 sync-free launches on fixed buffers (parameters are updated in place, gradients
+        # land in the flat buffer): replayed as one HIP graph per (batch, repeat_num) shape
+        import os
+        from .model.graphs import GraphedCall
+        self.use_graphs = os.environ.get('VPHO_GRAPHS', '1') != '0'
+        self._graph = GraphedCall(lambda t: self._loss_and_grads(t['feat'], t['gt'], t['ts'], t['zs']), self.dev)
 
     # ---------------------------------------------------------------------------------------------- loss + gradients
     @torch.no_grad()
     def loss_and_grads(self, feat, gt_pose, ts, zs):
         """feat (bs,1024), gt_pose (bs,D), ts (reps,bs) in [1e-5,1], zs (reps,bs,D) standard normal.
         Fills self.grads; returns (loss: 0-d fp64 device tensor, d loss / d feat (bs,1024))."""
+        f32 = lambda t: t.float().contiguous()
+        if not self.use_graphs:
+            return self._loss_and_grads(f32(feat), f32(gt_pose), f32(ts), f32(zs))
+        with torch.cuda.device(self.dev):
+            loss, dfeat = self._graph(dict(feat=f32(feat), gt=f32(gt_pose), ts=f32(ts), zs=f32(zs)))
+            return loss.clone(), dfeat.clone()
+
+    @torch.no_grad()
+    def _loss_and_grads(self, feat, gt_pose, ts, zs):
         P, n, D, Dp = self.params, self.nheads, self.D, self.Dp
         reps, bs = ts.shape
         M = reps * bs
-        f32 = lambda t: t.float().contiguous()
-        feat, gt_pose, ts, zs = f32(feat), f32(gt_pose), f32(ts), f32(zs)
         with torch.cuda.device(self.dev):
             xt, emb, std = ops.dsm_prepare(gt_pose, ts, zs, self.fourier_W, Dp)
             # ---- forward (denoiser.py:68-82), activations kept
