@@ -4,7 +4,9 @@
 prints the MJE/MVE tables after ONE all-gather of fixed-layout metric rows.  One process per GPU: launch with
 ``python -m torch.distributed.run --nproc-per-node N main.py --mode eval ...`` (or ``accelerate launch``, which sets the
 same RANK/LOCAL_RANK/WORLD_SIZE variables).  There is no dataset in this build: batches are synthetic (vpho_amd.synth).
-Training (``run``) is out of scope of the hot path and raises.
+``run`` (``--mode train``) trains the two score networks on frozen features (first slice; the backbone
+backward is not built): per batch the feature path runs in inference mode and ``ScoreTrainer.step`` makes the reference's
+``repeat_num`` DSM draws, the backward, the data-parallel gradient average and the AdamW update for each denoiser.
 """
 import os
 import time
@@ -56,8 +58,33 @@ class Trainer:
             model.load_state_dict(synth_state_dict(model, seed=1))
         return model.to(self.device).eval()
 
-    def run(self):
-        raise NotImplementedError('vpho_amd builds the inference hot path; training (--mode train) is not part of it')
+    def run(self, n_batches=None):
+        """Score-network training on frozen features over synthetic batches (train_diff_hand_obj.py:169-199 restricted to
+        ``denoiser_hand.*`` / ``denoiser_obj.*``; VPHO.py:190-191).  Returns the per-batch (hand, object) losses."""
+        from .model.engine import Engine
+        from .train_score import ScoreTrainer
+        cfg, bs = self.cfg, self.cfg.eval_batch_size
+        n_batches = cfg.num_batches if n_batches is None else n_batches
+        eng = Engine(self.model)
+        sd = self.model.state_dict()
+        hand, obj = ScoreTrainer(sd, 'denoiser_hand', self.device), ScoreTrainer(sd, 'denoiser_obj', self.device)
+        losses = []
+        for i in range(n_batches):
+            batch = {k: (v.to(self.device) if torch.is_tensor(v) else v)
+                     for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
+            with torch.no_grad():
+                f = eng.features(batch)
+            g = torch.Generator().manual_seed(int(cfg.random_seed + 7919 * i + self.rank))
+            rot = torch.linalg.qr(torch.randn(bs, 17, 3, 3, generator=g))[0]               # synthetic ground truth: random rotations
+            gt_hand = rot[:, :16, :2, :].reshape(bs, 96).to(self.device)                   # 16 x rot6d (mano_aa_to_6D(...)[..., :-10])
+            gt_obj = torch.cat([rot[:, 16, :2, :].reshape(bs, 6), torch.randn(bs, 3, generator=g) * 0.05], -1).to(self.device)
+            lh, _ = hand.step(f['encoding_hand'], gt_hand, repeat_num=getattr(cfg, 'repeat_num', 20))
+            lo, _ = obj.step(f['encoding_obj'], gt_obj, repeat_num=getattr(cfg, 'repeat_num', 20))
+            losses.append((float(lh), float(lo)))
+            if self.rank == 0 and i % max(1, getattr(cfg, 'print_freq', 10)) == 0:
+                print(f'[{i:04d}/{n_batches}] diff_hand_loss {losses[-1][0]:.3e}  diff_obj_loss {losses[-1][1]:.3e}')
+        self.model.load_state_dict({**hand.state_dict(), **obj.state_dict()}, strict=False)
+        return losses
 
     @torch.no_grad()
     def eval(self):
@@ -84,8 +111,11 @@ class Trainer:
         dt = time.perf_counter() - t0
         if self.rank == 0:
             print(f'evaluated {rows.shape[0]} synthetic images on {self.world} GPU(s) in {dt:.2f} s ({rows.shape[0] / dt:.1f} images/s)')
-            for name, r in E.summarize(rows.cpu()).items():
-                print(f'{name:>5s}: n={r["n"]:5d}  MJE reg {r["MJE_reg"]:.2f}  first {r["MJE_first"]:.2f}  agg {r["MJE_agg"]:.2f}  MVE agg {r["MVE_agg"]:.2f}  (mm)')
+            table = E.summarize(rows.cpu())
+            for name, r in table.items():
+                if name != 'object':
+                    print(f'{name:>5s}: n={r["n"]:5d}  MJE reg {r["MJE_reg"]:.2f}  first {r["MJE_first"]:.2f}  agg {r["MJE_agg"]:.2f}  MVE agg {r["MVE_agg"]:.2f}  (mm)')
+            print('object (aggregated pose): ' + '  '.join(f'{k} {v:.2f}' for k, v in table['object'].items()))
         if self.world > 1:
             dist.barrier()
         return rows
