@@ -303,6 +303,11 @@ int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out
 int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream);
 /* y[c][r] = x[r][c] (operands of the weight-gradient GEMMs) */
 int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
+/* Transposed im2col, the second operand of a convolution's weight gradient dW[co][(r,s,ci)] = sum_p dY^T[co][p] * out[(r,s,ci)][p]
+ * (the product itself is vpho_conv2d_nhwc_f32 as a GEMM): out[(r*KW+s)*Cin + ci][p] = x[n, oy*stride+r-pad_y, ox*stride+s-pad_x, ci],
+ * p = (n*OH+oy)*OW+ox, zero outside the image and in the padding columns p >= N*OH*OW of the leading dimension ldo. */
+int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, int KH, int KW, int stride, int pad_y, int pad_x,
+                      int OH, int OW, float* out, long long ldo, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient
  * first (1 / world_size after a sum all-reduce) */
 int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,

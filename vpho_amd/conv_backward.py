@@ -1,0 +1,71 @@
+"""Backward of the NHWC convolutions (building blocks for the backbone backward; not yet wired into a
+training step).  Both gradients reuse the forward fp32-MFMA implicit-GEMM kernel ``vpho_conv2d_nhwc_f32``:
+
+* ``conv2d_dgrad``: the gradient w.r.t. the input of a stride-1 convolution is a stride-1 convolution of dY with the spatially
+  flipped, channel-transposed weights; for stride 2 every output-pixel parity (iy%2, ix%2) only sees the taps r with
+  r = (iy + pad) mod 2, so dX is four small convolutions of dY written to interleaved positions (the same phase trick as the
+  forward ConvTranspose);
+* ``conv2d_wgrad``: dW[co][(r,s,ci)] = sum_p dY[p][co] * x_gathered[p][(r,s,ci)] is the GEMM dY^T . im2col(x)^T with the
+  pixel index as the reduction dimension; both operands are brought into the kernel's [row][K] layout by a transpose and by
+  ``vpho_im2col_t_f32`` (9x the input for a 3x3 -- memory, not a fused gather; adequate for the 288 GB part, to be fused).
+
+Weights are in the forward kernel's packed layout (Cout, KH*KW*Cin), activations NHWC fp32.  torch only allocates and permutes.
+Reference semantics: torch.nn.functional.conv2d's autograd (what ``loss.backward()`` does for every ``nn.Conv2d`` of
+lib/model/backbone_FPN_HFL.py, encoding.py, head_inplane.py under lib/engine/train_diff_hand_obj.py:181-182).
+"""
+import torch
+
+from . import ops
+
+
+def _flip_transpose(w_packed, cout, cin, kh, kw):
+    """(Cout, KH*KW*Cin) -> (Cin, KH*KW*Cout) with both spatial axes reversed"""
+    return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
+
+
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0):
+    """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad)."""
+    N, OH, OW, cout = dy.shape
+    H, W = in_hw
+    cin = w_packed.shape[1] // (kh * kw)
+    if stride == 1:
+        return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1, pad=kh - 1 - pad,
+                               pad_x=kw - 1 - pad, pad_y=kh - 1 - pad, out_hw=(H, W))
+    assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
+    w4 = w_packed.view(cout, kh, kw, cin)
+    dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)
+
+    def taps(parity, k):
+        # input row iy = 2a + parity receives tap r from output row a + (parity + pad - r) / 2
+        rs = [r for r in range(k) if (parity + pad - r) % 2 == 0]
+        return sorted(((parity + pad - r) // 2, r) for r in rs)          # (offset of the output row, tap), ascending offset
+
+    for py in (0, 1):
+        ty = taps(py, kh)
+        for px in (0, 1):
+            tx = taps(px, kw)
+            if not ty or not tx:
+                continue
+            oy0, ox0 = ty[0][0], tx[0][0]
+            khp, kwp = ty[-1][0] - oy0 + 1, tx[-1][0] - ox0 + 1
+            sub = torch.zeros((cin, khp, kwp, cout), device=dy.device, dtype=dy.dtype)
+            for offy, r in ty:
+                for offx, s in tx:
+                    sub[:, offy - oy0, offx - ox0, :] = w4[:, r, s, :].t()
+            # phase output (a, b) reads dY rows a + oy0 .. : a stride-1 convolution with padding -oy0 / -ox0
+            ops.conv2d_nhwc(dy, sub.reshape(cin, khp * kwp * cout).contiguous(), None, kh=khp, kw=kwp, stride=1, pad_y=-oy0, pad_x=-ox0,
+                            out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin))
+    return dx
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None):
+    """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights."""
+    N, OH, OW, cout = dy.shape
+    xg_t = ops.im2col_t(x, kh, kw, stride, pad, pad, OH, OW, cin=cin)             # (kh*kw*cin, P4)
+    dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns
+    return ops.linear(dy_t, xg_t)
+
+
+def conv2d_bias_grad(dy):
+    N, OH, OW, cout = dy.shape
+    return ops.colsum(dy.reshape(N * OH * OW, cout))

@@ -187,6 +187,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// Transposed im2col for the weight gradient of a convolution: out[(tap*Cin + ci)][p] = x[n, oy*stride + r - pad_y, ox*stride + s - pad_x, ci]
+// (0 outside the image), p = (n*OH + oy)*OW + ox, tap = r*KW + s.  32x32 tiles through LDS: reads are 128-B channel rows of
+// one pixel, writes 128-B pixel runs of one (tap, channel) row; grid (Cin/32, P/32, KH*KW).
+struct Im2colArgs { const float* x; int N, H, W, Cin, x_ld, KH, KW, stride, pad_y, pad_x, OH, OW; long long P, ldo; float* out; };
+__global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colArgs a) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32;
+    const long long p0 = (long long)blockIdx.y * 32;
+    const int tap = blockIdx.z, r = tap / a.KW, s = tap - r * a.KW;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const long long p = p0 + j;
+        float v = 0.f;
+        if (p < a.P && c0 + tx < a.Cin) {
+            const int ox = (int)(p % a.OW);
+            const long long q = p / a.OW;
+            const int oy = (int)(q % a.OH), n = (int)(q / a.OH);
+            const int iy = oy * a.stride + r - a.pad_y, ix = ox * a.stride + s - a.pad_x;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.x[(((long long)n * a.H + iy) * a.W + ix) * a.x_ld + c0 + tx];
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long long p = p0 + tx;
+        if (c < a.Cin && p < a.ldo) a.out[((long long)tap * a.Cin + c) * a.ldo + p] = p < a.P ? tile[tx][j] : 0.f;
+    }
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -266,4 +296,15 @@ extern "C" int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, f
     hipLaunchKernelGGL(adamw_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, (float)((double)lr / bc1), (float)std::sqrt(bc2), grad_scale);
     return vpho::check_launch("adamw_kernel");
+}
+
+extern "C" int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, int KH, int KW, int stride, int pad_y, int pad_x,
+                                 int OH, int OW, float* out, long long ldo, void* stream) {
+    VPHO_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && Cin > 0 && x_ld >= Cin && KH > 0 && KW > 0 && stride > 0 && OH > 0 && OW > 0,
+                 "vpho_im2col_t_f32: bad argument");
+    const long long P = (long long)N * OH * OW;
+    VPHO_REQUIRE(ldo >= P, "vpho_im2col_t_f32: leading dimension %lld < %lld pixels", ldo, P);
+    Im2colArgs a{x, N, H, W, Cin, x_ld, KH, KW, stride, pad_y, pad_x, OH, OW, P, ldo, out};
+    hipLaunchKernelGGL(im2col_t_kernel, dim3((Cin + 31) / 32, (unsigned)((ldo + 31) / 32), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
+    return vpho::check_launch("im2col_t_kernel");
 }

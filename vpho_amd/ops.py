@@ -667,6 +667,17 @@ def transpose(x, pad_to=4):
     return y
 
 
+def im2col_t(x, kh, kw, stride, pad_y, pad_x, OH, OW, cin=None):
+    """x (N,H,W,ld) NHWC -> (kh*kw*cin, P rounded up to a multiple of 4) with P = N*OH*OW; see vpho_im2col_t_f32"""
+    N, H, W, ld = x.shape
+    cin = ld if cin is None else cin
+    P = N * OH * OW
+    ldo = (P + 3) // 4 * 4
+    out = _new((kh * kw * cin, ldo), x)
+    _call('vpho_im2col_t_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), I(kh), I(kw), I(stride), I(pad_y), I(pad_x), I(OH), I(OW), _f32(out), LL(ldo))
+    return out
+
+
 def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
     """in-place torch.optim.AdamW step on one tensor"""
     _call('vpho_adamw_f32', _f32(param), _f32(grad), _f32(m), _f32(v), LL(param.numel()), F(lr), F(beta1), F(beta2), F(eps), F(weight_decay),
