@@ -39,6 +39,7 @@ int vpho_prof_collect(int kernel_class, double* total_ms, long long* launches, d
  * pre(v) = lrelu(v*in_scale[c]+in_shift[c], in_slope) when in_scale != NULL (pre-activation BN of encoding.Residual),
  * zero padding is applied after pre().  BatchNorm following a conv is folded into w/bias by the caller.
  * Requirements: Cin % 4 == 0, x_ld % 4 == 0 (x_ld = floats between consecutive pixels of x), 16-byte aligned x and w.
+ * The same kernel is the GEMM of the training slices (H=W=1: rows x Cin times Cout x Cin transposed).
  */
 typedef struct {
     const float* x; const float* w; const float* bias;
@@ -49,6 +50,11 @@ typedef struct {
     long long y_sn, y_sy, y_sx;      /* element strides of y for (n, oy, ox); channel stride is 1 */
     long long r_sn, r_sy, r_sx;      /* same for res */
     float in_slope, out_slope;
+    /* Optional (zero = off).  w_ld: floats between consecutive rows of w when a launch reduces only a K-slice of wider rows.
+     * splits > 1: blockIdx.y = 0..splits-1 runs the same problem on x + i*x_split, w + i*w_split and writes y + i*y_split --
+     * partial sums of a long reduction (the pixel dimension of a weight gradient) for the caller to add; no bias / res. */
+    int w_ld, splits;
+    long long x_split, w_split, y_split;
 } vpho_conv_desc;
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
 

@@ -63,7 +63,20 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None):
     N, OH, OW, cout = dy.shape
     xg_t = ops.im2col_t(x, kh, kw, stride, pad, pad, OH, OW, cin=cin)             # (kh*kw*cin, P4)
     dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns
-    return ops.linear(dy_t, xg_t)
+    kc, P4 = xg_t.shape
+    # The reduction runs over the pixels (P ~ 1e5) while the result is only Cout x kh*kw*Cin: split the pixel range over
+    # blockIdx.y until the launch has a few tiles per CU, then add the partial results in a fixed order
+    tiles = ((cout + 127) // 128) * ((kc + 127) // 128)
+    splits = 1
+    while tiles * splits < 512 and P4 // (splits * 2) >= 2048 and (P4 // (splits * 2)) % 4 == 0 and P4 % (splits * 2) == 0:
+        splits *= 2
+    if splits == 1:
+        return ops.linear(dy_t, xg_t)
+    ks = P4 // splits
+    part = torch.empty((splits * cout, kc), device=x.device, dtype=x.dtype)
+    ops.conv2d_nhwc(dy_t.view(cout, 1, 1, P4), xg_t, None, cin=ks, out=part.view(splits * cout, 1, 1, kc)[:cout],
+                    split=(splits, P4, ks, ks, cout * kc))
+    return ops.sum_repeats(part, 0, cout, splits, kc)
 
 
 def conv2d_bias_grad(dy):

@@ -22,6 +22,8 @@ constexpr int LDS_LD = BK + 4;
 struct Geo {
     vpho_conv_desc d;
     int M, K, tiles_m, tiles_n, ntiles;
+    int w_ld;                       // floats between consecutive weight rows (K unless the launch reduces a K-slice)
+    long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions; 0 for ordinary launches)
     int y_linear, r_linear, vec_epilogue;
     int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores
 };
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     static_assert(TM >= 1 && TN >= 1, "tile too small for the wave layout");
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
 
-    const vpho_conv_desc& d = g.d;
+    vpho_conv_desc d = g.d;
+    d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
     // XCD-aware renumbering: hardware block b runs on XCD (b % 8); give each XCD a contiguous run of logical tiles
     const int per_xcd = gridDim.x >> 3;
     const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int n = n0 + lrow + ROWS * j;
-        b_off[j] = (n < d.Cout && !(B_PART && lrow >= BN)) ? (long long)n * g.K + 4 * VEC * kq : -1;
+        b_off[j] = (n < d.Cout && !(B_PART && lrow >= BN)) ? (long long)n * g.w_ld + 4 * VEC * kq : -1;
     }
     // (r, s, c) of this thread's 16-byte piece of the NEXT tile to load; advanced by BK channels per tile without divisions
     int ld_c, ld_r, ld_s;
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     constexpr int TILE = (BM + BN) * BK;              // floats per stage (unpadded)
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
 
-    const vpho_conv_desc& d = g.d;
+    vpho_conv_desc d = g.d;
+    d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
     const int per_xcd = gridDim.x >> 3;
     const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (lb >= g.ntiles) return;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int n = n0 + lrow + ROWS * j;
-        b_off[j] = n < d.Cout ? (long long)n * g.K + 4 * kq : -1;
+        b_off[j] = n < d.Cout ? (long long)n * g.w_ld + 4 * kq : -1;
     }
     int ld_c, ld_r, ld_s;
     {
@@ -495,6 +499,11 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.d = d;
     g.M = (int)M;
     g.K = d.KH * d.KW * d.Cin;
+    const int splits = d.splits > 1 ? d.splits : 1;
+    g.w_ld = d.w_ld > 0 ? d.w_ld : g.K;
+    g.x_zs = splits > 1 ? d.x_split : 0; g.w_zs = splits > 1 ? d.w_split : 0; g.y_zs = splits > 1 ? d.y_split : 0;
+    VPHO_REQUIRE(g.w_ld >= g.K && g.w_ld % 4 == 0 && g.x_zs % 4 == 0 && g.w_zs % 4 == 0, "vpho_conv2d_nhwc_f32: w_ld / split strides must be multiples of 4, w_ld >= K");
+    VPHO_REQUIRE(splits == 1 || (!d.res && !d.bias && !d.in_scale), "vpho_conv2d_nhwc_f32: split launches produce plain partial sums (no bias / residual / prologue)");
     g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
     g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
     // 16-byte epilogue when every output pixel's channel run (and the residual's) is 16-byte addressable
@@ -505,14 +514,14 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     static const int dbg = getenv("VPHO_CONV_DBG") ? atoi(getenv("VPHO_CONV_DBG")) : 0;
     g.dbg = dbg;
     hipStream_t s = (hipStream_t)stream;
-    const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
-    const double flops = 2.0 * (double)M * d.Cout * g.K;
+    const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * splits;
+    const double flops = 2.0 * (double)M * d.Cout * g.K * splits;
     // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
     const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + (double)M * d.Cout * (d.res ? 2 : 1) + d.Cout);
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
-    const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64);
+    const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64) * splits;
     int variant = 64;
     if (big_tiles >= 256 && d.Cout % 128 == 0) variant = 1288;
     else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
@@ -521,7 +530,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         vpho::ProfScope prof(cls, s, flops, bytes);
         g.tiles_m = (int)((M + bm - 1) / bm); g.tiles_n = (d.Cout + bn - 1) / bn;
         g.ntiles = g.tiles_m * g.tiles_n;
-        hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(threads), 0, s, g);
+        hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8, splits), dim3(threads), 0, s, g);
     };
     static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
     const bool glds = d.in_scale == nullptr && !no_glds;

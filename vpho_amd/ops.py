@@ -54,7 +54,8 @@ class ConvDesc(C.Structure):
                 ('pad_x', C.c_int), ('OH', C.c_int), ('OW', C.c_int),
                 ('y_sn', C.c_longlong), ('y_sy', C.c_longlong), ('y_sx', C.c_longlong),
                 ('r_sn', C.c_longlong), ('r_sy', C.c_longlong), ('r_sx', C.c_longlong),
-                ('in_slope', C.c_float), ('out_slope', C.c_float)]
+                ('in_slope', C.c_float), ('out_slope', C.c_float),
+                ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -65,7 +66,7 @@ def _addr(t):
 
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
-                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None):
+                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
 
     ``out_view`` = (tensor, y_sn, y_sy, y_sx, element_offset) writes into a strided destination (concat buffers,
@@ -73,7 +74,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     N, H, W, x_ld = x.shape
     cin = x_ld if cin is None else cin
     cout = w.shape[0]
-    assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
+    assert split is not None or w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
     py = pad if pad_y is None else pad_y
     px = pad if pad_x is None else pad_x
     if out_hw is None:
@@ -103,6 +104,8 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     d.N, d.H, d.W, d.Cin, d.x_ld = N, H, W, cin, x_ld
     d.Cout, d.KH, d.KW, d.stride, d.pad_y, d.pad_x, d.OH, d.OW = cout, kh, kw, stride, py, px, OH, OW
     d.in_slope, d.out_slope = in_slope, out_slope
+    if split is not None:                                   # (splits, w_ld, x_split, w_split, y_split): see vpho_conv_desc
+        d.splits, d.w_ld, d.x_split, d.w_split, d.y_split = split
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
     return ret
 
