@@ -314,6 +314,20 @@ int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, in
  * p = (n*OH+oy)*OW+ox, zero outside the image and in the padding columns p >= N*OH*OW of the leading dimension ldo. */
 int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, int KH, int KW, int stride, int pad_y, int pad_x,
                       int OH, int OW, float* out, long long ldo, void* stream);
+/* nn.BatchNorm2d in training mode on NHWC rows (rows = N*H*W, leading dimension ld >= C) -- every BatchNorm of
+ * backbone_FPN_HFL.py / encoding.py / head_inplane.py under model.train() (train_diff_hand_obj.py:171): batch mean and biased
+ * variance (fp64 two-level reduction), y = lrelu((x - mean) * invstd * gamma + beta, slope) (slope 1 = no activation), running
+ * statistics updated with `momentum` and the unbiased variance; save_mean / save_invstd feed the backward:
+ * dbeta = sum dy, dgamma = sum dy * xhat, dx = gamma * invstd / rows * (rows * dy - dbeta - xhat * dgamma).
+ * (For a fused activation pass its backward first: vpho_lrelu_bwd_f32 on y.)  workspace: vpho_bn_workspace_bytes(C). */
+long long vpho_bn_workspace_bytes(int C);
+int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
+                              float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* y,
+                              void* workspace, void* stream);
+int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
+                               const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
+/* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
+int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient
  * first (1 / world_size after a sum all-reduce) */
 int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,

@@ -34,3 +34,33 @@ def test_dgrad_and_wgrad_match_autograd(N, H, W, cin, cout, k, stride, pad):
     np.testing.assert_allclose(dw.numpy(), dw_ref.numpy(), atol=2e-5 * float(dw_ref.abs().max()), rtol=1e-4)
     db = CB.conv2d_bias_grad(dyg).cpu()
     np.testing.assert_allclose(db.numpy(), dy.sum(dim=(0, 2, 3)).numpy(), atol=1e-4 * float(dy.abs().sum(dim=(0, 2, 3)).max()), rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,H,W,C,slope', [(2, 8, 8, 16, 1.0), (4, 16, 12, 33, 0.01), (64, 32, 32, 64, 0.01), (3, 1, 1, 8, 0.0)])
+def test_batchnorm_training_mode_matches_autograd(N, H, W, C, slope):
+    """nn.BatchNorm2d.train() (+ LeakyReLU) forward, running statistics and backward vs torch autograd"""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = torch.nn.functional.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    y = torch.nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    yg, saved = ops.bn_train_forward(nhwc(x), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g, slope=slope)
+    np.testing.assert_allclose(yg.permute(0, 3, 1, 2).cpu().numpy(), y.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(rm_g.cpu().numpy(), rm_ref.numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(rv_g.cpu().numpy(), rv_ref.numpy(), atol=1e-6, rtol=1e-5)
+    dyg = nhwc(dy)
+    if slope != 1.0:
+        dyg = ops.lrelu_bwd(dyg, yg, slope)
+    dx, dgam, dbet = ops.bn_train_backward(nhwc(x), dyg, gamma.detach().cuda(), saved)
+    tol = lambda ref: 3e-5 * float(ref.abs().max()) + 1e-7
+    np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy(), atol=tol(x.grad), rtol=1e-4)
+    np.testing.assert_allclose(dgam.cpu().numpy(), gamma.grad.numpy(), atol=tol(gamma.grad), rtol=1e-4)
+    np.testing.assert_allclose(dbet.cpu().numpy(), beta.grad.numpy(), atol=tol(beta.grad), rtol=1e-4)

@@ -217,6 +217,89 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm, training mode
+// nn.BatchNorm2d.train() on NHWC [rows][C] (rows = N*H*W; every BatchNorm of backbone_FPN_HFL.py / encoding.py /
+// head_inplane.py under model.train(), train_diff_hand_obj.py:171): per-channel reductions are column sums -- block = 32
+// channels x 8 row groups over a chunk of rows, fp64 partials [chunk][C] combined in a fixed order by the finishing kernel.
+// mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy * xhat) with xhat = (x - mean) * invstd
+struct BnRedArgs { const float* x; const float* dy; const float* mean; const float* invstd; long long rows; int C, ld, mode, rows_per_chunk; double* part; };
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnRedArgs a) {
+    __shared__ double p0[8][32], p1[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const long long r0 = (long long)blockIdx.y * a.rows_per_chunk, r1 = r0 + a.rows_per_chunk < a.rows ? r0 + a.rows_per_chunk : a.rows;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < a.C) {
+        const float mu = a.mode ? a.mean[c] : 0.f, is = a.mode ? a.invstd[c] : 0.f;
+        for (long long r = r0 + g; r < r1; r += 8) {
+            const float xv = a.x[r * a.ld + c];
+            if (a.mode == 0) { s0 += (double)xv; s1 += (double)xv * (double)xv; }
+            else { const float d = a.dy[r * a.ld + c]; s0 += (double)d; s1 += (double)d * (double)((xv - mu) * is); }
+        }
+    }
+    p0[g][cl] = s0; p1[g][cl] = s1;
+    __syncthreads();
+    if (g == 0 && c < a.C) {
+        double t0 = p0[0][cl], t1 = p1[0][cl];
+        for (int k = 1; k < 8; ++k) { t0 += p0[k][cl]; t1 += p1[k][cl]; }
+        a.part[((long long)blockIdx.y * 2) * a.C + c] = t0;
+        a.part[((long long)blockIdx.y * 2 + 1) * a.C + c] = t1;
+    }
+}
+// statistics: mean, biased variance -> invstd = 1/sqrt(var + eps); running stats with the unbiased variance (torch semantics)
+__global__ void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
+                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2) * C + c]; ss += part[((long long)k * 2 + 1) * C + c]; }
+    const double m = s / (double)rows;
+    double var = ss / (double)rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+__global__ void bn_finish_grads_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2) * C + c]; ss += part[((long long)k * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)ss;
+}
+// y = lrelu((x - mean) * invstd * gamma + beta, slope)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, long long rows, int C, int ld, float slope, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const float v = (x[r * ld + c] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    y[r * ld + c] = v > 0.f ? v : v * slope;
+}
+// dx = gamma * invstd / rows * (rows * dy - dbeta - xhat * dgamma)
+__global__ void bn_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                   long long rows, int C, int ld, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const float xh = (x[r * ld + c] - mean[c]) * invstd[c];
+    const float m = (float)rows;
+    dx[r * ld + c] = gamma[c] * invstd[c] / m * (m * dy[r * ld + c] - dbeta[c] - xh * dgamma[c]);
+}
+// dx = y > 0 ? dy : dy * slope  (LeakyReLU backward given its output; slope > 0 keeps the sign of the input)
+__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n, float slope, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dx[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -307,4 +390,50 @@ extern "C" int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, i
     Im2colArgs a{x, N, H, W, Cin, x_ld, KH, KW, stride, pad_y, pad_x, OH, OW, P, ldo, out};
     hipLaunchKernelGGL(im2col_t_kernel, dim3((Cin + 31) / 32, (unsigned)((ldo + 31) / 32), KH * KW), dim3(256), 0, (hipStream_t)stream, a);
     return vpho::check_launch("im2col_t_kernel");
+}
+
+namespace {
+int bn_chunks(long long rows, int* rows_per_chunk) {
+    int chunks = (int)std::min<long long>(256, (rows + 2047) / 2048);
+    if (chunks < 1) chunks = 1;
+    *rows_per_chunk = (int)((rows + chunks - 1) / chunks);
+    return (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
+}
+}  // namespace
+
+extern "C" long long vpho_bn_workspace_bytes(int C) { return C > 0 ? (long long)256 * 2 * C * 8 : -1; }
+
+extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
+                                         float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* y,
+                                         void* workspace, void* stream) {
+    VPHO_REQUIRE(x && gamma && beta && save_mean && save_invstd && y && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_forward_f32: bad argument");
+    VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_f32: running_mean/var must come together");
+    hipStream_t s = (hipStream_t)stream;
+    int rpc;
+    const int chunks = bn_chunks(rows, &rpc);
+    BnRedArgs a{x, nullptr, nullptr, nullptr, rows, C, ld, 0, rpc, (double*)workspace};
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 31) / 32, chunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
+                       running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
+    return vpho::check_launch("bn_train_forward kernels");
+}
+
+extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
+                                          const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_backward_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rpc;
+    const int chunks = bn_chunks(rows, &rpc);
+    BnRedArgs a{x, dy, save_mean, save_invstd, rows, C, ld, 1, rpc, (double*)workspace};
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 31) / 32, chunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_backward_kernel, dim3(nblk(rows * C)), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
+    return vpho::check_launch("bn_train_backward kernels");
+}
+
+extern "C" int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream) {
+    VPHO_REQUIRE(dy && y && dx && n > 0, "vpho_lrelu_bwd_f32: bad argument");
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope, dx);
+    return vpho::check_launch("lrelu_bwd_kernel");
 }

@@ -18,6 +18,7 @@ lib = C.CDLL(LIB_PATH)
 lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
 lib.vpho_obj_metrics_workspace_bytes.restype = C.c_longlong
+lib.vpho_bn_workspace_bytes.restype = C.c_longlong
 
 
 class VphoError(RuntimeError):
@@ -679,6 +680,33 @@ def im2col_t(x, kh, kw, stride, pad_y, pad_x, OH, OW, cin=None):
     out = _new((kh * kw * cin, ldo), x)
     _call('vpho_im2col_t_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), I(kh), I(kw), I(stride), I(pad_y), I(pad_x), I(OH), I(OW), _f32(out), LL(ldo))
     return out
+
+
+def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0):
+    """x (..., C) NHWC -> y, (save_mean, save_invstd); running stats updated in place (nn.BatchNorm2d.train())"""
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y, mean, invstd = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
+    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
+    _call('vpho_bn_train_forward_f32', _f32(x), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(beta), F(eps), F(momentum), F(slope),
+          _f32(running_mean), _f32(running_var), _f32(mean), _f32(invstd), _f32(y), _ptr(ws))
+    return y, (mean, invstd)
+
+
+def bn_train_backward(x, dy, gamma, saved):
+    """-> dx, dgamma, dbeta"""
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx, dg, db = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
+    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
+    _call('vpho_bn_train_backward_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]), _f32(dx), _f32(dg), _f32(db), _ptr(ws))
+    return dx, dg, db
+
+
+def lrelu_bwd(dy, y, slope):
+    dx = torch.empty_like(dy)
+    _call('vpho_lrelu_bwd_f32', _f32(dy), _f32(y), LL(dy.numel()), F(slope), _f32(dx))
+    return dx
 
 
 def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
