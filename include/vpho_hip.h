@@ -328,6 +328,8 @@ int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, 
                                const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
 int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
+/* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */
+int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient
  * first (1 / world_size after a sum all-reduce) */
 int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,

@@ -64,3 +64,43 @@ def test_batchnorm_training_mode_matches_autograd(N, H, W, C, slope):
     np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy(), atol=tol(x.grad), rtol=1e-4)
     np.testing.assert_allclose(dgam.cpu().numpy(), gamma.grad.numpy(), atol=tol(gamma.grad), rtol=1e-4)
     np.testing.assert_allclose(dbet.cpu().numpy(), beta.grad.numpy(), atol=tol(beta.grad), rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag,stride', [('id', 1), ('down', 2)])
+def test_bottleneck_training_step_matches_reference_module(tag, stride):
+    """Training-mode forward + backward of a whole Bottleneck (conv/BN(train)/LeakyReLU x3, shortcut, residual) vs the
+    reference's own module under autograd (fixture by tests/golden/make_golden_bottleneck.py)."""
+    import os
+    from vpho_amd.model.pack import pack_conv
+    from vpho_amd.train_blocks import BottleneckTrain
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_bottleneck.npz'))
+    t = lambda k: torch.from_numpy(G[f'{tag}_{k}'])
+    bn = lambda n: dict(gamma=t(f'init_{n}.weight').cuda(), beta=t(f'init_{n}.bias').cuda(),
+                        running_mean=t(f'init_{n}.running_mean').cuda(), running_var=t(f'init_{n}.running_var').cuda())
+    params = dict(conv1=pack_conv(t('init_conv1.weight')).cuda(), conv2=pack_conv(t('init_conv2.weight')).cuda(),
+                  conv3=pack_conv(t('init_conv3.weight')).cuda(), bn1=bn('bn1'), bn2=bn('bn2'), bn3=bn('bn3'))
+    names = {'conv1': 'conv1.weight', 'conv2': 'conv2.weight', 'conv3': 'conv3.weight'}
+    bns = {'bn1': 'bn1', 'bn2': 'bn2', 'bn3': 'bn3'}
+    if tag == 'down':
+        params['down'] = pack_conv(t('init_downsample.0.weight')).cuda()
+        params['bnd'] = bn('downsample.1')
+        names['down'] = 'downsample.0.weight'
+        bns['bnd'] = 'downsample.1'
+    blk = BottleneckTrain(params, stride)
+    nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous().cuda()
+    out = blk.forward(nhwc(t('x')))
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), G[f'{tag}_out'], atol=3e-5, rtol=1e-4)
+    dx, grads = blk.backward(nhwc(t('dout')))
+    tol = lambda ref: 1e-4 * float(np.abs(ref).max()) + 1e-7
+    np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), G[f'{tag}_dx'], atol=tol(G[f'{tag}_dx']), rtol=1e-3)
+    for k, ref_name in names.items():
+        ref = G[f'{tag}_grad_{ref_name}']
+        cout, cin, kh, kw = ref.shape
+        got = grads[k].cpu().view(cout, kh, kw, cin).permute(0, 3, 1, 2).numpy()
+        np.testing.assert_allclose(got, ref, atol=tol(ref), rtol=1e-3, err_msg=k)
+    for k, ref_name in bns.items():
+        for ours, theirs in (('gamma', 'weight'), ('beta', 'bias')):
+            ref = G[f'{tag}_grad_{ref_name}.{theirs}']
+            np.testing.assert_allclose(grads[f'{k}.{ours}'].cpu().numpy(), ref, atol=tol(ref), rtol=1e-3, err_msg=f'{k}.{ours}')
+        for stat in ('running_mean', 'running_var'):
+            np.testing.assert_allclose(params[k][stat].cpu().numpy(), G[f'{tag}_after_{ref_name}.{stat}'], atol=2e-6, rtol=2e-5, err_msg=f'{k}.{stat}')

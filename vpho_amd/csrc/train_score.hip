@@ -300,6 +300,14 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __re
     dx[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
 }
 
+// y = lrelu(a + b, slope)  (residual add of a bottleneck; slope 1 = plain sum, e.g. of two input gradients)
+__global__ void add_lrelu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float slope, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = a[i] + b[i];
+    y[i] = v > 0.f ? v : v * slope;
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -436,4 +444,10 @@ extern "C" int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, 
     VPHO_REQUIRE(dy && y && dx && n > 0, "vpho_lrelu_bwd_f32: bad argument");
     hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope, dx);
     return vpho::check_launch("lrelu_bwd_kernel");
+}
+
+extern "C" int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream) {
+    VPHO_REQUIRE(a && b && y && n > 0, "vpho_add_lrelu_f32: bad argument");
+    hipLaunchKernelGGL(add_lrelu_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
+    return vpho::check_launch("add_lrelu_kernel");
 }

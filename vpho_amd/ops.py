@@ -709,6 +709,12 @@ def lrelu_bwd(dy, y, slope):
     return dx
 
 
+def add_lrelu(a, b, slope=1.0):
+    y = torch.empty_like(a)
+    _call('vpho_add_lrelu_f32', _f32(a), _f32(b), LL(a.numel()), F(slope), _f32(y))
+    return y
+
+
 def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
     """in-place torch.optim.AdamW step on one tensor"""
     _call('vpho_adamw_f32', _f32(param), _f32(grad), _f32(m), _f32(v), LL(param.numel()), F(lr), F(beta1), F(beta2), F(eps), F(weight_decay),
