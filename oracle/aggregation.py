@@ -246,17 +246,17 @@ def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, ro
     fpnt, fglob = local_to_global(anchor, anchor_skeleton, force_local, h['agg_vert'] + root_joint_flip[:, None])
 
     common = dict(root=root_joint, names=obj_name, is_right=is_right)
-    t_idx, t_w, _ = obj_heat_topk(ycb, obj_pose6d, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=obj_topk, **common)
+    t_idx, t_w, t_hv = obj_heat_topk(ycb, obj_pose6d, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=obj_topk, **common)
     transl = fuse_topk(obj_pose6d, t_idx, t_w)[:, 6:]
     upd = obj_pose6d.clone()
     upd[..., 6:] = transl[:, None]
-    r_idx, _, _ = obj_heat_topk(ycb, upd, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=obj_topk, **common)
+    r_idx, _, r_hv = obj_heat_topk(ycb, upd, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=obj_topk, **common)
     g = lambda idx: torch.gather(obj_pose6d, 1, idx[:, :, None].expand(bs, obj_topk, 9))
     ct = g(t_idx)[:, :, None, 6:].expand(bs, obj_topk, obj_topk, 3)
     cr = g(r_idx)[:, None, :, :6].expand(bs, obj_topk, obj_topk, 6)
     cand = torch.cat([cr, ct], -1).reshape(bs, -1, 9)
     p_idx, p_w, p_score = obj_physics_topk(ycb, cand, force_point=fpnt, force_global=fglob, k=phy_topk, **common)
-    m_idx, m_w, _ = obj_heat_topk(ycb, cand, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=phy_topk, **common)
+    m_idx, m_w, m_hv = obj_heat_topk(ycb, cand, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=phy_topk, **common)
     new_idx = torch.where(is_grasped[:, None], p_idx, m_idx)
     new_w = torch.where(is_grasped[:, None], p_w, m_w)
     obj_fused = fuse_topk(cand, new_idx, new_w)
@@ -275,4 +275,4 @@ def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, ro
     return dict(obj_agg_6d=obj_fused, pose6d_candidate=cand, agg_obj_vert=obj_vert,
                 hand_agg_mano=hp['agg_pose'], hand_agg_vert=hp['agg_vert'], hand_agg_joint=hp['agg_joint'],
                 dbg=dict(hand=h, transl_topk=t_idx, rot_topk=r_idx, phys_topk=p_idx, heat_topk=m_idx,
-                         phys_score=p_score, hand_phys=hp, cascade_mano=agg_mano, force_point=fpnt, force_global=fglob))
+                         phys_score=p_score, transl_score=t_hv, rot_score=r_hv, heat_score=m_hv, hand_phys=hp, cascade_mano=agg_mano, force_point=fpnt, force_global=fglob))

@@ -237,3 +237,30 @@ def test_readme_config_parity_with_the_oracle_up_to_score_ties(model_cpu, sd, as
     clean = swaps == 0
     if clean.any():
         assert float(dj[clean].max()) < 1e-5
+
+
+def test_hip_path_matches_reference_at_readme_sizes(model_cpu, assets):
+    """Whole forward at sample_num=100, sampling_steps=50, topk 30/10 (2 images, T0=0.2 -- see make_golden_readme.py) against
+    the REFERENCE's own run: continuous outputs 2e-4, every selection stage rank by rank, aggregated poses on tie-free images."""
+    import copy
+    from tests._readme_fixture import R, CFG, compare
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.synth import synth_batch
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = (CFG[k] for k in ('sample_num', 'sampling_steps', 'topk_hand', 'topk_obj', 'sample_T0'))
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(2, assets, seed=4242).items()}
+        m(data, mode='predict')
+        out = m._engine.predict(data, noise_hand=torch.from_numpy(R['noise_hand']), noise_obj=torch.from_numpy(R['noise_obj']))
+        torch.cuda.synchronize()
+        d = m._engine.last_info['agg']
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+    c = lambda t: t.detach().cpu()
+    hand = [c(d['hand_topk'][0])] + [c(d['hand_topk'][l]).reshape(2, 5, -1).transpose(1, 2) for l in (1, 2, 3)]
+    dirty = compare({k: c(v) for k, v in out.items() if torch.is_tensor(v)}, hand,
+            dict(transl=c(d['transl_topk']), rot=c(d['rot_topk']), final=c(d['heat_topk']), phys=c(d['phys_topk'])), upstream_tol=2e-4,
+            obj_scores=dict(transl=c(d['transl_score']), rot=c(d['rot_score']), final=c(d['heat_score']), phys=c(d['phys_score'])),
+            hand_val=[c(d['hand_val'][0])] + [c(d['hand_val'][l]).reshape(2, 5, -1).transpose(1, 2) for l in (1, 2, 3)])
+    assert dirty <= 1                                        # at least one of the two images is compared end to end

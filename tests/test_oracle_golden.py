@@ -211,3 +211,14 @@ def test_dsm_training_step_matches_reference(sd, name, D):
         new, _, _ = T.adamw_step(w, grads[s], torch.zeros_like(w), torch.zeros_like(w), step=1)
         np.testing.assert_allclose(new.reshape(-1)[::9973].numpy(), g[f'{name}_psample_{s}'], rtol=2e-6, atol=1e-9, err_msg=s)
         np.testing.assert_allclose(float((new - w).double().norm()), float(g[f'{name}_dnorm_{s}']), rtol=1e-4, err_msg=s)
+
+
+def test_oracle_matches_reference_at_readme_sizes(sd, assets):
+    """Whole forward at sample_num=100, sampling_steps=50, topk 30/10, T0=0.65 (2 images): the oracle vs the reference's own
+    run (tests/golden/make_golden_readme.py), same prior draws."""
+    from tests._readme_fixture import R, CFG, compare
+    data = synth_batch(2, assets, seed=4242)
+    out, info = OV.predict(sd, assets, ANCHOR_SKELETON, data, noise_hand=torch.from_numpy(R['noise_hand']), noise_obj=torch.from_numpy(R['noise_obj']), **CFG)
+    d = info['agg']
+    compare(out, d['hand']['topk'], dict(transl=d['transl_topk'], rot=d['rot_topk'], final=d['heat_topk'], phys=d['phys_topk']), upstream_tol=1e-4,
+            obj_scores=dict(transl=d['transl_score'], rot=d['rot_score'], final=d['heat_score'], phys=d['phys_score']))

@@ -309,7 +309,7 @@ class Engine:
         _, fidx = A.topk(fs, PHY_TOPK, 5)
         out58 = A.hand_phys_fuse(cand58, fidx)
         out_vert, out_joint = M.fk(out58, ctx, 1, True)
-        dbg.update(transl_topk=ti, rot_topk=ri, phys_topk=pi, heat_topk=hi, phys_score=ps, hand_phys_topk=fidx, hand_phys_score=fs, cand58=cand58, cand_vert=cverts, cand_force_point=fp2, cand_force_global=fg2,
+        dbg.update(transl_topk=ti, rot_topk=ri, phys_topk=pi, heat_topk=hi, phys_score=ps, transl_score=sc, rot_score=sc2, heat_score=hs, hand_phys_topk=fidx, hand_phys_score=fs, cand58=cand58, cand_vert=cverts, cand_force_point=fp2, cand_force_global=fg2,
                    cascade_pose=fused_rows[:, :48], force_point=fpnt, force_global=fglob, obj_vert=obj_vert, pose6d_candidate=cand)
         return dict(obj_agg_6d=obj_fused, hand_agg_mano=out58, hand_agg_vert=out_vert, hand_agg_joint=out_joint), dbg
 
