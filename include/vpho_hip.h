@@ -328,6 +328,12 @@ int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, 
                                const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
 int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
+/* nn.MaxPool2d backward (backbone_FPN_HFL.py:209): dx[n,iy,ix,c] = sum of dy over the windows whose first maximum (row-major)
+ * is (iy,ix); x is the pooling input.  Deterministic gather, no atomics. */
+int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) backward (FPN._upsample_add, backbone_FPN_HFL.py:66-68):
+ * dy [N][OH][OW][C] -> dx [N][H][W][C] */
+int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);
 /* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */
 int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient

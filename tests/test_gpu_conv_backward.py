@@ -104,3 +104,28 @@ def test_bottleneck_training_step_matches_reference_module(tag, stride):
             np.testing.assert_allclose(grads[f'{k}.{ours}'].cpu().numpy(), ref, atol=tol(ref), rtol=1e-3, err_msg=f'{k}.{ours}')
         for stat in ('running_mean', 'running_var'):
             np.testing.assert_allclose(params[k][stat].cpu().numpy(), G[f'{tag}_after_{ref_name}.{stat}'], atol=2e-6, rtol=2e-5, err_msg=f'{k}.{stat}')
+
+
+@pytest.mark.parametrize('N,H,W,C,k,stride,pad', [(2, 16, 16, 8, 3, 2, 1), (1, 9, 11, 4, 3, 2, 1), (2, 8, 8, 16, 2, 2, 0)])
+def test_maxpool_backward_matches_autograd(N, H, W, C, k, stride, pad):
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(x, k, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    dx = ops.maxpool_bwd(nhwc(x), nhwc(dy), k, stride, pad).permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(dx.numpy(), x.grad.numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize('N,H,W,C,OH,OW', [(2, 8, 8, 16, 16, 16), (1, 4, 6, 8, 8, 12), (2, 16, 16, 4, 8, 8), (1, 5, 7, 4, 13, 9)])
+def test_bilinear_resize_backward_matches_autograd(N, H, W, C, OH, OW):
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(H * OW)
+    x = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
+    y = torch.nn.functional.interpolate(x, size=(OH, OW), mode='bilinear', align_corners=False)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dx = ops.resize_bilinear_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), H, W).permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(dx.numpy(), x.grad.numpy(), atol=2e-6 * float(x.grad.abs().max()) + 1e-7, rtol=1e-5)

@@ -308,6 +308,80 @@ __global__ void add_lrelu_kernel(const float* __restrict__ a, const float* __res
     y[i] = v > 0.f ? v : v * slope;
 }
 
+// ------------------------------------------------------------------------------------------------ pooling / resize backward
+// nn.MaxPool2d backward as a gather (deterministic): input pixel (iy, ix) receives dy of every window whose arg-max it is --
+// the first maximum in row-major window order, as torch's CPU/GPU kernels pick it.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int H, int W, int C, int k, int stride, int pad,
+                                   int OH, int OW, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const long long n = p / H;
+    const float* xb = x + n * H * W * (long long)C + c;
+    float g = 0.f;
+    // windows covering iy: oy*stride - pad <= iy <= oy*stride - pad + k - 1
+    const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
+    const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            float m = -INFINITY;
+            int ay = -1, ax = -1;
+            for (int r = 0; r < k; ++r) {
+                const int yy = oy * stride - pad + r;
+                if (yy < 0 || yy >= H) continue;
+                for (int q = 0; q < k; ++q) {
+                    const int xx = ox * stride - pad + q;
+                    if (xx < 0 || xx >= W) continue;
+                    const float v = xb[((long long)yy * W + xx) * C];
+                    if (v > m || ay < 0) { m = v; ay = yy; ax = xx; }
+                }
+            }
+            if (ay == iy && ax == ix) g += dy[((n * OH + oy) * OW + ox) * (long long)C + c];
+        }
+    dx[i] = g;
+}
+
+__device__ inline void lin_src_t(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = ((float)dst + 0.5f) * scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+// F.interpolate(mode='bilinear', align_corners=False) backward as a gather: dx[iy, ix] = sum over the outputs whose two source
+// rows / columns include (iy, ix) of their weights * dy, outputs visited in ascending order (deterministic)
+__global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, int N, int OH, int OW, int C, int H, int W, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const long long n = p / H;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    // outputs whose source position lies in (iy - 1, iy + 1): a conservative index range, exact weights recomputed inside
+    const int oy_lo = max(0, (int)floorf(((float)iy - 1.f + 0.5f) / sy - 0.5f) - 1), oy_hi = min(OH - 1, (int)ceilf(((float)iy + 1.f + 0.5f) / sy - 0.5f) + 1);
+    const int ox_lo = max(0, (int)floorf(((float)ix - 1.f + 0.5f) / sx - 0.5f) - 1), ox_hi = min(OW - 1, (int)ceilf(((float)ix + 1.f + 0.5f) / sx - 0.5f) + 1);
+    float g = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1; float ly;
+        lin_src_t(oy, sy, H, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            int x0, x1; float lx;
+            lin_src_t(ox, sx, W, x0, x1, lx);
+            const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            if (wx == 0.f) continue;
+            g += wy * wx * dy[((n * OH + oy) * OW + ox) * (long long)C + c];
+        }
+    }
+    dx[i] = g;
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -450,4 +524,17 @@ extern "C" int vpho_add_lrelu_f32(const float* a, const float* b, long long n, f
     VPHO_REQUIRE(a && b && y && n > 0, "vpho_add_lrelu_f32: bad argument");
     hipLaunchKernelGGL(add_lrelu_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
     return vpho::check_launch("add_lrelu_kernel");
+}
+
+extern "C" int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream) {
+    VPHO_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, "vpho_maxpool_bwd_nhwc_f32: bad argument");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H, W, C, k, stride, pad, OH, OW, dx);
+    return vpho::check_launch("maxpool_bwd_kernel");
+}
+
+extern "C" int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream) {
+    VPHO_REQUIRE(dy && dx && N > 0 && OH > 0 && OW > 0 && C > 0 && H > 0 && W > 0, "vpho_resize_bilinear_bwd_nhwc_f32: bad argument");
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, N, OH, OW, C, H, W, dx);
+    return vpho::check_launch("resize_bilinear_bwd_kernel");
 }

@@ -709,6 +709,20 @@ def lrelu_bwd(dy, y, slope):
     return dx
 
 
+def maxpool_bwd(x, dy, k, stride, pad):
+    N, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    _call('vpho_maxpool_bwd_nhwc_f32', _f32(x), _f32(dy), I(N), I(H), I(W), I(Cc), I(k), I(stride), I(pad), _f32(dx))
+    return dx
+
+
+def resize_bilinear_bwd(dy, H, W):
+    N, OH, OW, Cc = dy.shape
+    dx = _new((N, H, W, Cc), dy)
+    _call('vpho_resize_bilinear_bwd_nhwc_f32', _f32(dy), I(N), I(OH), I(OW), I(Cc), I(H), I(W), _f32(dx))
+    return dx
+
+
 def add_lrelu(a, b, slope=1.0):
     y = torch.empty_like(a)
     _call('vpho_add_lrelu_f32', _f32(a), _f32(b), LL(a.numel()), F(slope), _f32(y))
