@@ -129,3 +129,37 @@ def test_bilinear_resize_backward_matches_autograd(N, H, W, C, OH, OW):
     y.backward(dy)
     dx = ops.resize_bilinear_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), H, W).permute(0, 3, 1, 2).cpu()
     np.testing.assert_allclose(dx.numpy(), x.grad.numpy(), atol=2e-6 * float(x.grad.abs().max()) + 1e-7, rtol=1e-5)
+
+
+def test_backbone_training_step_matches_reference_fpn(sd):
+    """Training-mode forward + backward of the whole two-branch ResNet-50 / FPN backbone vs the reference's own FPN module under
+    autograd (fixture by tests/golden/make_golden_fpn_train.py): outputs, all 275 parameter gradients (norm + strided sample),
+    running statistics (incl. the shared layer4, updated by both branch calls)."""
+    import os
+    from vpho_amd.train_blocks import FPNTrain
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_fpn_train.npz'))
+    net = FPNTrain(sd, 'feature_extractor', 'cuda')
+    ph, po = net.forward(torch.from_numpy(G['x']).cuda())
+    for got, key in ((ph, 'p2_h'), (po, 'p2_o')):
+        ref = G[key]
+        np.testing.assert_allclose(got.permute(0, 3, 1, 2)[:, ::8].cpu().numpy(), ref, atol=2e-4 * float(np.abs(ref).max()), rtol=1e-3)
+    nhwc = lambda a: torch.from_numpy(a).permute(0, 2, 3, 1).contiguous().cuda()
+    grads = net.backward(nhwc(G['A']), nhwc(G['B']))
+    names = [k[len('gnorm_'):] for k in G.files if k.startswith('gnorm_')]
+    assert set(names) == set(grads), (sorted(set(names) ^ set(grads))[:10])
+    worst = 0.0
+    for k in names:
+        g = grads[k].reshape(-1).cpu()
+        nrm = float(G['gnorm_' + k])
+        assert abs(float(g.double().norm()) - nrm) <= 2e-3 * nrm + 1e-9, (k, float(g.double().norm()), nrm)
+        err = float(np.abs(g[::997].numpy() - G['gsample_' + k]).max()) / (nrm / max(1.0, g.numel() ** 0.5) + 1e-30)
+        worst = max(worst, err)
+        assert err < 0.05, (k, err)                       # sampled entries within 5 % of the RMS entry (deep net, fp32 both sides)
+    for k in ('layer0_h.1', 'layer4_h.0.2.bn3', 'layer2_o.0.0.downsample.1'):
+        pass
+    st = {'layer0_h.1': net.stem['bn']}
+    st['layer4_h.0.2.bn3'] = net.blocks['layer4_h'][2][1]['bn3']
+    st['layer2_o.0.0.downsample.1'] = net.blocks['layer2_o'][0][1]['bnd']
+    for k, b in st.items():
+        np.testing.assert_allclose(b['running_mean'].cpu().numpy(), G['rm_' + k], atol=1e-5, rtol=1e-4, err_msg=k)
+        np.testing.assert_allclose(b['running_var'].cpu().numpy(), G['rv_' + k], atol=1e-5, rtol=1e-4, err_msg=k)

@@ -58,3 +58,142 @@ class BottleneckTrain:
         else:
             dx = ops.add_lrelu(dx, dsum)
         return dx, g
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def _bn_params(sd, key, dev):
+    g = lambda s: sd[f'{key}.{s}'].detach().float().to(dev).contiguous().clone()
+    return dict(gamma=g('weight'), beta=g('bias'), running_mean=g('running_mean'), running_var=g('running_var'))
+
+
+def _unpack_grad(gp, cout, cin, kh, kw):
+    """packed (Cout, kh*kw*cin_pad) gradient -> the reference's (Cout, Cin, kh, kw)"""
+    return gp.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2).contiguous()
+
+
+class FPNTrain:
+    """Training-mode forward + backward of the two-branch ResNet-50 / FPN backbone (``FPN.forward``,
+    lib/model/backbone_FPN_HFL.py:70-109, under ``model.train()``): shared stem and layer1, hand / object layers 2-3, the SHARED
+    layer4 applied to both branches in two separate calls (each with its own batch statistics, quirk Q6), top-down path with
+    lateral 1x1 convolutions and bilinear up-sample-add, 3x3 smoothing.  ``backward`` returns the gradient of every parameter
+    under the reference's state_dict names and layouts."""
+    LAYERS = (('layer1_h', 3, 64, 1), ('layer2_h', 4, 128, 2), ('layer2_o', 4, 128, 2), ('layer3_h', 6, 256, 2), ('layer3_o', 6, 256, 2),
+              ('layer4_h', 3, 512, 2))
+
+    def __init__(self, sd, prefix, device):
+        from .model.pack import pack_conv
+        self.dev = dev = device
+        self.pfx = prefix
+        w = lambda k: sd[f'{prefix}.{k}'].detach().float()
+        self.shapes = {}
+
+        def conv(key, cin_pad=None):
+            t = w(key + '.weight')
+            self.shapes[key + '.weight'] = tuple(t.shape)
+            return pack_conv(t, cin_pad).to(dev)
+
+        self.stem = dict(conv=conv('layer0_h.0', 4), bn=_bn_params(sd, f'{prefix}.layer0_h.1', dev))
+        self.blocks = {}
+        for name, n, planes, stride in self.LAYERS:
+            blks = []
+            for i in range(n):
+                k = f'{name}.0.{i}'
+                p = dict(conv1=conv(k + '.conv1'), conv2=conv(k + '.conv2'), conv3=conv(k + '.conv3'),
+                         bn1=_bn_params(sd, f'{prefix}.{k}.bn1', dev), bn2=_bn_params(sd, f'{prefix}.{k}.bn2', dev), bn3=_bn_params(sd, f'{prefix}.{k}.bn3', dev))
+                if f'{prefix}.{k}.downsample.0.weight' in sd:
+                    p['down'] = conv(k + '.downsample.0')
+                    p['bnd'] = _bn_params(sd, f'{prefix}.{k}.downsample.1', dev)
+                blks.append((k, p, stride if i == 0 else 1))
+            self.blocks[name] = blks
+        self.heads = {}
+        for k in ('toplayer', 'latlayer1', 'latlayer2', 'latlayer3', 'smooth3'):
+            for br in 'ho':
+                self.heads[f'{k}_{br}'] = (conv(f'{k}_{br}'), w(f'{k}_{br}.bias').to(dev).contiguous())
+
+    # -------------------------------------------------------------------------------------------------- forward
+    def _run_layer(self, name, x, tag):
+        seq = []
+        for k, p, stride in self.blocks[name]:
+            b = BottleneckTrain(p, stride)
+            x = b.forward(x)
+            seq.append((k, b))
+        self.calls[(name, tag)] = seq
+        return x
+
+    def forward(self, rgb_nchw):
+        """rgb (N,3,H,W) -> p2_h, p2_o (N,H/4,W/4,256) NHWC"""
+        self.calls = {}
+        x = ops.nchw_to_nhwc(rgb_nchw.float().contiguous(), 4)
+        c0 = ops.conv2d_nhwc(x, self.stem['conv'], kh=7, kw=7, stride=2, pad=3)
+        b = self.stem['bn']
+        a0, s0 = ops.bn_train_forward(c0, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=SLOPE)
+        c1 = ops.maxpool_nhwc(a0, 3, 2, 1)
+        c2 = self._run_layer('layer1_h', c1, 'h')
+        c3h, c3o = self._run_layer('layer2_h', c2, 'h'), self._run_layer('layer2_o', c2, 'o')
+        c4h, c4o = self._run_layer('layer3_h', c3h, 'h'), self._run_layer('layer3_o', c3o, 'o')
+        c5h = self._run_layer('layer4_h', c4h, 'h')
+        c5o = self._run_layer('layer4_h', c4o, 'o')
+        feats = dict(h=(c5h, c4h, c3h, c2), o=(c5o, c4o, c3o, c2))
+        out, self.td = {}, {}
+        for br in 'ho':
+            c5, c4, c3, c2_ = feats[br]
+            p = ops.conv2d_nhwc(c5, *self.heads[f'toplayer_{br}'])
+            for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2_)):
+                q = ops.conv2d_nhwc(c, *self.heads[lat])
+                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
+            self.td[br] = p                                               # p2 before smoothing
+            out[br] = ops.conv2d_nhwc(p, *self.heads[f'smooth3_{br}'], kh=3, kw=3, pad=1)
+        self.saved = dict(x=x, c0=c0, a0=a0, s0=s0, c1=c1, feats=feats)
+        return out['h'], out['o']
+
+    # -------------------------------------------------------------------------------------------------- backward
+    def _back_layer(self, name, tag, dy, grads):
+        for k, b in reversed(self.calls[(name, tag)]):
+            dy, g = b.backward(dy)
+            for gk, gv in g.items():
+                if gk in ('conv1', 'conv2', 'conv3', 'down'):
+                    key = f'{k}.{"downsample.0" if gk == "down" else gk}.weight'
+                    val = _unpack_grad(gv, *self.shapes[key])
+                else:
+                    bn, which = gk.split('.')
+                    key = f'{k}.{"downsample.1" if bn == "bnd" else bn}.{"weight" if which == "gamma" else "bias"}'
+                    val = gv
+                grads[key] = grads[key] + val if key in grads else val    # layer4 is called twice: its gradients add up
+        return dy
+
+    def backward(self, dp2_h, dp2_o):
+        S, grads = self.saved, {}
+        add = lambda a, b_: b_ if a is None else ops.add_lrelu(a, b_)
+        dfe = dict(h=[None] * 3, o=[None] * 3)                            # gradients reaching c5, c4, c3 of each branch
+        dc2 = None
+        for br, dp in (('h', dp2_h), ('o', dp2_o)):
+            c5, c4, c3, c2 = S['feats'][br]
+            wS = self.heads[f'smooth3_{br}'][0]
+            grads[f'smooth3_{br}.weight'] = _unpack_grad(CB.conv2d_wgrad(self.td[br], dp, 3, 3, 1, 1), *self.shapes[f'smooth3_{br}.weight'])
+            grads[f'smooth3_{br}.bias'] = CB.conv2d_bias_grad(dp)
+            d = CB.conv2d_dgrad(dp, wS, self.td[br].shape[1:3], 3, 3, 1, 1)                 # d p2 (pre-smoothing)
+            for lat, c, slot in ((f'latlayer3_{br}', c2, None), (f'latlayer2_{br}', c3, 2), (f'latlayer1_{br}', c4, 1)):
+                wl = self.heads[lat][0]
+                grads[lat + '.weight'] = _unpack_grad(CB.conv2d_wgrad(c, d, 1, 1), *self.shapes[lat + '.weight'])
+                grads[lat + '.bias'] = CB.conv2d_bias_grad(d)
+                dc = CB.conv2d_dgrad(d, wl, c.shape[1:3], 1, 1)
+                if slot is None:
+                    dc2 = add(dc2, dc)
+                else:
+                    dfe[br][slot] = add(dfe[br][slot], dc)
+                nxt = {f'latlayer3_{br}': c3, f'latlayer2_{br}': c4, f'latlayer1_{br}': c5}[lat]
+                d = ops.resize_bilinear_bwd(d, nxt.shape[1], nxt.shape[2])                  # gradient of the up-sampled coarser map
+            wt = self.heads[f'toplayer_{br}'][0]
+            grads[f'toplayer_{br}.weight'] = _unpack_grad(CB.conv2d_wgrad(c5, d, 1, 1), *self.shapes[f'toplayer_{br}.weight'])
+            grads[f'toplayer_{br}.bias'] = CB.conv2d_bias_grad(d)
+            dfe[br][0] = add(dfe[br][0], CB.conv2d_dgrad(d, wt, c5.shape[1:3], 1, 1))
+        # bottom-up path in reverse
+        for br in 'ho':
+            d4 = add(dfe[br][1], self._back_layer('layer4_h', br, dfe[br][0], grads))
+            d3 = add(dfe[br][2], self._back_layer(f'layer3_{br}', br, d4, grads))
+            dc2 = add(dc2, self._back_layer(f'layer2_{br}', br, d3, grads))
+        dc1 = self._back_layer('layer1_h', 'h', dc2, grads)
+        da0 = ops.lrelu_bwd(ops.maxpool_bwd(S['a0'], dc1, 3, 2, 1), S['a0'], SLOPE)
+        dc0, grads['layer0_h.1.weight'], grads['layer0_h.1.bias'] = ops.bn_train_backward(S['c0'], da0, self.stem['bn']['gamma'], S['s0'])
+        grads['layer0_h.0.weight'] = _unpack_grad(CB.conv2d_wgrad(S['x'], dc0, 7, 7, 2, 3), *self.shapes['layer0_h.0.weight'])
+        return grads
