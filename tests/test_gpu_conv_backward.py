@@ -163,3 +163,44 @@ def test_backbone_training_step_matches_reference_fpn(sd):
     for k, b in st.items():
         np.testing.assert_allclose(b['running_mean'].cpu().numpy(), G['rm_' + k], atol=1e-5, rtol=1e-4, err_msg=k)
         np.testing.assert_allclose(b['running_var'].cpu().numpy(), G['rv_' + k], atol=1e-5, rtol=1e-4, err_msg=k)
+
+
+def test_encoder_training_step_matches_reference_module(sd):
+    """Training-mode forward + backward of the residual Encoder (8 pre-activation bottlenecks, 4 max-pools) vs the reference's
+    own module under autograd, with gradients entering at the encoding and at the second stage map (the cross modules' input)."""
+    import os
+    from vpho_amd.train_blocks import EncoderTrain
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_encoder_train.npz'))
+    net = EncoderTrain(sd, 'encoder_hand', 'cuda')
+    g = np.random.default_rng(21)
+    NB = 12
+    x = torch.from_numpy((g.normal(size=(NB, net.cin, 32, 32)) * 0.3).astype(np.float32))
+    xin = torch.zeros(NB, 32, 32, net.cin_pad)
+    xin[..., :net.cin] = x.permute(0, 2, 3, 1)
+    enc, stages = net.forward(xin.cuda())
+    A = torch.from_numpy(g.normal(size=tuple(enc.shape)).astype(np.float32))
+    B = torch.from_numpy(g.normal(size=(NB, stages[1].shape[3], stages[1].shape[1], stages[1].shape[2])).astype(np.float32))
+    np.testing.assert_allclose(enc.cpu().numpy(), G['enc'], atol=3e-4 * float(np.abs(G['enc']).max()), rtol=1e-3)
+    np.testing.assert_allclose(stages[1].permute(0, 3, 1, 2).reshape(-1)[::499].cpu().numpy(), G['stage1_sample'], atol=3e-4 * float(np.abs(G['stage1_sample']).max()), rtol=1e-3)
+    dx, grads = net.backward(A.cuda(), B.permute(0, 2, 3, 1).contiguous().cuda())
+    dxn = dx[..., :net.cin].permute(0, 3, 1, 2).reshape(-1).cpu()
+    assert abs(float(dxn.double().norm()) - float(G['dx_norm'])) <= 2e-3 * float(G['dx_norm'])
+    # ReLU kinks and pooling arg-maxes are not smooth: where a pre-activation or two pooled values sit within rounding of each
+    # other the two implementations route the gradient differently, so single entries may differ -- the bulk must not
+    rms = float(G['dx_norm']) / dxn.numel() ** 0.5
+    err = np.abs(dxn[::499].numpy() - G['dx_sample'])
+    assert float(np.median(err)) < 1e-3 * rms and float(np.mean(err > 0.05 * rms)) < 0.01, (float(np.median(err)) / rms, float(np.mean(err > 0.05 * rms)))
+    names = [k[len('gnorm_'):] for k in G.files if k.startswith('gnorm_')]
+    assert set(names) == set(grads), sorted(set(names) ^ set(grads))[:10]
+    top = max(float(G['gnorm_' + k]) for k in names)
+    for k in names:
+        gr = grads[k].reshape(-1).cpu()
+        nrm = float(G['gnorm_' + k])
+        if k.endswith(('conv1.bias', 'conv2.bias')):      # a bias in front of a BatchNorm has zero gradient: both sides hold rounding noise
+            assert nrm < 1e-4 * top and float(gr.double().norm()) < 1e-4 * top, k
+            continue
+        assert abs(float(gr.double().norm()) - nrm) <= 3e-3 * nrm + 1e-9, (k, float(gr.double().norm()), nrm)
+        e = np.abs(gr[::499].numpy() - G['gsample_' + k])
+        rms_k = nrm / max(1.0, gr.numel() ** 0.5)
+        assert float(e.max()) < 0.15 * rms_k + 1e-9 and (e.size < 16 or float(np.median(e)) < 0.02 * rms_k + 1e-9), (k, float(e.max()) / rms_k, float(np.median(e)) / rms_k)
+    np.testing.assert_allclose(net.blocks[7][1]['bn2']['running_mean'].cpu().numpy(), G['rm_reg.7.bn2'], atol=1e-5, rtol=1e-4)

@@ -197,3 +197,92 @@ class FPNTrain:
         dc0, grads['layer0_h.1.weight'], grads['layer0_h.1.bias'] = ops.bn_train_backward(S['c0'], da0, self.stem['bn']['gamma'], S['s0'])
         grads['layer0_h.0.weight'] = _unpack_grad(CB.conv2d_wgrad(S['x'], dc0, 7, 7, 2, 3), *self.shapes['layer0_h.0.weight'])
         return grads
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+class EncoderTrain:
+    """Training-mode forward + backward of ``Encoder`` (lib/model/encoding.py:38-73): 1x1 ``project``, 8 pre-activation
+    ``Residual`` bottlenecks (:21-36: BN -> LeakyReLU -> 1x1 -> BN -> LeakyReLU -> 3x3 -> BN -> LeakyReLU -> 1x1, identity
+    shortcut since numIn == numOut), a 2x2 max-pool after every second one.  Gradients under the reference's names."""
+
+    def __init__(self, sd, prefix, device, cin_pad=None):
+        from .model.pack import pack_conv
+        self.dev = dev = device
+        w = lambda k: sd[f'{prefix}.{k}'].detach().float()
+        self.shapes = {}
+
+        def conv(key, pad=None):
+            t = w(key + '.weight')
+            self.shapes[key + '.weight'] = tuple(t.shape)
+            return pack_conv(t, pad).to(dev), w(key + '.bias').to(dev).contiguous()
+
+        cin = w('project.weight').shape[1]
+        self.cin, self.cin_pad = cin, (cin + 3) // 4 * 4 if cin_pad is None else cin_pad
+        self.project = conv('project', self.cin_pad)
+        self.blocks = []
+        i = 0
+        while f'{prefix}.reg.{i}.conv1.weight' in sd:
+            k = f'reg.{i}'
+            self.blocks.append((k, dict(bn=_bn_params(sd, f'{prefix}.{k}.bn', dev), conv1=conv(k + '.conv1'), bn1=_bn_params(sd, f'{prefix}.{k}.bn1', dev),
+                                        conv2=conv(k + '.conv2'), bn2=_bn_params(sd, f'{prefix}.{k}.bn2', dev), conv3=conv(k + '.conv3'))))
+            i += 1
+
+    def forward(self, x):
+        """x (N,32,32,cin_pad) NHWC (channels >= cin zero) -> encoding (N, C*2*2) in the reference's NCHW flatten order, stage maps"""
+        bn = lambda p, t: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=SLOPE)
+        self.saved = dict(x=x, blocks=[], pools=[])
+        h = ops.conv2d_nhwc(x, *self.project)
+        stages = []
+        for i, (k, p) in enumerate(self.blocks):
+            a0, s0 = bn(p['bn'], h)
+            c1 = ops.conv2d_nhwc(a0, *p['conv1'])
+            a1, s1 = bn(p['bn1'], c1)
+            c2 = ops.conv2d_nhwc(a1, *p['conv2'], kh=3, kw=3, pad=1)
+            a2, s2 = bn(p['bn2'], c2)
+            out = ops.conv2d_nhwc(a2, *p['conv3'], res=h)
+            self.saved['blocks'].append(dict(h=h, a0=a0, s0=s0, c1=c1, a1=a1, s1=s1, c2=c2, a2=a2, s2=s2))
+            h = out
+            if i % 2 == 1:
+                self.saved['pools'].append(h)
+                h = ops.maxpool_nhwc(h, 2, 2, 0)
+                stages.append(h)
+        N = h.shape[0]
+        return ops.nhwc_to_nchw(h).view(N, -1), stages
+
+    def backward(self, d_encoding, d_stage1=None):
+        """d_encoding (N, C*2*2) in the flatten order of forward's output; d_stage1: optional gradient reaching the second
+        stage map (enc_*_ls[1], the cross modules' input).  -> d input (N,32,32,cin_pad), grads"""
+        G = {}
+        N = d_encoding.shape[0]
+        C = self.saved['pools'][-1].shape[-1]
+        sp = self.saved['pools'][-1].shape[1] // 2
+        dh = d_encoding.view(N, C, sp, sp).permute(0, 2, 3, 1).contiguous()
+        n_stage = len(self.saved['pools'])
+        for i in reversed(range(len(self.blocks))):
+            k, p = self.blocks[i]
+            S = self.saved['blocks'][i]
+            if i % 2 == 1:
+                stage = i // 2
+                if d_stage1 is not None and stage == 1:
+                    dh = ops.add_lrelu(dh, d_stage1)
+                dh = ops.maxpool_bwd(self.saved['pools'][stage], dh, 2, 2, 0)
+            H, W = S['h'].shape[1:3]
+            # out = conv3(a2) + h
+            G[f'{k}.conv3.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dh, 1, 1), *self.shapes[f'{k}.conv3.weight'])
+            G[f'{k}.conv3.bias'] = CB.conv2d_bias_grad(dh)
+            da2 = ops.lrelu_bwd(CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1), S['a2'], SLOPE)
+            dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'])
+            G[f'{k}.conv2.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a1'], dc2, 3, 3, 1, 1), *self.shapes[f'{k}.conv2.weight'])
+            G[f'{k}.conv2.bias'] = CB.conv2d_bias_grad(dc2)
+            da1 = ops.lrelu_bwd(CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1), S['a1'], SLOPE)
+            dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
+            G[f'{k}.conv1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a0'], dc1, 1, 1), *self.shapes[f'{k}.conv1.weight'])
+            G[f'{k}.conv1.bias'] = CB.conv2d_bias_grad(dc1)
+            da0 = ops.lrelu_bwd(CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1), S['a0'], SLOPE)
+            dmain, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'] = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'])
+            dh = ops.add_lrelu(dmain, dh)                                 # identity shortcut
+        x = self.saved['x']
+        G['project.weight'] = _unpack_grad(CB.conv2d_wgrad(x, dh, 1, 1), *self.shapes['project.weight'])
+        G['project.bias'] = CB.conv2d_bias_grad(dh)
+        dx = CB.conv2d_dgrad(dh, self.project[0], x.shape[1:3], 1, 1)
+        return dx, G
