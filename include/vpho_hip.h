@@ -334,6 +334,10 @@ int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int
 /* F.interpolate(mode='bilinear', align_corners=False) backward (FPN._upsample_add, backbone_FPN_HFL.py:66-68):
  * dy [N][OH][OW][C] -> dx [N][H][W][C] */
 int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);
+/* torchvision.ops.roi_align backward (VPHO.py:125-128 under loss.backward()): dy [N][P][P][ldo] (channel slice c_off..c_off+C, optionally
+ * W-flipped like the forward) scattered into dfeat [N][H][W][C] += ...; dfeat must be zero-initialised (fp32 atomics) */
+int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+                                int out_size, const unsigned char* flip_w, float* dfeat, void* stream);
 /* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */
 int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient

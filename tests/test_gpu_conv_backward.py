@@ -204,3 +204,26 @@ def test_encoder_training_step_matches_reference_module(sd):
         rms_k = nrm / max(1.0, gr.numel() ** 0.5)
         assert float(e.max()) < 0.15 * rms_k + 1e-9 and (e.size < 16 or float(np.median(e)) < 0.02 * rms_k + 1e-9), (k, float(e.max()) / rms_k, float(np.median(e)) / rms_k)
     np.testing.assert_allclose(net.blocks[7][1]['bn2']['running_mean'].cpu().numpy(), G['rm_reg.7.bn2'], atol=1e-5, rtol=1e-4)
+
+
+def test_roi_align_backward_matches_oracle_autograd():
+    """RoIAlign backward (incl. the W-flip of left hands and accumulation of two RoIs into one gradient) vs autograd through the
+    oracle's differentiable restatement of torchvision.ops.roi_align"""
+    from oracle.roi_align import roi_align_fast
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, C, H, W, P = 3, 8, 20, 24, 8
+    feat = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
+    boxes = torch.tensor([[8.0, 6.0, 70.0, 60.0], [0.0, 0.0, 95.9, 79.0], [30.0, 20.0, 34.0, 90.0]])
+    boxes2 = boxes * 0.7 + 3.0
+    rois = lambda b: torch.cat([torch.arange(N, dtype=torch.float32)[:, None], b], 1)
+    flip = torch.tensor([True, False, True])
+    y1 = roi_align_fast(feat, rois(boxes), P, 0.25)
+    y2 = roi_align_fast(feat, rois(boxes2), P, 0.25)
+    y2 = torch.where(flip[:, None, None, None], y2.flip(-1), y2)
+    d1, d2 = torch.randn(y1.shape, generator=g), torch.randn(y2.shape, generator=g)
+    ((y1 * d1).sum() + (y2 * d2).sum()).backward()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    df = ops.roi_align_bwd(nhwc(d1), boxes.cuda(), (H, W), C, 0.25)
+    df = ops.roi_align_bwd(nhwc(d2), boxes2.cuda(), (H, W), C, 0.25, flip_w=flip.to(torch.uint8).cuda(), into=df)
+    np.testing.assert_allclose(df.permute(0, 3, 1, 2).cpu().numpy(), feat.grad.numpy(), atol=2e-5 * float(feat.grad.abs().max()), rtol=1e-4)

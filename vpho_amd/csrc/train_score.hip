@@ -382,6 +382,47 @@ __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, int N, 
     dx[i] = g;
 }
 
+// torchvision roi_align backward (aligned=False, adaptive sampling; one RoI per image): every sample of every bin adds its four
+// bilinear weights * dy / count to the feature gradient.  Bins of one RoI overlap in the taps they touch -> atomicAdd on fp32
+// (the summation order, hence the last bit, is not fixed -- as in torchvision's own GPU kernel).  dfeat must be zeroed.
+__global__ void roi_align_bwd_kernel(const float* __restrict__ dy, int ldo, int c_off, int N, int H, int W, int C, const float* __restrict__ boxes,
+                                     float scale, int P, const unsigned char* __restrict__ flip_w, float* __restrict__ dfeat) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * P * P * C) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int pw = (int)(p % P); p /= P;
+    const int ph = (int)(p % P);
+    const int n = (int)(p / P);
+    const float x1 = boxes[n * 4 + 0] * scale, y1 = boxes[n * 4 + 1] * scale;
+    const float x2 = boxes[n * 4 + 2] * scale, y2 = boxes[n * 4 + 3] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = fmaxf((float)(gh * gw), 1.f);
+    const int ow = (flip_w && flip_w[n]) ? P - 1 - pw : pw;
+    const float g = dy[(((long long)n * P + ph) * P + ow) * ldo + c_off + c] / cnt;
+    float* f = dfeat + (long long)n * H * W * C + c;
+    for (int iy = 0; iy < gh; ++iy) {
+        float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            float yy = y;
+            if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+            if (yy <= 0.f) yy = 0.f;
+            if (x <= 0.f) x = 0.f;
+            int yl = (int)yy, xl = (int)x, yh, xh;
+            if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+            if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+            const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+            atomicAdd(f + ((long long)yl * W + xl) * C, hy * hx * g);
+            atomicAdd(f + ((long long)yl * W + xh) * C, hy * lx * g);
+            atomicAdd(f + ((long long)yh * W + xl) * C, ly * hx * g);
+            atomicAdd(f + ((long long)yh * W + xh) * C, ly * lx * g);
+        }
+    }
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -537,4 +578,12 @@ extern "C" int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH,
     VPHO_REQUIRE(dy && dx && N > 0 && OH > 0 && OW > 0 && C > 0 && H > 0 && W > 0, "vpho_resize_bilinear_bwd_nhwc_f32: bad argument");
     hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, N, OH, OW, C, H, W, dx);
     return vpho::check_launch("resize_bilinear_bwd_kernel");
+}
+
+extern "C" int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+                                           int out_size, const unsigned char* flip_w, float* dfeat, void* stream) {
+    VPHO_REQUIRE(dy && boxes && dfeat && N > 0 && H > 0 && W > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_bwd_nhwc_f32: bad argument");
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(nblk((long long)N * out_size * out_size * C)), dim3(256), 0, (hipStream_t)stream, dy, ldo, c_off, N, H, W, C,
+                       boxes, spatial_scale, out_size, flip_w, dfeat);
+    return vpho::check_launch("roi_align_bwd_kernel");
 }

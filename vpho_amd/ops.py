@@ -723,6 +723,15 @@ def resize_bilinear_bwd(dy, H, W):
     return dx
 
 
+def roi_align_bwd(dy, boxes, feat_hw, C, scale, flip_w=None, c_off=0, into=None):
+    """dy (N,P,P,ld) -> feature gradient (N,H,W,C); `into` accumulates into an existing gradient tensor"""
+    N, P, _, ld = dy.shape
+    H, W = feat_hw
+    df = torch.zeros((N, H, W, C), device=dy.device, dtype=dy.dtype) if into is None else into
+    _call('vpho_roi_align_bwd_nhwc_f32', _f32(dy), I(ld), I(c_off), I(N), I(H), I(W), I(C), _f32(boxes), F(scale), I(P), _u8(flip_w), _f32(df))
+    return df
+
+
 def add_lrelu(a, b, slope=1.0):
     y = torch.empty_like(a)
     _call('vpho_add_lrelu_f32', _f32(a), _f32(b), LL(a.numel()), F(slope), _f32(y))
