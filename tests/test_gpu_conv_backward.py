@@ -227,3 +227,42 @@ def test_roi_align_backward_matches_oracle_autograd():
     df = ops.roi_align_bwd(nhwc(d1), boxes.cuda(), (H, W), C, 0.25)
     df = ops.roi_align_bwd(nhwc(d2), boxes2.cuda(), (H, W), C, 0.25, flip_w=flip.to(torch.uint8).cuda(), into=df)
     np.testing.assert_allclose(df.permute(0, 3, 1, 2).cpu().numpy(), feat.grad.numpy(), atol=2e-5 * float(feat.grad.abs().max()), rtol=1e-4)
+
+
+def _check_sampled_grads(G, grads, skip_zero=()):
+    names = [k[len('gnorm_'):] for k in G.files if k.startswith('gnorm_')]
+    assert set(names) == set(grads), sorted(set(names) ^ set(grads))[:10]
+    top = max(float(G['gnorm_' + k]) for k in names)
+    for k in names:
+        gr = grads[k].reshape(-1).cpu()
+        nrm = float(G['gnorm_' + k])
+        if k in skip_zero:                                     # a bias in front of a BatchNorm: zero gradient, rounding noise on both sides
+            assert nrm < 1e-4 * top and float(gr.double().norm()) < 1e-4 * top, k
+            continue
+        assert abs(float(gr.double().norm()) - nrm) <= 3e-3 * nrm + 1e-9, (k, float(gr.double().norm()), nrm)
+        e = np.abs(gr[::499].numpy() - G['gsample_' + k])
+        rms_k = nrm / max(1.0, gr.numel() ** 0.5)
+        assert float(e.max()) < 0.15 * rms_k + 1e-9 and (e.size < 16 or float(np.median(e)) < 0.02 * rms_k + 1e-9), (k, float(e.max()) / rms_k)
+
+
+def test_heatmap_head_training_step_matches_reference_module(sd):
+    """Training-mode forward + backward of HeadHeatmap2 incl. the transposed convolution (four phase convolutions and their
+    gradients reassembled into the (Cin, Cout, 4, 4) weight gradient) vs the reference's own module under autograd."""
+    import os
+    from vpho_amd.train_blocks import HeatmapHeadTrain
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_hmhead_train.npz'))
+    net = HeatmapHeadTrain(sd, 'head_hm_hand', 'cuda')
+    g = np.random.default_rng(33)
+    x = torch.from_numpy((g.normal(size=(4, 256, 16, 16)) * 0.2).astype(np.float32))
+    out = net.forward(x.permute(0, 2, 3, 1).contiguous().cuda())
+    A = torch.from_numpy(g.normal(size=(4, out.shape[3], out.shape[1], out.shape[2])).astype(np.float32))
+    o = out.permute(0, 3, 1, 2).reshape(-1).cpu()
+    assert abs(float(o.double().norm()) - float(G['out_norm'])) < 1e-4 * float(G['out_norm'])
+    np.testing.assert_allclose(o[::499].numpy(), G['out_sample'], atol=2e-4 * float(np.abs(G['out_sample']).max()), rtol=1e-3)
+    dx, grads = net.backward(A.permute(0, 2, 3, 1).contiguous().cuda())
+    dxn = dx.permute(0, 3, 1, 2).reshape(-1).cpu()
+    assert abs(float(dxn.double().norm()) - float(G['dx_norm'])) <= 2e-3 * float(G['dx_norm'])
+    rms = float(G['dx_norm']) / dxn.numel() ** 0.5
+    err = np.abs(dxn[::499].numpy() - G['dx_sample'])
+    assert float(np.median(err)) < 1e-3 * rms and float(np.mean(err > 0.05 * rms)) < 0.01
+    _check_sampled_grads(G, grads, skip_zero=('conv_layers.1.bias',))

@@ -23,14 +23,23 @@ def _flip_transpose(w_packed, cout, cin, kh, kw):
     return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
 
 
-def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0):
-    """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad)."""
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None):
+    """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
+    asymmetric top/left paddings of the transposed-convolution phases, stride 1 only)."""
     N, OH, OW, cout = dy.shape
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
+    if cout % 4:                                          # the GEMM kernel wants a reduction length that is a multiple of 4
+        extra = 4 - cout % 4
+        dy = torch.nn.functional.pad(dy, (0, extra)).contiguous()
+        w_packed = torch.cat([w_packed, w_packed.new_zeros(extra, w_packed.shape[1])], 0)
+        cout += extra
+    py = pad if pad_y is None else pad_y
+    px = pad if pad_x is None else pad_x
     if stride == 1:
-        return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1, pad=kh - 1 - pad,
-                               pad_x=kw - 1 - pad, pad_y=kh - 1 - pad, out_hw=(H, W))
+        return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1,
+                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W))
+    assert py == px == pad
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
     w4 = w_packed.view(cout, kh, kw, cin)
     dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)
@@ -58,10 +67,10 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0):
     return dx
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None):
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None):
     """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights."""
     N, OH, OW, cout = dy.shape
-    xg_t = ops.im2col_t(x, kh, kw, stride, pad, pad, OH, OW, cin=cin)             # (kh*kw*cin, P4)
+    xg_t = ops.im2col_t(x, kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, OH, OW, cin=cin)   # (kh*kw*cin, P4)
     dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns
     kc, P4 = xg_t.shape
     # The reduction runs over the pixels (P ~ 1e5) while the result is only Cout x kh*kw*Cin: split the pixel range over

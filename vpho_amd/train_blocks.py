@@ -286,3 +286,69 @@ class EncoderTrain:
         G['project.bias'] = CB.conv2d_bias_grad(dh)
         dx = CB.conv2d_dgrad(dh, self.project[0], x.shape[1:3], 1, 1)
         return dx, G
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+class HeatmapHeadTrain:
+    """Training-mode forward + backward of ``HeadHeatmap2`` (lib/model/head_inplane.py:40-58,102-107): 3x3 conv, 3x3 conv +
+    BatchNorm (+ LeakyReLU(True), the identity -- quirk Q1), ConvTranspose2d(4, 2, 1) + BatchNorm + ReLU, 1x1 conv.  The
+    transposed convolution runs as four 2x2 phase convolutions (forward, as in inference) and their dgrad / wgrad (backward)."""
+    TAP = {0: (3, 1), 1: (2, 0)}                           # kernel row used by output parity p at input offset d in {0,1}
+
+    def __init__(self, sd, prefix, device):
+        from .model.pack import pack_conv, pack_deconv4x4s2
+        dev = self.dev = device
+        w = lambda k: sd[f'{prefix}.{k}'].detach().float()
+        self.shapes = {k: tuple(w(k).shape) for k in ('conv_layers.0.weight', 'conv_layers.1.weight', 'deconv_layers.0.weight', 'final_layer.weight')}
+        self.c0 = (pack_conv(w('conv_layers.0.weight')).to(dev), w('conv_layers.0.bias').to(dev).contiguous())
+        self.c1 = (pack_conv(w('conv_layers.1.weight')).to(dev), w('conv_layers.1.bias').to(dev).contiguous())
+        self.bn1 = _bn_params(sd, f'{prefix}.conv_layers.2', dev)
+        self.deconv = {k: (v[0].to(dev), v[1], v[2]) for k, v in pack_deconv4x4s2(w('deconv_layers.0.weight')).items()}
+        self.bn2 = _bn_params(sd, f'{prefix}.deconv_layers.1', dev)
+        self.final = (pack_conv(w('final_layer.weight')).to(dev), w('final_layer.bias').to(dev).contiguous())
+
+    def forward(self, x):
+        import torch
+        bn = lambda p, t, slope: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=slope)
+        c0 = ops.conv2d_nhwc(x, *self.c0, kh=3, kw=3, pad=1)
+        c1 = ops.conv2d_nhwc(c0, *self.c1, kh=3, kw=3, pad=1)
+        a1, s1 = bn(self.bn1, c1, 1.0)
+        N, H, W, _ = a1.shape
+        co = self.shapes['deconv_layers.0.weight'][1]
+        up = torch.empty((N, 2 * H, 2 * W, co), device=x.device)
+        for (py, px), (wp, pady, padx) in self.deconv.items():
+            ops.conv2d_nhwc(a1, wp, None, kh=2, kw=2, pad_y=pady, pad_x=padx, out_hw=(H, W),
+                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co))
+        a2, s2 = bn(self.bn2, up, 0.0)
+        out = ops.conv2d_nhwc(a2, *self.final)
+        self.saved = dict(x=x, c0=c0, c1=c1, a1=a1, s1=s1, up=up, a2=a2, s2=s2)
+        return out
+
+    def backward(self, dout):
+        import torch
+        S, G = self.saved, {}
+        N, H, W, _ = S['a1'].shape
+        G['final_layer.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dout, 1, 1), *self.shapes['final_layer.weight'])
+        G['final_layer.bias'] = CB.conv2d_bias_grad(dout)
+        da2 = ops.lrelu_bwd(CB.conv2d_dgrad(dout, self.final[0], S['a2'].shape[1:3], 1, 1), S['a2'], 0.0)
+        dup, G['deconv_layers.1.weight'], G['deconv_layers.1.bias'] = ops.bn_train_backward(S['up'], da2, self.bn2['gamma'], S['s2'])
+        cin, co = self.shapes['deconv_layers.0.weight'][:2]
+        dwt = torch.zeros(self.shapes['deconv_layers.0.weight'], device=dout.device)
+        da1 = None
+        for (py, px), (wp, pady, padx) in self.deconv.items():
+            dph = dup[:, py::2, px::2, :].contiguous()                               # this parity's outputs (N,H,W,co)
+            g = CB.conv2d_wgrad(S['a1'], dph, 2, 2, 1, pad_y=pady, pad_x=padx).view(co, 2, 2, cin)
+            for dy_ in (0, 1):
+                for dx_ in (0, 1):
+                    dwt[:, :, self.TAP[py][dy_], self.TAP[px][dx_]] = g[:, dy_, dx_, :].t()
+            d = CB.conv2d_dgrad(dph, wp, (H, W), 2, 2, 1, pad_y=pady, pad_x=padx)
+            da1 = d if da1 is None else ops.add_lrelu(da1, d)
+        G['deconv_layers.0.weight'] = dwt
+        dc1, G['conv_layers.2.weight'], G['conv_layers.2.bias'] = ops.bn_train_backward(S['c1'], da1, self.bn1['gamma'], S['s1'])
+        G['conv_layers.1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['c0'], dc1, 3, 3, 1, 1), *self.shapes['conv_layers.1.weight'])
+        G['conv_layers.1.bias'] = CB.conv2d_bias_grad(dc1)
+        dc0 = CB.conv2d_dgrad(dc1, self.c1[0], S['c0'].shape[1:3], 3, 3, 1, 1)
+        G['conv_layers.0.weight'] = _unpack_grad(CB.conv2d_wgrad(S['x'], dc0, 3, 3, 1, 1), *self.shapes['conv_layers.0.weight'])
+        G['conv_layers.0.bias'] = CB.conv2d_bias_grad(dc0)
+        dx = CB.conv2d_dgrad(dc0, self.c0[0], S['x'].shape[1:3], 3, 3, 1, 1)
+        return dx, G
