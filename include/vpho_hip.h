@@ -338,6 +338,10 @@ int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, in
  * W-flipped like the forward) scattered into dfeat [N][H][W][C] += ...; dfeat must be zero-initialised (fp32 atomics) */
 int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                 int out_size, const unsigned char* flip_w, float* dfeat, void* stream);
+/* backward of vpho_align_heatmap_nhwc_f32 (align_hm_to_bbox_rectangle + flip, VPHO.py:333-346,139): dout [N][S][S][C] -> dhm [N][S][S][C]
+ * (+=, fp32 atomics: zero-initialise dhm) */
+int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
+                                    const unsigned char* flip_w, float* dhm, void* stream);
 /* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */
 int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient

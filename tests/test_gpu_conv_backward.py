@@ -266,3 +266,22 @@ def test_heatmap_head_training_step_matches_reference_module(sd):
     err = np.abs(dxn[::499].numpy() - G['dx_sample'])
     assert float(np.median(err)) < 1e-3 * rms and float(np.mean(err > 0.05 * rms)) < 0.01
     _check_sampled_grads(G, grads, skip_zero=('conv_layers.1.bias',))
+
+
+def test_align_heatmap_backward_matches_oracle_autograd():
+    """align_hm_to_bbox_rectangle (transposing bilinear resample, zero padding) + W-flip backward vs autograd on the oracle"""
+    from oracle.vpho import align_hm_to_bbox_rectangle, flip_w
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(4)
+    N, C, S = 3, 5, 16
+    hm = torch.randn(N, C, S, S, generator=g).requires_grad_(True)
+    bbox = torch.tensor([[40.0, 50.0, 180.0, 200.0], [10.0, 20.0, 250.0, 190.0], [90.0, 60.0, 160.0, 210.0]])
+    c = (bbox[:, :2] + bbox[:, 2:]) / 2
+    m = (bbox[:, 2:] - bbox[:, :2]).max(-1, keepdim=True).values
+    rect = torch.cat([c - m / 2, c + m / 2], -1)
+    flip = torch.tensor([True, False, True])
+    y = flip_w(align_hm_to_bbox_rectangle(hm, bbox, rect, S), flip)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    d = ops.align_heatmap_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), bbox.cuda(), rect.cuda(), flip.to(torch.uint8).cuda())
+    np.testing.assert_allclose(d.permute(0, 3, 1, 2).cpu().numpy(), hm.grad.numpy(), atol=2e-5 * float(hm.grad.abs().max()), rtol=1e-4)

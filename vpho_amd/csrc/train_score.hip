@@ -423,6 +423,33 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ dy, int ldo, int 
     }
 }
 
+// backward of vpho_align_heatmap_nhwc_f32 (VPHO.py:333-346 + the W-flip of :139): out[b,i,j] = bilinear_zero(hm[b]; x(i), y(j)),
+// so d hm[b, y0..y0+1, x0..x0+1] += weights * d out[b, i, flip ? S-1-j : j]; fp32 atomics (d hm zero-initialised)
+__global__ void align_heatmap_bwd_kernel(const float* __restrict__ dout, int N, int S, int C, const float* __restrict__ bbox,
+                                         const float* __restrict__ bbox_rect, const unsigned char* __restrict__ flip_w, float* __restrict__ dhm) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * S * S * C) return;
+    const int c = (int)(idx % C);
+    long long p = idx / C;
+    const int j = (int)(p % S); p /= S;
+    const int i = (int)(p % S);
+    const int n = (int)(p / S);
+    const float relw = (bbox_rect[n * 4 + 2] - bbox_rect[n * 4 + 0]) / (bbox[n * 4 + 2] - bbox[n * 4 + 0]);
+    const float relh = (bbox_rect[n * 4 + 3] - bbox_rect[n * 4 + 1]) / (bbox[n * 4 + 3] - bbox[n * 4 + 1]);
+    const float gx = ((float)i / (float)(S - 1) * 2.f - 1.f) * relw;
+    const float gy = ((float)j / (float)(S - 1) * 2.f - 1.f) * relh;
+    const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f, iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    const int oj = (flip_w && flip_w[n]) ? S - 1 - j : j;
+    const float g = dout[(((long long)n * S + i) * S + oj) * C + c];
+    float* b = dhm + (long long)n * S * S * C + c;
+    auto add = [&](int yy, int xx, float w) { if (yy >= 0 && yy < S && xx >= 0 && xx < S) atomicAdd(b + ((long long)yy * S + xx) * C, w * g); };
+    add(y0, x0, (1.f - tx) * (1.f - ty)); add(y0, x0 + 1, tx * (1.f - ty));
+    add(y0 + 1, x0, (1.f - tx) * ty); add(y0 + 1, x0 + 1, tx * ty);
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -586,4 +613,11 @@ extern "C" int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, 
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(nblk((long long)N * out_size * out_size * C)), dim3(256), 0, (hipStream_t)stream, dy, ldo, c_off, N, H, W, C,
                        boxes, spatial_scale, out_size, flip_w, dfeat);
     return vpho::check_launch("roi_align_bwd_kernel");
+}
+
+extern "C" int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
+                                               const unsigned char* flip_w, float* dhm, void* stream) {
+    VPHO_REQUIRE(dout && bbox && bbox_rect && dhm && N > 0 && size > 1 && C > 0, "vpho_align_heatmap_bwd_nhwc_f32: bad argument");
+    hipLaunchKernelGGL(align_heatmap_bwd_kernel, dim3(nblk((long long)N * size * size * C)), dim3(256), 0, (hipStream_t)stream, dout, N, size, C, bbox, bbox_rect, flip_w, dhm);
+    return vpho::check_launch("align_heatmap_bwd_kernel");
 }

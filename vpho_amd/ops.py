@@ -732,6 +732,13 @@ def roi_align_bwd(dy, boxes, feat_hw, C, scale, flip_w=None, c_off=0, into=None)
     return df
 
 
+def align_heatmap_bwd(dout, bbox, bbox_rect, flip_w=None):
+    N, S, _, Cc = dout.shape
+    dhm = torch.zeros_like(dout)
+    _call('vpho_align_heatmap_bwd_nhwc_f32', _f32(dout), I(N), I(S), I(Cc), _f32(bbox), _f32(bbox_rect), _u8(flip_w), _f32(dhm))
+    return dhm
+
+
 def add_lrelu(a, b, slope=1.0):
     y = torch.empty_like(a)
     _call('vpho_add_lrelu_f32', _f32(a), _f32(b), LL(a.numel()), F(slope), _f32(y))
