@@ -297,6 +297,10 @@ int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, cons
  * dout = d loss / d (un-normalised head output) [rows][D]; loss: one double on the device; partial_ws: >= 1024 doubles */
 int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
                       float* dout, double* loss, double* partial_ws, int partial_cap, void* stream);
+/* JointsMSELoss (lib/model/head_inplane.py:191-203: nn.MSELoss, mean over all elements) times its loss weight
+ * (VPHO.py:214-219): loss[0] = weight * mean((pd - gt)^2) in fp64, grad = weight * 2 (pd - gt) / n.  partial_ws: >= partial_cap doubles */
+int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws, int partial_cap,
+                      void* stream);
 /* backward of the second ParallelLinear and of the ReLU in front of it: dpre [rows][nheads*256] (gradient at the first
  * layer's pre-activation), dw2 [nheads][256][3], db2 [nheads][3] */
 int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,

@@ -1,0 +1,106 @@
+"""End-to-end training step (diffusion + heat-map losses) through the C-ABI vs the reference's own ``vpho_net.forward(mode=
+'train')`` + autograd (fixture: tests/golden/make_golden_diffusion_step.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'golden_diffusion_step.npz')
+BS, STRIDE = 12, 1999
+# biases directly in front of a BatchNorm: the mean subtraction removes them, both sides hold rounding noise
+ZERO_GRAD = ('.conv1.bias', '.conv2.bias', '.conv_layers.1.bias')
+
+
+def load_case():
+    from vpho_amd.assets import synthetic_assets
+    from vpho_amd.synth import synth_state_dict, synth_batch
+    from vpho_amd.model.VPHO import vpho_net
+    assets = synthetic_assets(0)
+    sd = synth_state_dict(vpho_net(assets), seed=1)
+    batch = synth_batch(BS, assets, seed=5)
+    G = np.load(GOLD)
+    g = np.random.default_rng(77)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    batch['hm_hand'] = f32(g.random(size=(BS, 21, 64, 64)) * 0.2)
+    batch['hm_obj'] = f32(g.random(size=(BS, 27, 64, 64)) * 0.2)
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    draws = {k: torch.from_numpy(G[k]).cuda() for k in ('t_h', 'z_h', 't_o', 'z_o')}
+    return sd, data, draws, G
+
+
+@pytest.fixture(scope='module')
+def setup():
+    return load_case()
+
+
+def compare_gradients(G, grads, report=None):
+    """After ~170 layers of batch-normalised, non-smooth backward on 12 images fp32 rounding alone moves a gradient entry by about
+    1 % of its tensor's rms: the fixture holds the reference's own fp32-vs-fp64 deviation per tensor ('noise_*', median |g32-g64| /
+    rms; median over tensors q = 1.1e-2, 90 % < 4e-2) and the fp64 samples.  Per tensor: the norm agrees with the reference's fp32
+    norm to 1 %; the median deviation of our sampled entries from the fp64 gradient stays within 2.5x the reference's own noise
+    (floored at q) -- 6x for tensors with fewer than 16 sampled entries, whose one-or-few-sample estimate is itself noise; no sampled
+    entry is off by more than 0.5 rms (isolated LeakyReLU-kink / pooling-tie flips).  Over all tensors the typical deviation must
+    not exceed the reference's own (test body)."""
+    names = [k[len('gnorm_'):] for k in G.files if k.startswith('gnorm_')]
+    assert set(names) == set(grads), sorted(set(names) ^ set(grads))[:10]
+    top = {}
+    for k in names:
+        mod = k.split('.')[0]
+        top[mod] = max(top.get(mod, 0.0), float(G['gnorm_' + k]))
+    bad, ours, theirs = [], [], []
+    q = float(np.median([float(G[k]) for k in G.files if k.startswith('noise_')]))
+    for k in names:
+        gr = grads[k].reshape(-1).cpu()
+        nrm, mine = float(G['gnorm_' + k]), float(grads[k].double().norm())
+        if k.endswith(ZERO_GRAD) and not k.startswith('denoiser_'):
+            ok = nrm < 1e-3 * top[k.split('.')[0]] and mine < 1e-3 * top[k.split('.')[0]]
+            rel_n = e_med = e_max = noise = 0.0
+        else:
+            rel_n = abs(mine - nrm) / (nrm + 1e-12)
+            rms_k = nrm / max(1.0, gr.numel() ** 0.5) + 1e-30
+            e = np.abs(gr[::STRIDE].numpy() - G['gsample64_' + k]) / rms_k
+            e_med, e_max, noise = float(np.median(e)), float(e.max()), float(G['noise_' + k])
+            ok = rel_n < 1e-2 and e_med <= (2.5 if e.size >= 16 else 6.0) * max(noise, q) and e_max < max(0.5, 10 * noise)
+            ours.append(e_med)
+            theirs.append(noise)
+        if report is not None:
+            report.append((k, rel_n, e_med, e_max, noise, ok))
+        if not ok:
+            bad.append((k, rel_n, e_med, e_max, noise))
+    return bad, float(np.median(ours)), float(np.median(theirs))
+
+
+def test_losses_and_gradients_match_reference_training_forward(setup):
+    from vpho_amd.train_step import DiffusionTrainStep
+    sd, data, draws, G = setup
+    step = DiffusionTrainStep(sd, 'cuda', loss_weights=dict(hm_hand=1e3, hm_obj=1e3))
+    L, grads = step.loss_and_grads(data, torch.from_numpy(G['gt_hand6d']).cuda(), torch.from_numpy(G['gt_obj']).cuda(), draws)
+    for k in ('diff_hand_loss', 'diff_obj_loss', 'hm_hand_loss', 'hm_obj_loss'):
+        assert abs(float(L[k]) - float(G[k])) <= 2e-4 * abs(float(G[k])), (k, float(L[k]), float(G[k]))
+    bad, ours, theirs = compare_gradients(G, grads)
+    assert not bad, bad[:10]
+    assert ours <= 1.5 * theirs, (ours, theirs)          # typical deviation from the fp64 gradient: ours vs the reference's own fp32 run
+
+
+def test_optimizer_step_updates_every_tensor_and_lowers_the_loss(setup):
+    """Three AdamW steps on the same batch and draws: every registered tensor moves by about lr in the first step (Adam's
+    normalised update), the packed kernel weights follow their masters, and the total loss decreases."""
+    from vpho_amd.train_step import DiffusionTrainStep
+    sd, data, draws, G = setup
+    step = DiffusionTrainStep(sd, 'cuda', lr=2e-4, loss_weights=dict(hm_hand=1e3, hm_obj=1e3))
+    gt_h, gt_o = torch.from_numpy(G['gt_hand6d']).cuda(), torch.from_numpy(G['gt_obj']).cuda()
+    before = {k: v.clone() for k, v in step.master.items()}
+    packed_before = step.fpn.blocks['layer2_o'][1][1]['conv2'].clone()
+    losses = [float(step.step(data, gt_h, gt_o, draws)['total_loss']) for _ in range(3)]
+    assert losses[2] < losses[0], losses
+    moved = {k: float((step.master[k] - before[k]).abs().max()) for k in step.names}
+    assert all(0 < v < 3 * 3 * 2e-4 + 1e-3 * float(before[k].abs().max()) for k, v in moved.items()), [k for k, v in moved.items() if v == 0][:5]
+    assert float((step.fpn.blocks['layer2_o'][1][1]['conv2'] - packed_before).abs().max()) > 0
+    out = step.state_dict()
+    assert set(sd) >= set(out) and all(out[k].shape == sd[k].shape for k in out)
+    # running statistics moved too (momentum 0.1 updates in the BatchNorm kernels)
+    k = 'encoder_obj.reg.3.bn1.running_mean'
+    assert float((out[k].cpu() - sd[k]).abs().max()) > 0

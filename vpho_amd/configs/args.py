@@ -35,6 +35,11 @@ class Config:
         self.topk_hand = 15
         self.topk_obj = 5
         self.asset_root = 'asset'
+        self.base_learning_rate = 2e-4
+        self.weight_diff_hand_loss = 1.0
+        self.weight_diff_obj_loss = 1.0
+        self.weight_hm_hand_loss = 1.0
+        self.weight_hm_obj_loss = 1.0
 
 
 def _parser():
@@ -64,6 +69,11 @@ def _parser():
     p.add_argument('--topk_hand', type=int, default=15)
     p.add_argument('--topk_obj', type=int, default=5)
     p.add_argument('--asset_root', type=str, default='asset')
+    p.add_argument('--base_learning_rate', type=float, default=2e-4)
+    p.add_argument('--weight_diff_hand_loss', type=float, default=1.0)
+    p.add_argument('--weight_diff_obj_loss', type=float, default=1.0)
+    p.add_argument('--weight_hm_hand_loss', type=float, default=1e3)
+    p.add_argument('--weight_hm_obj_loss', type=float, default=1e3)
     return p
 
 

@@ -87,6 +87,22 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
     if (threadIdx.x == 0) *out = red[0] * scale;
 }
 
+// nn.MSELoss (mean) times a loss weight: per-block partial sums of (pd - gt)^2, grad = weight * 2 (pd - gt) / n
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ pd, const float* __restrict__ gt, long long n_el, float grad_scale,
+                                                       float* __restrict__ grad, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_el; i += (long long)gridDim.x * 256) {
+        const float diff = pd[i] - gt[i];
+        acc += (double)(diff * diff);
+        grad[i] = diff * grad_scale;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // dpre[r][n*256+c] = h > 0 ? sum_d dout[r][3n+d] * w2[n][c][d] : 0   (backward of the second head layer and of the ReLU before it)
 __global__ void plinear2_bwd_input_kernel(const float* __restrict__ h, const float* __restrict__ dout, const float* __restrict__ w2,
                                           long long rows, int n, float* __restrict__ dpre) {
@@ -487,6 +503,15 @@ extern "C" int vpho_dsm_loss_f32(const float* score, const float* z, const float
     hipLaunchKernelGGL(dsm_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, z, std_rows, rows * D, D, 1.0f / (float)batch_times_reps, dout, partial_ws);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial_ws, nb, 1.0 / (double)batch_times_reps, loss);
     return vpho::check_launch("dsm_loss kernels");
+}
+
+extern "C" int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws,
+                                 int partial_cap, void* stream) {
+    VPHO_REQUIRE(pd && gt && grad && loss && partial_ws && n > 0 && partial_cap >= 1, "vpho_mse_loss_f32: bad argument");
+    const int nb = std::min(partial_cap, std::min(1024, nblk(n)));
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pd, gt, n, (float)(2.0 * (double)weight / (double)n), grad, partial_ws);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial_ws, nb, (double)weight / (double)n, loss);
+    return vpho::check_launch("mse_loss_kernel");
 }
 
 extern "C" int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,

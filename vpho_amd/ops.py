@@ -634,6 +634,16 @@ def dsm_loss(score, z, std_rows, batch_times_reps):
     return loss, dout
 
 
+def mse_loss(pd, gt, weight=1.0):
+    """-> weight * mean((pd-gt)^2) (0-d fp64 device tensor), its gradient w.r.t. pd"""
+    assert pd.shape == gt.shape
+    grad = torch.empty_like(pd)
+    loss = _new((), pd, torch.float64)
+    ws = _new((1024,), pd, torch.float64)
+    _call('vpho_mse_loss_f32', _f32(pd), _f32(gt), LL(pd.numel()), F(weight), _f32(grad), _f64(loss), _f64(ws), I(1024))
+    return loss, grad
+
+
 def plinear2_bwd(h, dout, w2, nheads):
     rows = h.shape[0]
     dpre, dw2, db2 = torch.empty_like(h), torch.empty_like(w2), _new((nheads, 3), h)

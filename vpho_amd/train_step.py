@@ -1,0 +1,231 @@
+"""End-to-end training step for the diffusion and heat-map losses: ``vpho_net.forward(mode='train')``
+restricted to ``diff_hand_loss + diff_obj_loss + hm_hand_loss + hm_obj_loss`` (lib/model/VPHO.py:115-150,175-195,214-220) with
+every module on the path in training mode, ``loss.backward()`` through score networks -> encoders -> heat-map heads /
+re-alignment -> RoIAlign -> the two-branch backbone, data-parallel gradient averaging and AdamW
+(lib/engine/train_diff_hand_obj.py:49-52,169-199).
+
+Not part of this step (the remaining losses of the reference's training forward and the modules only they reach): MANO and
+physics losses, ``head_mano``, the cross modules and ``head_physics``; gradient clipping is off as in the reference's default.
+Composition of ``train_blocks`` / ``train_score``; torch allocates, slices and, under ``torch.distributed``, all-reduces ONE
+flat gradient buffer (RCCL under backend 'nccl').
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .configs.args import cfg
+from .model.pack import pack_conv, pack_deconv4x4s2
+from .train_blocks import FPNTrain, EncoderTrain, HeatmapHeadTrain
+from .train_score import ScoreTrainer, SUFFIXES
+
+
+class DiffusionTrainStep:
+    def __init__(self, state_dict, device, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, loss_weights=None):
+        self.dev = torch.device(device)
+        sd = state_dict
+        lr = cfg.base_learning_rate if lr is None else lr
+        self.fpn = FPNTrain(sd, 'feature_extractor', self.dev)
+        self.hm = dict(h=HeatmapHeadTrain(sd, 'head_hm_hand', self.dev), o=HeatmapHeadTrain(sd, 'head_hm_obj', self.dev))
+        self.enc = dict(h=EncoderTrain(sd, 'encoder_hand', self.dev), o=EncoderTrain(sd, 'encoder_obj', self.dev))
+        self.score = dict(h=ScoreTrainer(sd, 'denoiser_hand', self.dev, lr, betas, eps, weight_decay),
+                          o=ScoreTrainer(sd, 'denoiser_obj', self.dev, lr, betas, eps, weight_decay))
+        self.w = dict(diff_hand=cfg.weight_diff_hand_loss, diff_obj=cfg.weight_diff_obj_loss, hm_hand=cfg.weight_hm_hand_loss,
+                      hm_obj=cfg.weight_hm_obj_loss)
+        self.w.update(loss_weights or {})
+        self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
+        self.steps = 0
+        # optimiser state: master copies in the reference's state_dict layout (what AdamW updates), re-packed into the kernels'
+        # layouts after each step.  Vectors and the denoisers' tensors already are in that layout: the live tensor is the master.
+        self.master, self._repack = {}, {}
+        self._register()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _register(self):
+        def add(name, tensor, repack):
+            self.master[name] = tensor
+            self._repack[name] = repack
+
+        def conv(name, live, shape, cin_pad=None):
+            cout, cin, kh, kw = shape
+            master = live.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2).contiguous()
+            add(name, master, lambda w, live=live, cin_pad=cin_pad: live.copy_(pack_conv(w, cin_pad)))
+
+        def vec(name, live):
+            add(name, live, None)
+
+        f = self.fpn
+        P = 'feature_extractor.'
+        conv(P + 'layer0_h.0.weight', f.stem['conv'], f.shapes['layer0_h.0.weight'], 4)
+        vec(P + 'layer0_h.1.weight', f.stem['bn']['gamma'])
+        vec(P + 'layer0_h.1.bias', f.stem['bn']['beta'])
+        for blks in f.blocks.values():
+            for k, p, _ in blks:
+                for c, b in (('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3')):
+                    conv(f'{P}{k}.{c}.weight', p[c], f.shapes[f'{k}.{c}.weight'])
+                    vec(f'{P}{k}.{b}.weight', p[b]['gamma'])
+                    vec(f'{P}{k}.{b}.bias', p[b]['beta'])
+                if 'down' in p:
+                    conv(f'{P}{k}.downsample.0.weight', p['down'], f.shapes[f'{k}.downsample.0.weight'])
+                    vec(f'{P}{k}.downsample.1.weight', p['bnd']['gamma'])
+                    vec(f'{P}{k}.downsample.1.bias', p['bnd']['beta'])
+        for hk, (wp, b) in f.heads.items():
+            conv(f'{P}{hk}.weight', wp, f.shapes[f'{hk}.weight'])
+            vec(f'{P}{hk}.bias', b)
+        for br, mod in (('hand', self.hm['h']), ('obj', self.hm['o'])):
+            P = f'head_hm_{br}.'
+            for (wp, b), key in ((mod.c0, 'conv_layers.0'), (mod.c1, 'conv_layers.1'), (mod.final, 'final_layer')):
+                conv(f'{P}{key}.weight', wp, mod.shapes[f'{key}.weight'])
+                vec(f'{P}{key}.bias', b)
+            vec(P + 'conv_layers.2.weight', mod.bn1['gamma'])
+            vec(P + 'conv_layers.2.bias', mod.bn1['beta'])
+            vec(P + 'deconv_layers.1.weight', mod.bn2['gamma'])
+            vec(P + 'deconv_layers.1.bias', mod.bn2['beta'])
+            cin, co = mod.shapes['deconv_layers.0.weight'][:2]
+            w = torch.zeros(mod.shapes['deconv_layers.0.weight'], device=self.dev)
+            for (py, px), (wp, _, _) in mod.deconv.items():          # ConvTranspose2d weight back from its four phase convolutions
+                sub = wp.view(co, 2, 2, cin)
+                for dy_ in (0, 1):
+                    for dx_ in (0, 1):
+                        w[:, :, mod.TAP[py][dy_], mod.TAP[px][dx_]] = sub[:, dy_, dx_, :].t()
+
+            def put(wnew, mod=mod):
+                for k, (wp, _, _) in pack_deconv4x4s2(wnew).items():
+                    mod.deconv[k][0].copy_(wp)
+            add(P + 'deconv_layers.0.weight', w, put)
+        for br, mod in (('hand', self.enc['h']), ('obj', self.enc['o'])):
+            P = f'encoder_{br}.'
+            conv(P + 'project.weight', mod.project[0], mod.shapes['project.weight'], mod.cin_pad)
+            vec(P + 'project.bias', mod.project[1])
+            for k, p in mod.blocks:
+                for c in ('conv1', 'conv2', 'conv3'):
+                    conv(f'{P}{k}.{c}.weight', p[c][0], mod.shapes[f'{k}.{c}.weight'])
+                    vec(f'{P}{k}.{c}.bias', p[c][1])
+                for b in ('bn', 'bn1', 'bn2'):
+                    vec(f'{P}{k}.{b}.weight', p[b]['gamma'])
+                    vec(f'{P}{k}.{b}.bias', p[b]['beta'])
+        for tr in self.score.values():
+            for s in SUFFIXES:
+                vec(f'{tr.prefix}.{s}', tr.params[s])
+        self.names = sorted(self.master)
+        sizes = [self.master[k].numel() for k in self.names]
+        self.flat_grad = torch.zeros(sum(sizes), device=self.dev)
+        self.grad_view, off = {}, 0
+        for k, n in zip(self.names, sizes):
+            self.grad_view[k] = self.flat_grad[off:off + n].view(self.master[k].shape)
+            off += n
+        self.m = {k: torch.zeros_like(v) for k, v in self.master.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.master.items()}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def loss_and_grads(self, data, gt_hand, gt_obj, draws):
+        """data: the batch dict of ``vpho_net`` (device tensors: rgb, bbox_hand, bbox_obj, bbox_hand_rect, bbox_obj_rect, is_right,
+        hm_hand (bs,21,64,64), hm_obj (bs,27,64,64)); gt_hand (bs,96) = mano_aa_to_6D(gt_mano), gt_obj (bs,9); draws: dict t_h, z_h,
+        t_o, z_o (reps,bs[,D]).  -> losses {name: 0-d fp64 tensor, weighted}, grads {reference parameter name: gradient}."""
+        R, HM = cfg.roi_size, cfg.heatmap_size
+        f32 = lambda t: t.float().contiguous()
+        bb_h, bb_o, bb_hr, bb_or = (f32(data[k]) for k in ('bbox_hand', 'bbox_obj', 'bbox_hand_rect', 'bbox_obj_rect'))
+        left = (~data['is_right'].bool()).to(torch.uint8).contiguous()
+        eh, eo = self.enc['h'], self.enc['o']
+        with torch.cuda.device(self.dev):
+            # ---- forward (VPHO.py:115-150)
+            ph, po = self.fpn.forward(data['rgb'])
+            bs, H, W = ph.shape[:3]
+            in_h = torch.zeros((bs, R, R, eh.cin_pad), device=self.dev)
+            in_o = torch.zeros((bs, R, R, eo.cin_pad), device=self.dev)
+            hf_hr = ops.roi_align_nhwc(ph, bb_h, R, 0.25)                          # tight box: the hand heat-map head's input
+            ops.roi_align_nhwc(ph, bb_hr, R, 0.25, out=in_h)                       # rectangular box: the encoder's input
+            of_or = ops.roi_align_nhwc(po, bb_or, R, 0.25)                         # un-flipped: the object heat-map head's input
+            ops.roi_align_nhwc(po, bb_or, R, 0.25, flip_w=left, out=in_o)
+            hm_h = self.hm['h'].forward(hf_hr)
+            hm_o = self.hm['o'].forward(of_or)
+            ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_h, bb_h, bb_hr), R, R, out=in_h, c_off=256)
+            ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_o, bb_o, bb_or, flip_w=left), R, R, out=in_o, c_off=256)
+            enc_h, _ = eh.forward(in_h)
+            enc_o, _ = eo.forward(in_o)
+            # ---- losses (VPHO.py:190-195,214-220) and their gradients at the encodings / heat maps
+            L = {}
+            L['diff_hand_loss'], d_enc_h = self.score['h']._loss_and_grads(enc_h, f32(gt_hand), f32(draws['t_h']), f32(draws['z_h']))
+            L['diff_obj_loss'], d_enc_o = self.score['o']._loss_and_grads(enc_o, f32(gt_obj), f32(draws['t_o']), f32(draws['z_o']))
+            L['hm_hand_loss'], d_hm_h = ops.mse_loss(hm_h, ops.nchw_to_nhwc(f32(data['hm_hand'])), self.w['hm_hand'])
+            L['hm_obj_loss'], d_hm_o = ops.mse_loss(hm_o, ops.nchw_to_nhwc(f32(data['hm_obj'])), self.w['hm_obj'])
+            L['diff_hand_loss'] = L['diff_hand_loss'] * self.w['diff_hand']
+            L['diff_obj_loss'] = L['diff_obj_loss'] * self.w['diff_obj']
+            # ---- backward
+            G = {}
+            dfeat = {}
+            for br, long_, enc, head, d_enc, d_hm_loss, w_diff, box_rect, box_head, box_tight, flip in (
+                    ('h', 'hand', eh, self.hm['h'], d_enc_h, d_hm_h, self.w['diff_hand'], bb_hr, bb_h, bb_h, None),
+                    ('o', 'obj', eo, self.hm['o'], d_enc_o, d_hm_o, self.w['diff_obj'], bb_or, bb_or, bb_o, left)):
+                if w_diff != 1.0:
+                    d_enc = d_enc * w_diff
+                d_in, g = enc.backward(d_enc)
+                G.update({f'encoder_{long_}.{k}': v for k, v in g.items()})
+                nj = enc.cin - 256
+                # feature channels of the encoder input: RoIAlign of the rectangular box (W-flipped for the object branch)
+                df = ops.roi_align_bwd(d_in, box_rect, (H, W), 256, 0.25, flip_w=flip, c_off=0)
+                # heat-map channels: 64 -> 32 resize, re-alignment (+ flip), joined by the heat-map loss's own gradient
+                d_al = ops.resize_bilinear_bwd(d_in[..., 256:256 + nj].contiguous(), HM, HM)
+                d_hm = ops.add_lrelu(ops.align_heatmap_bwd(d_al, box_tight, box_rect, flip), d_hm_loss)
+                d_head_in, gh = head.backward(d_hm)
+                G.update({f'head_hm_{long_}.{k}': v for k, v in gh.items()})
+                dfeat[br] = ops.roi_align_bwd(d_head_in, box_head, (H, W), 256, 0.25, into=df)
+            G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o']).items()})
+            for tr, w_diff in ((self.score['h'], self.w['diff_hand']), (self.score['o'], self.w['diff_obj'])):
+                G.update({f'{tr.prefix}.{s}': (tr.grads[s] if w_diff == 1.0 else tr.grads[s] * w_diff) for s in SUFFIXES})
+            L['total_loss'] = L['diff_hand_loss'] + L['diff_obj_loss'] + L['hm_hand_loss'] + L['hm_obj_loss']
+        return L, G
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, data, gt_hand, gt_obj, draws=None, repeat_num=None, eps=1e-5, lr=None):
+        """loss_and_grads + gradient average over the ranks (one all-reduce of the flat buffer) + AdamW on every tensor.
+        Without `draws` they are made like loss_fn's (torch.rand / torch.randn on the device, score_based_model.py:24,31)."""
+        bs = data['rgb'].shape[0]
+        reps = cfg.repeat_num if repeat_num is None else repeat_num
+        if draws is None:
+            u = lambda: torch.rand(reps, bs, device=self.dev) * (1. - eps) + eps
+            draws = dict(t_h=u(), z_h=torch.randn(reps, bs, 96, device=self.dev), t_o=u(), z_o=torch.randn(reps, bs, 9, device=self.dev))
+        losses, grads = self.loss_and_grads(data, gt_hand, gt_obj, draws)
+        mismatch = set(self.names) ^ set(grads)
+        assert not mismatch, sorted(mismatch)[:5]
+        for k in self.names:
+            self.grad_view[k].copy_(grads[k])
+        scale = 1.0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            scale = 1.0 / dist.get_world_size()
+        self.steps += 1
+        hyper = dict(self.hyper, lr=self.hyper['lr'] if lr is None else lr)
+        with torch.cuda.device(self.dev):
+            for k in self.names:
+                ops.adamw_(self.master[k], self.grad_view[k], self.m[k], self.v[k], self.steps, grad_scale=scale, **hyper)
+                if self._repack[k] is not None:
+                    self._repack[k](self.master[k])
+        return losses
+
+    def state_dict(self):
+        """trained tensors + BatchNorm running statistics under the reference's names"""
+        out = {k: v.clone() for k, v in self.master.items()}
+        for tr in self.score.values():
+            out[f'{tr.prefix}.t_encoder.0.W'] = tr.fourier_W.clone()
+
+        def bn(name, p):
+            out[name + '.running_mean'] = p['running_mean'].clone()
+            out[name + '.running_var'] = p['running_var'].clone()
+
+        f = self.fpn
+        bn('feature_extractor.layer0_h.1', f.stem['bn'])
+        for blks in f.blocks.values():
+            for k, p, _ in blks:
+                for b, nm in (('bn1', 'bn1'), ('bn2', 'bn2'), ('bn3', 'bn3'), ('bnd', 'downsample.1')):
+                    if b in p:
+                        bn(f'feature_extractor.{k}.{nm}', p[b])
+        for br, mod in (('hand', self.hm['h']), ('obj', self.hm['o'])):
+            bn(f'head_hm_{br}.conv_layers.2', mod.bn1)
+            bn(f'head_hm_{br}.deconv_layers.1', mod.bn2)
+        for br, mod in (('hand', self.enc['h']), ('obj', self.enc['o'])):
+            for k, p in mod.blocks:
+                for b in ('bn', 'bn1', 'bn2'):
+                    bn(f'encoder_{br}.{k}.{b}', p[b])
+        return out
