@@ -82,8 +82,8 @@ def test_trainer_train_mode_runs_and_learns(assets):
     import copy
     from vpho_amd.configs.args import cfg
     from vpho_amd.trainer import Trainer
-    saved = (cfg.eval_batch_size, cfg.num_batches, cfg.random_seed)
-    cfg.eval_batch_size, cfg.num_batches = 8, 1
+    saved = (cfg.eval_batch_size, cfg.num_batches, cfg.random_seed, cfg.train_scope)
+    cfg.eval_batch_size, cfg.num_batches, cfg.train_scope = 8, 1, 'score'
     try:
         tr = Trainer(cfg)
         before = copy.deepcopy({k: v for k, v in tr.model.state_dict().items() if k.startswith('denoiser_')})
@@ -91,7 +91,7 @@ def test_trainer_train_mode_runs_and_learns(assets):
         for _ in range(30):                              # same seed -> same batch and ground truth: the loss must go down
             last = tr.run(n_batches=1)[0]
     finally:
-        cfg.eval_batch_size, cfg.num_batches, cfg.random_seed = saved
+        cfg.eval_batch_size, cfg.num_batches, cfg.random_seed, cfg.train_scope = saved
     after = tr.model.state_dict()
     changed = [k for k in before if not torch.equal(before[k].cpu(), after[k].cpu())]
     assert any(k.endswith('head.head.0.weight') for k in changed) and not any(k.endswith('t_encoder.0.W') for k in changed)

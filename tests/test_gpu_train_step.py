@@ -104,3 +104,26 @@ def test_optimizer_step_updates_every_tensor_and_lowers_the_loss(setup):
     # running statistics moved too (momentum 0.1 updates in the BatchNorm kernels)
     k = 'encoder_obj.reg.3.bn1.running_mean'
     assert float((out[k].cpu() - sd[k]).abs().max()) > 0
+
+
+def test_trainer_full_scope_runs_and_writes_back():
+    """`main.py --mode train` (train_scope 'full'): end-to-end steps on synthetic batches; the updated backbone / head / encoder /
+    denoiser weights and the BatchNorm running statistics land in the module's state_dict under the reference's keys."""
+    import copy
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.trainer import Trainer
+    saved = (cfg.batch_size, cfg.num_batches, cfg.train_scope, cfg.repeat_num)
+    cfg.batch_size, cfg.num_batches, cfg.train_scope, cfg.repeat_num = 8, 1, 'full', 4
+    try:
+        tr = Trainer(cfg)
+        before = copy.deepcopy({k: v.cpu() for k, v in tr.model.state_dict().items()})
+        hist = tr.run(n_batches=2)
+    finally:
+        cfg.batch_size, cfg.num_batches, cfg.train_scope, cfg.repeat_num = saved
+    after = {k: v.cpu() for k, v in tr.model.state_dict().items()}
+    changed = {k for k in before if not torch.equal(before[k], after[k])}
+    for k in ('feature_extractor.layer0_h.0.weight', 'feature_extractor.layer3_o.0.2.bn2.running_var', 'head_hm_obj.deconv_layers.0.weight',
+              'encoder_hand.project.weight', 'denoiser_obj.head.head.2.bias'):
+        assert k in changed, k
+    assert not any(k.startswith(('head_mano', 'cross_', 'head_physics')) for k in changed)      # not on this step's path
+    assert all(np.isfinite(list(h.values())).all() for h in hist) and set(hist[0]) >= {'total_loss', 'diff_hand_loss', 'hm_obj_loss'}

@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""End-to-end training step: images/s of forward + backward + AdamW on synthetic batches.
+
+    python train.py --steps 10 [--bs 64 --repeat_num 20]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P train.py --gpus N
+
+One step = the reference's ``accel.backward(loss) + optimizer.step()`` (lib/engine/train_diff_hand_obj.py:169-199) with the loss
+restricted to diff_hand + diff_obj + hm_hand + hm_obj (lib/model/VPHO.py:190-195): training-mode two-branch ResNet-50/FPN,
+RoIAlign, heat-map heads and re-alignment, the two encoders, repeat_num DSM draws per score network, the whole backward,
+one all-reduce of the flat gradient buffer (RCCL) under data parallelism, AdamW on all 513 tensors.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--bs', type=int, default=64)
+    ap.add_argument('--repeat_num', type=int, default=20)
+    ap.add_argument('--breakdown', action='store_true', help='also time forward+backward and the optimiser separately')
+    args = ap.parse_args()
+    sys.argv = sys.argv[:1]
+    import torch
+    import torch.distributed as dist
+    from vpho_amd.assets import synthetic_assets
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_state_dict, synth_batch
+    from vpho_amd.train_step import DiffusionTrainStep
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assets = synthetic_assets(0)
+    sd = synth_state_dict(vpho_net(assets), seed=1)
+    step = DiffusionTrainStep(sd, dev)
+    bs = args.bs
+    data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth_batch(bs, assets, seed=11, rank=rank).items()}
+    g = torch.Generator().manual_seed(100 + rank)
+    data['hm_hand'] = (torch.rand(bs, 21, 64, 64, generator=g) * 0.2).to(dev)
+    data['hm_obj'] = (torch.rand(bs, 27, 64, 64, generator=g) * 0.2).to(dev)
+    gt_h, gt_o = (torch.randn(bs, 96, generator=g) * 0.5).to(dev), (torch.randn(bs, 9, generator=g) * 0.5).to(dev)
+
+    first = None
+    for _ in range(args.warmup):
+        L = step.step(data, gt_h, gt_o, repeat_num=args.repeat_num)
+        first = first or {k: float(v) for k, v in L.items()}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        L = step.step(data, gt_h, gt_o, repeat_num=args.repeat_num)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    res = {'metric': 'end-to-end training images/s (diffusion + heat-map losses, all modules on the path trained)',
+           'value': world * args.steps * bs / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
+           'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
+           'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),
+           'loss_first': first, 'loss_last': {k: float(v) for k, v in L.items()}}
+    if args.breakdown:
+        draws = dict(t_h=torch.rand(args.repeat_num, bs, device=dev) * 0.99 + 0.01, z_h=torch.randn(args.repeat_num, bs, 96, device=dev),
+                     t_o=torch.rand(args.repeat_num, bs, device=dev) * 0.99 + 0.01, z_o=torch.randn(args.repeat_num, bs, 9, device=dev))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step.loss_and_grads(data, gt_h, gt_o, draws)
+        torch.cuda.synchronize()
+        res['ms_forward_backward'] = 1e3 * (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step.fpn.forward(data['rgb'])
+        torch.cuda.synchronize()
+        res['ms_backbone_forward'] = 1e3 * (time.perf_counter() - t0) / 3
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,9 +58,41 @@ class Trainer:
             model.load_state_dict(synth_state_dict(model, seed=1))
         return model.to(self.device).eval()
 
+    def _synthetic_targets(self, bs, i):
+        g = torch.Generator().manual_seed(int(self.cfg.random_seed + 7919 * i + self.rank))
+        rot = torch.linalg.qr(torch.randn(bs, 17, 3, 3, generator=g))[0]                   # synthetic ground truth: random rotations
+        gt_hand = rot[:, :16, :2, :].reshape(bs, 96).to(self.device)                       # 16 x rot6d (mano_aa_to_6D(...)[..., :-10])
+        gt_obj = torch.cat([rot[:, 16, :2, :].reshape(bs, 6), torch.randn(bs, 3, generator=g) * 0.05], -1).to(self.device)
+        return gt_hand, gt_obj, g
+
+    def run_full(self, n_batches=None):
+        """End-to-end training on the diffusion + heat-map losses over synthetic batches (train_diff_hand_obj.py:169-199 with the
+        loss restricted to diff_hand + diff_obj + hm_hand + hm_obj, see train_step.DiffusionTrainStep): backbone, heat-map heads,
+        encoders and score networks are all updated.  Returns the per-batch loss dicts (floats)."""
+        from .train_step import DiffusionTrainStep
+        cfg, bs = self.cfg, self.cfg.batch_size
+        n_batches = cfg.num_batches if n_batches is None else n_batches
+        step = DiffusionTrainStep(self.model.state_dict(), self.device)
+        hist = []
+        for i in range(n_batches):
+            batch = {k: (v.to(self.device) if torch.is_tensor(v) else v)
+                     for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
+            gt_hand, gt_obj, g = self._synthetic_targets(bs, i)
+            batch['hm_hand'] = (torch.rand(bs, 21, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
+            batch['hm_obj'] = (torch.rand(bs, 27, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
+            L = step.step(batch, gt_hand, gt_obj)
+            hist.append({k: float(v) for k, v in L.items()})
+            if self.rank == 0 and i % max(1, getattr(cfg, 'print_freq', 10)) == 0:
+                print(f'[{i:04d}/{n_batches}] ' + '  '.join(f'{k.replace("_loss", "")} {v:.3e}' for k, v in hist[-1].items()))
+        self.model.load_state_dict(step.state_dict(), strict=False)
+        return hist
+
     def run(self, n_batches=None):
-        """Score-network training on frozen features over synthetic batches (train_diff_hand_obj.py:169-199 restricted to
-        ``denoiser_hand.*`` / ``denoiser_obj.*``; VPHO.py:190-191).  Returns the per-batch (hand, object) losses."""
+        if getattr(self.cfg, 'train_scope', 'full') == 'full':
+            return self.run_full(n_batches)
+        return self.run_score(n_batches)
+
+    def run_score(self, n_batches=None):
         from .model.engine import Engine
         from .train_score import ScoreTrainer
         cfg, bs = self.cfg, self.cfg.eval_batch_size
@@ -74,10 +106,7 @@ class Trainer:
                      for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
             with torch.no_grad():
                 f = eng.features(batch)
-            g = torch.Generator().manual_seed(int(cfg.random_seed + 7919 * i + self.rank))
-            rot = torch.linalg.qr(torch.randn(bs, 17, 3, 3, generator=g))[0]               # synthetic ground truth: random rotations
-            gt_hand = rot[:, :16, :2, :].reshape(bs, 96).to(self.device)                   # 16 x rot6d (mano_aa_to_6D(...)[..., :-10])
-            gt_obj = torch.cat([rot[:, 16, :2, :].reshape(bs, 6), torch.randn(bs, 3, generator=g) * 0.05], -1).to(self.device)
+            gt_hand, gt_obj, _ = self._synthetic_targets(bs, i)
             lh, _ = hand.step(f['encoding_hand'], gt_hand, repeat_num=getattr(cfg, 'repeat_num', 20))
             lo, _ = obj.step(f['encoding_obj'], gt_obj, repeat_num=getattr(cfg, 'repeat_num', 20))
             losses.append((float(lh), float(lo)))
