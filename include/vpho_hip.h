@@ -307,8 +307,9 @@ int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, lo
                           void* stream);
 /* dx = y > 0 ? dy : 0 on [rows][cols] slices with leading dimensions (gradient through nn.ReLU given its output y) */
 int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int ld_y, long long rows, int cols, float* dx, int ld_dx, void* stream);
-/* out[c] = sum_r x[r][c] (bias gradients; fixed summation order: 8 interleaved row groups, then their sum) */
-int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* stream);
+/* out[c] = sum_r x[r][c] (bias gradients; fp64 partial sums over row chunks, combined in a fixed order).
+ * workspace: vpho_bn_workspace_bytes(cols) bytes */
+int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream);
 /* out[b][c] = sum_rep x[rep*bs + b][c_off + c]: the encoding is shared by the repeat_num draws of an image */
 int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream);
 /* y[c][r] = x[r][c] (operands of the weight-gradient GEMMs) */

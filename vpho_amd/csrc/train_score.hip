@@ -10,11 +10,25 @@
 #include "../../include/vpho_hip.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 
 namespace {
 
 constexpr float SIG_MIN = 0.01f, SIG_MAX = 50.0f;
 inline int nblk(long long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// V consecutive floats as one access (V = 4: 16 B) -- the HBM-bound kernels below move whole channel quads per thread
+template <int V>
+__device__ inline void ldv(const float* __restrict__ p, float (&o)[V]) {
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+    else o[0] = p[0];
+}
+template <int V>
+__device__ inline void stv(float* __restrict__ p, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else p[0] = v[0];
+}
 
 // rows r = rep * bs + b:  std = sigma_min (sigma_max / sigma_min)^t,  x_t = x0[b] + z * std,  emb = [sin, cos](t W 2 pi)
 __global__ void dsm_prepare_kernel(const float* __restrict__ gt, const float* __restrict__ t, const float* __restrict__ z,
@@ -157,26 +171,6 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, int ld_dy, const f
     dx[r * ld_dx + c] = y[r * ld_y + c] > 0.f ? dy[r * ld_dy + c] : 0.f;
 }
 
-// out[c] = sum_r x[r][c] (bias gradients): block = 32 columns x 8 row groups; a thread adds rows g, g+8, ... in order, the 8
-// partial sums are combined in a fixed order (deterministic, coalesced 128-B row segments)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, long long rows, int cols, float* __restrict__ out) {
-    __shared__ float part[8][32];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float s = 0.f;
-    if (c < cols) {
-#pragma unroll 8
-        for (long long r = g; r < rows; r += 8) s += x[r * ld + c];
-    }
-    part[g][cl] = s;
-    __syncthreads();
-    if (g == 0 && c < cols) {
-        float t = part[0][cl];
-        for (int k = 1; k < 8; ++k) t += part[k][cl];
-        out[c] = t;
-    }
-}
-
 // out[b][c] = sum_rep x[rep*bs + b][c_off + c]  (gradient w.r.t. the image encoding, shared by the repeat_num draws)
 __global__ void sum_repeats_kernel(const float* __restrict__ x, int ld, int c_off, int bs, int reps, int cols, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,28 +233,94 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colArgs a) {
 // channels x 8 row groups over a chunk of rows, fp64 partials [chunk][C] combined in a fixed order by the finishing kernel.
 // mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy * xhat) with xhat = (x - mean) * invstd
 struct BnRedArgs { const float* x; const float* dy; const float* mean; const float* invstd; long long rows; int C, ld, mode, rows_per_chunk; double* part; };
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnRedArgs a) {
-    __shared__ double p0[8][32], p1[8][32];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+// block = 8 column groups of V channels x 32 row groups over one chunk of rows; a thread walks rows g, g+32, ... of its chunk with
+// four loads in flight, fp64 partial sums; the 32 row groups are combined in a fixed order.  mode 2: plain column sum (s0 only).
+template <int V>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const BnRedArgs a) {
+    __shared__ double p0[32][8 * V], p1[32][8 * V];
+    const int cq = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int c = (blockIdx.x * 8 + cq) * V;
     const long long r0 = (long long)blockIdx.y * a.rows_per_chunk, r1 = r0 + a.rows_per_chunk < a.rows ? r0 + a.rows_per_chunk : a.rows;
-    double s0 = 0.0, s1 = 0.0;
-    if (c < a.C) {
-        const float mu = a.mode ? a.mean[c] : 0.f, is = a.mode ? a.invstd[c] : 0.f;
-        for (long long r = r0 + g; r < r1; r += 8) {
-            const float xv = a.x[r * a.ld + c];
-            if (a.mode == 0) { s0 += (double)xv; s1 += (double)xv * (double)xv; }
-            else { const float d = a.dy[r * a.ld + c]; s0 += (double)d; s1 += (double)d * (double)((xv - mu) * is); }
+    double s0[V], s1[V];
+    float mu[V], is[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { s0[v] = 0.0; s1[v] = 0.0; mu[v] = 0.f; is[v] = 0.f; }
+    const bool live = c < a.C;                           // C % V == 0 on the vector path, so a live thread owns V valid channels
+    if (live && a.mode == 1) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) { mu[v] = a.mean[c + v]; is[v] = a.invstd[c + v]; }
+    }
+    if (live) {
+        for (long long r = r0 + g; r < r1; r += 128) {
+            float xv[4][V], dv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + 32 * u;
+                const bool ok = rr < r1;
+#pragma unroll
+                for (int v = 0; v < V; ++v) { xv[u][v] = 0.f; dv[u][v] = 0.f; }
+                if (ok) {
+                    ldv<V>(a.x + rr * a.ld + c, xv[u]);
+                    if (a.mode == 1) ldv<V>(a.dy + rr * a.ld + c, dv[u]);
+                }
+                if (!ok && a.mode == 1) {                 // padding rows must not contribute (x - mean) terms
+#pragma unroll
+                    for (int v = 0; v < V; ++v) xv[u][v] = mu[v];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    if (a.mode == 0) { s0[v] += (double)xv[u][v]; s1[v] += (double)xv[u][v] * (double)xv[u][v]; }
+                    else if (a.mode == 1) { s0[v] += (double)dv[u][v]; s1[v] += (double)dv[u][v] * (double)((xv[u][v] - mu[v]) * is[v]); }
+                    else s0[v] += (double)xv[u][v];
+                }
+            }
         }
     }
-    p0[g][cl] = s0; p1[g][cl] = s1;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { p0[g][cq * V + v] = s0[v]; p1[g][cq * V + v] = s1[v]; }
     __syncthreads();
-    if (g == 0 && c < a.C) {
-        double t0 = p0[0][cl], t1 = p1[0][cl];
-        for (int k = 1; k < 8; ++k) { t0 += p0[k][cl]; t1 += p1[k][cl]; }
-        a.part[((long long)blockIdx.y * 2) * a.C + c] = t0;
-        a.part[((long long)blockIdx.y * 2 + 1) * a.C + c] = t1;
+    if (threadIdx.x < 8 * V) {
+        const int cc = blockIdx.x * 8 * V + threadIdx.x;
+        if (cc < a.C) {
+            double t0 = p0[0][threadIdx.x], t1 = p1[0][threadIdx.x];
+            for (int k = 1; k < 32; ++k) { t0 += p0[k][threadIdx.x]; t1 += p1[k][threadIdx.x]; }
+            if (a.mode == 2) a.part[(long long)blockIdx.y * a.C + cc] = t0;
+            else {
+                a.part[((long long)blockIdx.y * 2) * a.C + cc] = t0;
+                a.part[((long long)blockIdx.y * 2 + 1) * a.C + cc] = t1;
+            }
+        }
     }
+}
+__global__ void colsum_finish_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += part[(long long)k * C + c];
+    out[c] = (float)s;
+}
+// chunking of a [rows][C] column reduction: enough (column block, row chunk) workgroups to fill 256 CUs several times over,
+// at most 256 chunks (the workspace holds 256 x 2 x C doubles), at least 32 rows per chunk (one per row group)
+int col_chunks(long long rows, int C, int V, int* rows_per_chunk) {
+    const int colblocks = (C + 8 * V - 1) / (8 * V);
+    long long chunks = std::max(1, 2048 / colblocks);
+    chunks = std::min<long long>(std::min<long long>(chunks, 256), (rows + 31) / 32);
+    if (chunks < 1) chunks = 1;
+    *rows_per_chunk = (int)((rows + chunks - 1) / chunks);
+    return (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
+}
+// launches the column reduction; returns the number of chunks written to the workspace
+int launch_col_reduce(BnRedArgs a, hipStream_t s) {
+    const bool vec = a.C % 4 == 0 && a.ld % 4 == 0 && aligned16(a.x) && (a.mode != 1 || aligned16(a.dy));
+    const int V = vec ? 4 : 1;
+    const int chunks = col_chunks(a.rows, a.C, V, &a.rows_per_chunk);
+    const dim3 grid((a.C + 8 * V - 1) / (8 * V), chunks);
+    if (vec) hipLaunchKernelGGL(col_reduce_kernel<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, a);
+    return chunks;
 }
 // statistics: mean, biased variance -> invstd = 1/sqrt(var + eps); running stats with the unbiased variance (torch semantics)
 __global__ void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
@@ -287,41 +347,61 @@ __global__ void bn_finish_grads_kernel(const double* __restrict__ part, int chun
     for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2) * C + c]; ss += part[((long long)k * 2 + 1) * C + c]; }
     dbeta[c] = (float)s; dgamma[c] = (float)ss;
 }
-// y = lrelu((x - mean) * invstd * gamma + beta, slope)
+// y = lrelu((x - mean) * invstd * gamma + beta, slope); a thread handles V consecutive channels of a row
+template <int V>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, long long rows, int C, int ld, float slope, float* __restrict__ y) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const long long r = i / C;
-    const int c = (int)(i - r * C);
-    const float v = (x[r * ld + c] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    y[r * ld + c] = v > 0.f ? v : v * slope;
+    const int cq = C / V;
+    if (i >= rows * cq) return;
+    const long long r = i / cq;
+    const int c = (int)(i - r * cq) * V;
+    float xv[V], m[V], is[V], ga[V], be[V], o[V];
+    ldv<V>(x + r * ld + c, xv); ldv<V>(mean + c, m); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga); ldv<V>(beta + c, be);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { const float t = (xv[v] - m[v]) * is[v] * ga[v] + be[v]; o[v] = t > 0.f ? t : t * slope; }
+    stv<V>(y + r * ld + c, o);
 }
 // dx = gamma * invstd / rows * (rows * dy - dbeta - xhat * dgamma)
+template <int V>
 __global__ void bn_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ invstd,
                                    const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                    long long rows, int C, int ld, float* __restrict__ dx) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const long long r = i / C;
-    const int c = (int)(i - r * C);
-    const float xh = (x[r * ld + c] - mean[c]) * invstd[c];
+    const int cq = C / V;
+    if (i >= rows * cq) return;
+    const long long r = i / cq;
+    const int c = (int)(i - r * cq) * V;
+    float xv[V], dv[V], mu[V], is[V], ga[V], db[V], dg[V], o[V];
+    ldv<V>(x + r * ld + c, xv); ldv<V>(dy + r * ld + c, dv); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga);
+    ldv<V>(dbeta + c, db); ldv<V>(dgamma + c, dg);
     const float m = (float)rows;
-    dx[r * ld + c] = gamma[c] * invstd[c] / m * (m * dy[r * ld + c] - dbeta[c] - xh * dgamma[c]);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { const float xh = (xv[v] - mu[v]) * is[v]; o[v] = ga[v] * is[v] / m * (m * dv[v] - db[v] - xh * dg[v]); }
+    stv<V>(dx + r * ld + c, o);
 }
 // dx = y > 0 ? dy : dy * slope  (LeakyReLU backward given its output; slope > 0 keeps the sign of the input)
+template <int V>
 __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n, float slope, float* __restrict__ dx) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
-    dx[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+    float d[V], yv[V], o[V];
+    ldv<V>(dy + i, d); ldv<V>(y + i, yv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) o[v] = yv[v] > 0.f ? d[v] : d[v] * slope;
+    stv<V>(dx + i, o);
 }
 
 // y = lrelu(a + b, slope)  (residual add of a bottleneck; slope 1 = plain sum, e.g. of two input gradients)
+template <int V>
 __global__ void add_lrelu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float slope, float* __restrict__ y) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
-    const float v = a[i] + b[i];
-    y[i] = v > 0.f ? v : v * slope;
+    float av[V], bv[V], o[V];
+    ldv<V>(a + i, av); ldv<V>(b + i, bv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { const float t = av[v] + bv[v]; o[v] = t > 0.f ? t : t * slope; }
+    stv<V>(y + i, o);
 }
 
 // ------------------------------------------------------------------------------------------------ pooling / resize backward
@@ -528,10 +608,11 @@ extern "C" int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int
     return vpho::check_launch("relu_bwd_kernel");
 }
 
-extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* stream) {
-    VPHO_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out);
-    return vpho::check_launch("colsum_kernel");
+extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream) {
+    VPHO_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
+    const int chunks = launch_col_reduce(BnRedArgs{x, nullptr, nullptr, nullptr, rows, cols, ld, 2, 0, (double*)workspace}, (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 64)), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
+    return vpho::check_launch("colsum kernels");
 }
 
 extern "C" int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream) {
@@ -567,15 +648,6 @@ extern "C" int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, i
     return vpho::check_launch("im2col_t_kernel");
 }
 
-namespace {
-int bn_chunks(long long rows, int* rows_per_chunk) {
-    int chunks = (int)std::min<long long>(256, (rows + 2047) / 2048);
-    if (chunks < 1) chunks = 1;
-    *rows_per_chunk = (int)((rows + chunks - 1) / chunks);
-    return (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
-}
-}  // namespace
-
 extern "C" long long vpho_bn_workspace_bytes(int C) { return C > 0 ? (long long)256 * 2 * C * 8 : -1; }
 
 extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
@@ -584,13 +656,13 @@ extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, 
     VPHO_REQUIRE(x && gamma && beta && save_mean && save_invstd && y && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_forward_f32: bad argument");
     VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_f32: running_mean/var must come together");
     hipStream_t s = (hipStream_t)stream;
-    int rpc;
-    const int chunks = bn_chunks(rows, &rpc);
-    BnRedArgs a{x, nullptr, nullptr, nullptr, rows, C, ld, 0, rpc, (double*)workspace};
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 31) / 32, chunks), dim3(256), 0, s, a);
+    const int chunks = launch_col_reduce(BnRedArgs{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace}, s);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
                        running_mean, running_var);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
+    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd))
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
     return vpho::check_launch("bn_train_forward kernels");
 }
 
@@ -598,24 +670,27 @@ extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long 
                                           const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream) {
     VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_backward_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    int rpc;
-    const int chunks = bn_chunks(rows, &rpc);
-    BnRedArgs a{x, dy, save_mean, save_invstd, rows, C, ld, 1, rpc, (double*)workspace};
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 31) / 32, chunks), dim3(256), 0, s, a);
+    const int chunks = launch_col_reduce(BnRedArgs{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace}, s);
     hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
-    hipLaunchKernelGGL(bn_backward_kernel, dim3(nblk(rows * C)), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
+    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
+        aligned16(dbeta) && aligned16(dgamma))
+        hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
+    else
+        hipLaunchKernelGGL(bn_backward_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
     return vpho::check_launch("bn_train_backward kernels");
 }
 
 extern "C" int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream) {
     VPHO_REQUIRE(dy && y && dx && n > 0, "vpho_lrelu_bwd_f32: bad argument");
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope, dx);
+    if (n % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(dx)) hipLaunchKernelGGL(lrelu_bwd_kernel<4>, dim3(nblk(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope, dx);
+    else hipLaunchKernelGGL(lrelu_bwd_kernel<1>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope, dx);
     return vpho::check_launch("lrelu_bwd_kernel");
 }
 
 extern "C" int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream) {
     VPHO_REQUIRE(a && b && y && n > 0, "vpho_add_lrelu_f32: bad argument");
-    hipLaunchKernelGGL(add_lrelu_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
+    if (n % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(y)) hipLaunchKernelGGL(add_lrelu_kernel<4>, dim3(nblk(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
+    else hipLaunchKernelGGL(add_lrelu_kernel<1>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
     return vpho::check_launch("add_lrelu_kernel");
 }
 

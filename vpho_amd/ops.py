@@ -661,7 +661,8 @@ def relu_bwd(dy, dy_off, ld_dy, y, y_off, ld_y, rows, cols):
 def colsum(x):
     rows, cols = x.shape
     out = _new((cols,), x)
-    _call('vpho_colsum_f32', _f32(x), I(cols), LL(rows), I(cols), _f32(out))
+    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(cols)), dtype=torch.uint8, device=x.device)
+    _call('vpho_colsum_f32', _f32(x), I(cols), LL(rows), I(cols), _f32(out), _ptr(ws))
     return out
 
 
