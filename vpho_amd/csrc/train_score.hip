@@ -295,12 +295,30 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const BnRedArgs a) {
         }
     }
 }
-__global__ void colsum_finish_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += part[(long long)k * C + c];
-    out[c] = (float)s;
+// sum over the row chunks of one or two partial-sum planes: block = 32 channels x 8 chunk groups (chunks g, g+8, ... per thread,
+// the 8 group sums combined in a fixed order); the result is valid in the threads with g == 0
+template <int PLANES>
+__device__ inline bool finish_sums(const double* __restrict__ part, int chunks, int C, int& c, double& s0, double& s1) {
+    __shared__ double q0[8][32], q1[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    c = blockIdx.x * 32 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        for (int k = g; k < chunks; k += 8) {
+            a0 += part[((long long)k * PLANES) * C + c];
+            if (PLANES == 2) a1 += part[((long long)k * PLANES + 1) * C + c];
+        }
+    }
+    q0[g][cl] = a0; q1[g][cl] = a1;
+    __syncthreads();
+    if (g != 0 || c >= C) return false;
+    s0 = q0[0][cl]; s1 = q1[0][cl];
+    for (int k = 1; k < 8; ++k) { s0 += q0[k][cl]; s1 += q1[k][cl]; }
+    return true;
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ out) {
+    int c; double s, unused;
+    if (finish_sums<1>(part, chunks, C, c, s, unused)) out[c] = (float)s;
 }
 // chunking of a [rows][C] column reduction: enough (column block, row chunk) workgroups to fill 256 CUs several times over,
 // at most 256 chunks (the workspace holds 256 x 2 x C doubles), at least 32 rows per chunk (one per row group)
@@ -323,12 +341,11 @@ int launch_col_reduce(BnRedArgs a, hipStream_t s) {
     return chunks;
 }
 // statistics: mean, biased variance -> invstd = 1/sqrt(var + eps); running stats with the unbiased variance (torch semantics)
-__global__ void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
-                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2) * C + c]; ss += part[((long long)k * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
+                                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+    int c; double s, ss;
+    if (!finish_sums<2>(part, chunks, C, c, s, ss)) return;
     const double m = s / (double)rows;
     double var = ss / (double)rows - m * m;
     if (var < 0.0) var = 0.0;
@@ -340,12 +357,9 @@ __global__ void bn_finish_stats_kernel(const double* __restrict__ part, int chun
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
 }
-__global__ void bn_finish_grads_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2) * C + c]; ss += part[((long long)k * 2 + 1) * C + c]; }
-    dbeta[c] = (float)s; dgamma[c] = (float)ss;
+__global__ __launch_bounds__(256) void bn_finish_grads_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    int c; double s, ss;
+    if (finish_sums<2>(part, chunks, C, c, s, ss)) { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
 }
 // y = lrelu((x - mean) * invstd * gamma + beta, slope); a thread handles V consecutive channels of a row
 template <int V>
@@ -611,7 +625,7 @@ extern "C" int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int
 extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream) {
     VPHO_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
     const int chunks = launch_col_reduce(BnRedArgs{x, nullptr, nullptr, nullptr, rows, cols, ld, 2, 0, (double*)workspace}, (hipStream_t)stream);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 64)), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
     return vpho::check_launch("colsum kernels");
 }
 
@@ -657,7 +671,7 @@ extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, 
     VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_f32: running_mean/var must come together");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = launch_col_reduce(BnRedArgs{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace}, s);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
                        running_mean, running_var);
     if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd))
         hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
@@ -671,7 +685,7 @@ extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long 
     VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_backward_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = launch_col_reduce(BnRedArgs{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace}, s);
-    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 64)), dim3(64), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
     if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
         aligned16(dbeta) && aligned16(dgamma))
         hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
