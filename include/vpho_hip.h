@@ -297,6 +297,15 @@ int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, cons
  * dout = d loss / d (un-normalised head output) [rows][D]; loss: one double on the device; partial_ws: >= 1024 doubles */
 int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
                       float* dout, double* loss, double* partial_ws, int partial_cap, void* stream);
+/* Weight gradient of an NHWC convolution without materialised im2col / transposes (torch.nn.functional.conv2d's autograd for
+ * every nn.Conv2d of lib/model/backbone_FPN_HFL.py, encoding.py, head_inplane.py under lib/engine/train_diff_hand_obj.py:181-182):
+ * dw[co][(r*KW+s)*Cin + ci] = sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*stride+r-pad_y, ox*stride+s-pad_x, ci]   (zero outside the image)
+ * in the packed layout of the forward weights.  x [N][H][W][x_ld], dy [N][OH][OW][dy_ld]; Cin, Cout and both leading dimensions
+ * multiples of 4, pointers 16-byte aligned.  The pixel range is reduced in slices (fp32 MFMA accumulation inside a slice, slices
+ * added in ascending order): workspace of vpho_conv2d_wgrad_workspace_bytes(...) bytes (may be 0 -> workspace may be NULL). */
+long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
+                               int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream);
 /* JointsMSELoss (lib/model/head_inplane.py:191-203: nn.MSELoss, mean over all elements) times its loss weight
  * (VPHO.py:214-219): loss[0] = weight * mean((pd - gt)^2) in fp64, grad = weight * 2 (pd - gt) / n.  partial_ws: >= partial_cap doubles */
 int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws, int partial_cap,

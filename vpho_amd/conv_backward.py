@@ -18,6 +18,11 @@ import torch
 from . import ops
 
 
+import os
+
+USE_TN_WGRAD = os.environ.get('VPHO_WGRAD_IM2COL', '0') == '0'      # tuning aid: 1 = the explicit im2col + transpose path for every shape
+
+
 def _flip_transpose(w_packed, cout, cin, kh, kw):
     """(Cout, KH*KW*Cin) -> (Cin, KH*KW*Cout) with both spatial axes reversed"""
     return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
@@ -70,6 +75,9 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None):
     """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights."""
     N, OH, OW, cout = dy.shape
+    c_in = x.shape[-1] if cin is None else cin
+    if USE_TN_WGRAD and c_in % 4 == 0 and c_in >= 32 and cout % 4 == 0 and x.shape[-1] % 4 == 0:
+        return ops.conv2d_wgrad_nhwc(x, dy.contiguous(), kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, cin=cin)
     xg_t = ops.im2col_t(x, kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, OH, OW, cin=cin)   # (kh*kw*cin, P4)
     dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns
     kc, P4 = xg_t.shape

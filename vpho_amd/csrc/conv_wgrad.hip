@@ -1,0 +1,201 @@
+// Weight gradient of the NHWC convolutions as ONE implicit "TN" GEMM on the fp32 matrix cores:
+//     dW[co][(r,s),ci] = sum over output pixels p of dY[p][co] * x[n(p), oy(p)*stride + r - pad_y, ox(p)*stride + s - pad_x, ci]
+// -- torch.nn.functional.conv2d's weight gradient, what loss.backward() computes for every nn.Conv2d of
+// lib/model/backbone_FPN_HFL.py, encoding.py and head_inplane.py (lib/engine/train_diff_hand_obj.py:181-182).
+//
+// The reduction runs over the pixel index, which is the SLOW index of both NHWC operands, so the tiles are staged k-major:
+// a stage is 32 pixels x (BM output channels of dY | BN input channels of the tap-shifted x), every pixel row one contiguous
+// 16-byte-chunked channel run moved by `global_load_lds_dwordx4` (out-of-image taps, pixel and channel tails read a zero
+// page).  The MFMA fragments are then single dwords at [k][lane & 31]: half-wave-contiguous ds_read_b32, conflict-free
+// without padding or swizzle.  A workgroup owns one (Cout tile, Cin tile, tap) for one slice of the pixel range (split-K over
+// blockIdx.y); slices are summed in a fixed order by a second kernel.  No im2col / transposed copies are materialised.
+#include "common.h"
+#include "../../include/vpho_hip.h"
+#include <algorithm>
+#include <cstdint>
+
+namespace {
+
+constexpr int BK = 32;
+__device__ __attribute__((aligned(256))) float g_wgrad_zero[64];
+
+struct WgArgs {
+    const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
+    int N, H, W, Cin, x_ld, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x;
+    int M, K, tiles_n, taps, ntiles, m_chunk;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int A_INSTR = BK * BM / 256, B_INSTR = BK * BN / 256;         // 1024-byte wave instructions per stage
+    constexpr int A_LD = A_INSTR / NW, B_LD = B_INSTR / NW;
+    constexpr int A_CPR = BM / 4, B_CPR = BN / 4;                           // 16-byte chunks per tile row
+    static_assert(TM >= 1 && TN >= 1 && A_INSTR % NW == 0 && B_INSTR % NW == 0 && A_LD >= 1 && B_LD >= 1, "tile/wave layout");
+    static_assert(64 % A_CPR == 0 && 64 % B_CPR == 0, "a wave instruction must cover whole tile rows");
+    constexpr int TILE = (BM + BN) * BK;
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+
+    const int per_xcd = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);          // consecutive tiles (= taps of one tile pair) share an XCD's L2
+    if (lb >= a.ntiles) return;
+    const int tap = lb % a.taps, t2 = lb / a.taps;
+    const int tile_n = t2 % a.tiles_n, tile_m = t2 / a.tiles_n;
+    const int co0 = tile_m * BM, c0 = tile_n * BN;
+    const int tr = tap / a.KW, ts = tap - tr * a.KW;
+    const int m_begin = blockIdx.y * a.m_chunk;
+    const int m_end = m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ohw = a.OH * a.OW;
+
+    // fill roles of this lane: A_LD rows of the dY tile, B_LD rows of the x tile (one 16-byte chunk of each)
+    int a_row[A_LD], b_row[B_LD];
+    const int a_col = co0 + 4 * (lane % A_CPR), b_col = c0 + 4 * (lane % B_CPR);
+    const bool a_ok = a_col < a.Cout, b_ok = b_col < a.Cin;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_row[j] = (wave + NW * j) * (64 / A_CPR) + lane / A_CPR;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) b_row[j] = (wave + NW * j) * (64 / B_CPR) + lane / B_CPR;
+    const float* zero = g_wgrad_zero + 4 * (lane & 15);
+
+    auto fill = [&](int buf, int kt) {
+        float* As = smem + buf * TILE;
+        float* Bs = As + BM * BK;
+        const int mb = m_begin + kt * BK;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int m = mb + a_row[j];
+            const float* src = (a_ok && m < m_end) ? a.dy + (long long)m * a.dy_ld + a_col : zero;
+            __builtin_amdgcn_global_load_lds(src, As + (wave + NW * j) * 256, 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int m = mb + b_row[j];
+            const float* src = zero;
+            if (b_ok && m < m_end) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                const unsigned iy = (unsigned)(oy * a.stride + tr - a.pad_y), ix = (unsigned)(ox * a.stride + ts - a.pad_x);
+                if (iy < (unsigned)a.H && ix < (unsigned)a.W) src = a.x + ((long long)(n * a.H + (int)iy) * a.W + (int)ix) * a.x_ld + b_col;
+            }
+            __builtin_amdgcn_global_load_lds(src, Bs + (wave + NW * j) * 256, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (m_end - m_begin + BK - 1) / BK;
+    if (nk > 0) {
+        fill(0, 0);
+        __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fill(buf ^ 1, kt + 1);
+        const float* As = smem + buf * TILE + wm * (BM / WM) + li;
+        const float* Bs = smem + buf * TILE + BM * BK + wn * (BN / WN) + li;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[(2 * kk + lh) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[(2 * kk + lh) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* out = a.out + (long long)blockIdx.y * a.Cout * a.K + (long long)tap * a.Cin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = c0 + wn * (BN / WN) + j * 32 + li;
+        if (col >= a.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row < a.Cout) out[(long long)row * a.K + col] = acc[i][j][e];
+            }
+    }
+}
+
+// out[i] = sum_s part[s][i], s ascending (n multiple of 4, 16-byte aligned)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long long n4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(part)[(long long)k * n4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+struct WgPlan { int bm, bn, tiles_m, tiles_n, splits, m_chunk; };
+
+WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
+    WgPlan p;
+    const bool big = Cin >= 128 && Cout >= 128;
+    p.bm = p.bn = big ? 128 : 64;
+    p.tiles_m = (Cout + p.bm - 1) / p.bm;
+    p.tiles_n = (Cin + p.bn - 1) / p.bn;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n * taps;
+    // enough workgroups for 256 CUs (2 x 128x128 or 4 x 64x64 tiles fit a CU's LDS), at least 8 stages of 32 pixels per slice
+    const long long want = big ? 768 : 1536;
+    long long splits = std::max<long long>(1, (want + tiles - 1) / tiles);
+    splits = std::min<long long>(splits, std::max<long long>(1, M / (8 * BK)));
+    splits = std::min<long long>(splits, 256);
+    long long chunk = (M + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    p.m_chunk = (int)chunk;
+    p.splits = (int)((M + chunk - 1) / chunk);
+    return p;
+}
+
+}  // namespace
+
+extern "C" long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return -1;
+    const WgPlan p = plan_wgrad((long long)N * OH * OW, Cin, Cout, KH * KW);
+    return p.splits > 1 ? (long long)p.splits * Cout * KH * KW * Cin * 4 : 0;
+}
+
+extern "C" int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
+                                          int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream) {
+    VPHO_REQUIRE(x && dy && dw, "vpho_conv2d_wgrad_nhwc_f32: null tensor");
+    VPHO_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && OH > 0 && OW > 0, "vpho_conv2d_wgrad_nhwc_f32: non-positive dimension");
+    VPHO_REQUIRE(Cin % 4 == 0 && x_ld % 4 == 0 && x_ld >= Cin && Cout % 4 == 0 && dy_ld % 4 == 0 && dy_ld >= Cout,
+                 "vpho_conv2d_wgrad_nhwc_f32: Cin=%d x_ld=%d Cout=%d dy_ld=%d must be multiples of 4 (ld >= channels)", Cin, x_ld, Cout, dy_ld);
+    VPHO_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dw & 15) == 0, "vpho_conv2d_wgrad_nhwc_f32: x/dy/dw must be 16-byte aligned");
+    VPHO_REQUIRE((OH - 1) * stride - pad_y < H && (OW - 1) * stride - pad_x < W, "vpho_conv2d_wgrad_nhwc_f32: output larger than input allows");
+    const long long M = (long long)N * OH * OW;
+    VPHO_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31), "vpho_conv2d_wgrad_nhwc_f32: too many pixels");
+    const int taps = KH * KW;
+    const WgPlan p = plan_wgrad(M, Cin, Cout, taps);
+    VPHO_REQUIRE(p.splits == 1 || (workspace && ((uintptr_t)workspace & 15) == 0), "vpho_conv2d_wgrad_nhwc_f32: %d pixel slices need the workspace", p.splits);
+    WgArgs a;
+    a.x = x; a.dy = dy; a.out = p.splits > 1 ? (float*)workspace : dw;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_ld = dy_ld;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
+    a.M = (int)M; a.K = taps * Cin; a.tiles_n = p.tiles_n; a.taps = taps; a.ntiles = p.tiles_m * p.tiles_n * taps; a.m_chunk = p.m_chunk;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((a.ntiles + 7) / 8 * 8, p.splits);
+    if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
+    if (p.splits > 1) {
+        const long long n4 = (long long)Cout * a.K / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, p.splits, n4, dw);
+    }
+    return vpho::check_launch("conv_wgrad_tn_kernel");
+}

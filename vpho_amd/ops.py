@@ -19,6 +19,7 @@ lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
 lib.vpho_obj_metrics_workspace_bytes.restype = C.c_longlong
 lib.vpho_bn_workspace_bytes.restype = C.c_longlong
+lib.vpho_conv2d_wgrad_workspace_bytes.restype = C.c_longlong
 
 
 class VphoError(RuntimeError):
@@ -691,6 +692,19 @@ def im2col_t(x, kh, kw, stride, pad_y, pad_x, OH, OW, cin=None):
     out = _new((kh * kw * cin, ldo), x)
     _call('vpho_im2col_t_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), I(kh), I(kw), I(stride), I(pad_y), I(pad_x), I(OH), I(OW), _f32(out), LL(ldo))
     return out
+
+
+def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None):
+    """x (N,H,W,ld), dy (N,OH,OW,Cout) contiguous -> dW (Cout, kh*kw*cin) packed; implicit TN GEMM (csrc/conv_wgrad.hip)"""
+    N, H, W, ld = x.shape
+    _, OH, OW, cout = dy.shape
+    cin = ld if cin is None else cin
+    dw = _new((cout, kh * kw * cin), x)
+    nbytes = lib.vpho_conv2d_wgrad_workspace_bytes(I(N), I(OH), I(OW), I(cin), I(cout), I(kh), I(kw))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes > 0 else None
+    _call('vpho_conv2d_wgrad_nhwc_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), _f32(dy), I(OH), I(OW), I(cout), I(cout),
+          I(kh), I(kw), I(stride), I(pad_y), I(pad_x), _f32(dw), _ptr(ws))
+    return dw
 
 
 def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0):
