@@ -21,11 +21,11 @@ def _case(N, H, W, cin, cout, k, stride, pad, seed):
 @pytest.mark.parametrize('N,H,W,cin,cout,k,stride,pad', [(2, 16, 16, 8, 12, 3, 1, 1), (3, 10, 14, 16, 8, 1, 1, 0), (2, 16, 12, 8, 16, 3, 2, 1),
                                                          (2, 8, 8, 12, 20, 1, 2, 0), (1, 9, 9, 4, 8, 2, 1, 0), (1, 12, 12, 4, 8, 7, 1, 3),
                                                          (4, 32, 32, 64, 64, 3, 1, 1), (2, 32, 32, 128, 64, 3, 2, 1),
-                                                         # implicit TN weight-gradient kernel (Cin >= 32): ragged channel tails, both tile
+                                                         # implicit TN weight-gradient kernel (Cin, Cout multiples of 4; the rest take the im2col path): ragged channel tails, both tile
                                                          # sizes, strides, split pixel ranges (8x64x64 pixels), a 1-pixel-row tail
                                                          (2, 9, 11, 36, 44, 3, 1, 1), (1, 16, 16, 128, 256, 1, 1, 0), (2, 14, 14, 256, 128, 3, 1, 1),
                                                          (2, 16, 16, 160, 136, 3, 2, 1), (3, 6, 10, 64, 32, 1, 2, 0), (8, 64, 64, 64, 64, 3, 1, 1),
-                                                         (1, 1, 1, 32, 4, 1, 1, 0), (2, 8, 8, 284, 256, 1, 1, 0)])
+                                                         (1, 1, 1, 32, 4, 1, 1, 0), (2, 8, 8, 284, 256, 1, 1, 0), (2, 32, 32, 4, 64, 7, 2, 3), (2, 8, 8, 6, 10, 3, 1, 1)])
 def test_dgrad_and_wgrad_match_autograd(N, H, W, cin, cout, k, stride, pad):
     from vpho_amd import conv_backward as CB
     from vpho_amd.model.pack import pack_conv

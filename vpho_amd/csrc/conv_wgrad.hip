@@ -7,8 +7,10 @@
 // a stage is 32 pixels x (BM output channels of dY | BN input channels of the tap-shifted x), every pixel row one contiguous
 // 16-byte-chunked channel run moved by `global_load_lds_dwordx4` (out-of-image taps, pixel and channel tails read a zero
 // page).  The MFMA fragments are then single dwords at [k][lane & 31]: half-wave-contiguous ds_read_b32, conflict-free
-// without padding or swizzle.  A workgroup owns one (Cout tile, Cin tile, tap) for one slice of the pixel range (split-K over
-// blockIdx.y); slices are summed in a fixed order by a second kernel.  No im2col / transposed copies are materialised.
+// without padding or swizzle.  A workgroup owns one (Cout tile, tile of the flattened (tap, ci) axis) for one slice of the pixel
+// range (split-K over blockIdx.y); a 16-byte chunk never straddles taps (Cin % 4 == 0), so the tap is a per-lane constant and
+// narrow inputs (the 4-channel stem: 16 taps per 64-column tile) take the same path.  Slices are summed in a fixed order by a
+// second kernel.  No im2col / transposed copies are materialised.
 #include "common.h"
 #include "../../include/vpho_hip.h"
 #include <algorithm>
@@ -22,7 +24,7 @@ __device__ __attribute__((aligned(256))) float g_wgrad_zero[64];
 struct WgArgs {
     const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
     int N, H, W, Cin, x_ld, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x;
-    int M, K, tiles_n, taps, ntiles, m_chunk;
+    int M, K, tiles_n, ntiles, m_chunk;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -38,12 +40,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
 
     const int per_xcd = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);          // consecutive tiles (= taps of one tile pair) share an XCD's L2
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);          // consecutive column tiles of one Cout tile share an XCD's L2
     if (lb >= a.ntiles) return;
-    const int tap = lb % a.taps, t2 = lb / a.taps;
-    const int tile_n = t2 % a.tiles_n, tile_m = t2 / a.tiles_n;
-    const int co0 = tile_m * BM, c0 = tile_n * BN;
-    const int tr = tap / a.KW, ts = tap - tr * a.KW;
+    const int tile_n = lb % a.tiles_n, tile_m = lb / a.tiles_n;
+    const int co0 = tile_m * BM, c0 = tile_n * BN;                          // c0: column of the flattened (tap, ci) axis
     const int m_begin = blockIdx.y * a.m_chunk;
     const int m_end = m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     // fill roles of this lane: A_LD rows of the dY tile, B_LD rows of the x tile (one 16-byte chunk of each)
     int a_row[A_LD], b_row[B_LD];
     const int a_col = co0 + 4 * (lane % A_CPR), b_col = c0 + 4 * (lane % B_CPR);
-    const bool a_ok = a_col < a.Cout, b_ok = b_col < a.Cin;
+    const bool a_ok = a_col < a.Cout, b_ok = b_col < a.K;
+    const int tap = b_col / a.Cin, b_ci = b_col - tap * a.Cin;              // this lane's tap and first input channel
+    const int tr = tap / a.KW, ts = tap - tr * a.KW;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) a_row[j] = (wave + NW * j) * (64 / A_CPR) + lane / A_CPR;
 #pragma unroll
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
                 const int n = m / ohw, rem = m - n * ohw;
                 const int oy = rem / a.OW, ox = rem - oy * a.OW;
                 const unsigned iy = (unsigned)(oy * a.stride + tr - a.pad_y), ix = (unsigned)(ox * a.stride + ts - a.pad_x);
-                if (iy < (unsigned)a.H && ix < (unsigned)a.W) src = a.x + ((long long)(n * a.H + (int)iy) * a.W + (int)ix) * a.x_ld + b_col;
+                if (iy < (unsigned)a.H && ix < (unsigned)a.W) src = a.x + ((long long)(n * a.H + (int)iy) * a.W + (int)ix) * a.x_ld + b_ci;
             }
             __builtin_amdgcn_global_load_lds(src, Bs + (wave + NW * j) * 256, 16, 0, 0);
         }
@@ -118,11 +120,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
         __syncthreads();
     }
 
-    float* out = a.out + (long long)blockIdx.y * a.Cout * a.K + (long long)tap * a.Cin;
+    float* out = a.out + (long long)blockIdx.y * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = c0 + wn * (BN / WN) + j * 32 + li;
-        if (col >= a.Cin) continue;
+        if (col >= a.K) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -146,11 +148,12 @@ struct WgPlan { int bm, bn, tiles_m, tiles_n, splits, m_chunk; };
 
 WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     WgPlan p;
-    const bool big = Cin >= 128 && Cout >= 128;
+    const int K = Cin * taps;
+    const bool big = K >= 128 && Cout >= 128;
     p.bm = p.bn = big ? 128 : 64;
     p.tiles_m = (Cout + p.bm - 1) / p.bm;
-    p.tiles_n = (Cin + p.bn - 1) / p.bn;
-    const long long tiles = (long long)p.tiles_m * p.tiles_n * taps;
+    p.tiles_n = (K + p.bn - 1) / p.bn;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
     // enough workgroups for 256 CUs (2 x 128x128 or 4 x 64x64 tiles fit a CU's LDS), at least 8 stages of 32 pixels per slice
     const long long want = big ? 768 : 1536;
     long long splits = std::max<long long>(1, (want + tiles - 1) / tiles);
@@ -188,7 +191,7 @@ extern "C" int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, i
     a.x = x; a.dy = dy; a.out = p.splits > 1 ? (float*)workspace : dw;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_ld = dy_ld;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
-    a.M = (int)M; a.K = taps * Cin; a.tiles_n = p.tiles_n; a.taps = taps; a.ntiles = p.tiles_m * p.tiles_n * taps; a.m_chunk = p.m_chunk;
+    a.M = (int)M; a.K = taps * Cin; a.tiles_n = p.tiles_n; a.ntiles = p.tiles_m * p.tiles_n; a.m_chunk = p.m_chunk;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((a.ntiles + 7) / 8 * 8, p.splits);
     if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);
