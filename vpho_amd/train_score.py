@@ -31,6 +31,11 @@ def allreduce_mean_scale(flat_grad):
     return 1.0
 
 
+def _wgrad(x, dy):
+    """weight gradient of y = x W^T: dy^T x (out, in) -- the implicit TN GEMM of csrc/conv_wgrad.hip on a 1x1 'image' per row"""
+    return ops.conv2d_wgrad_nhwc(x.view(x.shape[0], 1, 1, x.shape[1]), dy.view(dy.shape[0], 1, 1, dy.shape[1]), 1, 1, 1, 0, 0)
+
+
 class ScoreTrainer:
     def __init__(self, state_dict, prefix, device, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         self.prefix, self.dev = prefix, torch.device(device)
@@ -95,20 +100,20 @@ class ScoreTrainer:
             G['head.head.2.weight'].copy_(dw2)
             G['head.head.2.bias'].copy_(db2)
             G['head.head.0.bias'].copy_(ops.colsum(dpre).view(n, 256))
-            dw1 = ops.linear(ops.transpose(dpre), ops.transpose(total))                                            # (n*256, 1408)
+            dw1 = _wgrad(total, dpre)                                                                              # (n*256, 1408)
             G['head.head.0.weight'].copy_(dw1.view(n, 256, 1408).permute(0, 2, 1))
             w1_bwd = W1.permute(1, 0, 2).reshape(1408, n * 256).contiguous()
             dtotal = ops.linear(dpre, w1_bwd)                                                                      # (M, 1408)
             dfeat = ops.sum_repeats(dtotal, 384, bs, reps, 1024)
             dtf = ops.relu_bwd(dtotal, 0, 1408, total, 0, 1408, M, 128)
-            G['t_encoder.1.weight'].copy_(ops.linear(ops.transpose(dtf), ops.transpose(emb)))
+            G['t_encoder.1.weight'].copy_(_wgrad(emb, dtf))
             G['t_encoder.1.bias'].copy_(ops.colsum(dtf))
             dq2 = ops.relu_bwd(dtotal, 128, 1408, total, 128, 1408, M, 256)
-            G['pose_encoder.2.weight'].copy_(ops.linear(ops.transpose(dq2), ops.transpose(p1)))
+            G['pose_encoder.2.weight'].copy_(_wgrad(p1, dq2))
             G['pose_encoder.2.bias'].copy_(ops.colsum(dq2))
             dp1 = ops.linear(dq2, P['pose_encoder.2.weight'].t().contiguous())
             dq1 = ops.relu_bwd(dp1, 0, 256, p1, 0, 256, M, 256)
-            G['pose_encoder.0.weight'].copy_(ops.linear(ops.transpose(dq1), ops.transpose(xt))[:, :D])
+            G['pose_encoder.0.weight'].copy_(_wgrad(xt, dq1)[:, :D])
             G['pose_encoder.0.bias'].copy_(ops.colsum(dq1))
         return loss, dfeat
 
