@@ -7,7 +7,9 @@ def timeit(f, n=5):
     f(); torch.cuda.synchronize(); t = time.time()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.time() - t) / n
-for (N, H, cin, cout, k, st) in [(64, 64, 256, 256, 3, 1), (64, 32, 128, 128, 3, 1), (64, 16, 1024, 256, 1, 1), (64, 64, 128, 128, 3, 2), (64, 16, 256, 1024, 1, 1)]:
+for (N, H, cin, cout, k, st) in [(64, 64, 256, 256, 3, 1), (64, 32, 128, 128, 3, 1), (64, 16, 1024, 256, 1, 1), (64, 64, 128, 128, 3, 2), (64, 16, 256, 1024, 1, 1),
+                                 (64, 64, 64, 64, 3, 1), (64, 64, 64, 256, 1, 1), (64, 8, 512, 512, 3, 1), (64, 8, 2048, 512, 1, 1), (64, 16, 256, 256, 3, 1),
+                                 (64, 256, 4, 64, 7, 2)]:
     pad = k // 2
     OH = (H + 2 * pad - k) // st + 1
     x = torch.randn(N, H, H, cin, device=dev); w = torch.randn(cout, k * k * cin, device=dev) * 0.05; dy = torch.randn(N, OH, OH, cout, device=dev)

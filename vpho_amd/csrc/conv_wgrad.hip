@@ -15,6 +15,7 @@
 #include "../../include/vpho_hip.h"
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -105,17 +106,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
         if (kt + 1 < nk) fill(buf ^ 1, kt + 1);
         const float* As = smem + buf * TILE + wm * (BM / WM) + li;
         const float* Bs = smem + buf * TILE + BM * BK + wn * (BN / WN) + li;
+        // the stage's fragments are read in two halves of 8 k-steps; the second half's ds_reads are in flight while the first
+        // half's MFMAs run (scheduling barriers keep the compiler from sinking the reads back next to their uses)
+        constexpr int HK = BK / 4;
+        float av[2][HK][TM], bv[2][HK][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[TM], bv[TN];
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[(2 * kk + lh) * BM + i * 32];
+            for (int kk = 0; kk < HK; ++kk) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[(2 * kk + lh) * BN + j * 32];
+                for (int i = 0; i < TM; ++i) av[h][kk][i] = As[(2 * (h * HK + kk) + lh) * BM + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) bv[h][kk][j] = Bs[(2 * (h * HK + kk) + lh) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kk = 0; kk < HK; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][kk][i], bv[h][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -155,7 +169,8 @@ WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     // enough workgroups for 256 CUs (2 x 128x128 or 4 x 64x64 tiles fit a CU's LDS), at least 8 stages of 32 pixels per slice
-    const long long want = big ? 768 : 1536;
+    static const int want_env = getenv("VPHO_WGRAD_WANT") ? atoi(getenv("VPHO_WGRAD_WANT")) : 0;      // tuning aid
+    const long long want = want_env > 0 ? (big ? want_env : 2 * want_env) : 1536;
     long long splits = std::max<long long>(1, (want + tiles - 1) / tiles);
     splits = std::min<long long>(splits, std::max<long long>(1, M / (8 * BK)));
     splits = std::min<long long>(splits, 256);
