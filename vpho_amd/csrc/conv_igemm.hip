@@ -283,12 +283,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Direct-to-LDS variant (no prologue affine): tiles are filled by `global_load_lds_dwordx4` (16 B per lane, no VGPR round
+// Direct-to-LDS variant (no prologue affine): tiles are filled by `buffer_load_dwordx4 ... lds` (16 B per lane, no VGPR round
 // trip, no ds_write).  One wave instruction writes 64 x 16 B = 8 tile rows of 128 B linearly, so the LDS rows are
 // unpadded; bank conflicts are avoided by XOR-swizzling the 16-byte chunk index of row r with (r >> 1) & 7 -- applied to
 // the per-lane SOURCE address (the LDS destination is lane-linear by construction) and again when the MFMA fragments are
-// read.  Out-of-image taps / K and M tails read from a 256-byte zero page instead of being masked.
-__device__ __attribute__((aligned(256))) float g_zero_page[64];
+// read.  Tiles are addressed through buffer resources: out-of-image taps / K and M tails carry an out-of-range offset, for which
+// the hardware writes zeros -- no masking, no 64-bit address arithmetic in the loop.
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo g) {
@@ -314,7 +314,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     const int lrow = wave * 8 + (lane >> 3);                        // tile row filled by this lane (per pass: + ROWS*j)
     const int kq = (lane & 7) ^ ((lrow >> 1) & 7);                  // logical 16-B chunk this lane must FETCH (swizzle)
 
-    long long a_off[A_LD];
+    // Buffer addressing: 32-bit byte offsets into x / w (the host checks both extents are < 4 GB); a lane whose tap falls outside
+    // the image, whose pixel / weight row is a tail, or whose k is beyond K gets offset 0xFFFFFFFF -- out of the buffer's range,
+    // for which `buffer_load ... lds` writes zeros (scripts/microbench/buffer_lds_oob.hip checks this on the hardware).
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, 0xFFFFFFF0u, 0x00020000);
+    unsigned a_off[A_LD];
     int a_iy0[A_LD], a_ix0[A_LD];
     const int ohw = d.OH * d.OW;
 #pragma unroll
@@ -325,39 +330,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
             int oy = rem / d.OW, ox = rem - oy * d.OW;
             a_iy0[j] = oy * d.stride - d.pad_y;
             a_ix0[j] = ox * d.stride - d.pad_x;
-            a_off[j] = ((long long)(n * d.H + a_iy0[j]) * d.W + a_ix0[j]) * d.x_ld;
+            a_off[j] = (unsigned)(((long long)(n * d.H + a_iy0[j]) * d.W + a_ix0[j]) * d.x_ld * 4);   // mod 2^32: exact once a valid tap is added
         } else {
             a_off[j] = 0; a_iy0[j] = -(1 << 28); a_ix0[j] = 0;
         }
     }
-    long long b_off[B_LD];
+    unsigned b_off[B_LD];
+    bool b_ok[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int n = n0 + lrow + ROWS * j;
-        b_off[j] = n < d.Cout ? (long long)n * g.w_ld + 4 * kq : -1;
+        b_ok[j] = n < d.Cout;
+        b_off[j] = (unsigned)(((long long)n * g.w_ld + 4 * kq) * 4);
     }
     int ld_c, ld_r, ld_s;
     {
         const int kg = 4 * kq, rs = kg / d.Cin;
         ld_c = kg - rs * d.Cin; ld_r = rs / d.KW; ld_s = rs - ld_r * d.KW;
     }
-    const float* zero = g_zero_page;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     auto fill = [&](int buf) {
         float* As = smem + buf * TILE + wave * 8 * BK;              // wave-uniform destination of this wave's 8 rows
         float* Bs = smem + buf * TILE + BM * BK + wave * 8 * BK;
         const bool kin = ld_r < d.KH;
-        const int tap = (ld_r * d.W + ld_s) * d.x_ld + ld_c;
+        const unsigned tap = (unsigned)(((ld_r * d.W + ld_s) * d.x_ld + ld_c) * 4);
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const unsigned iy = (unsigned)(a_iy0[j] + ld_r), ix = (unsigned)(a_ix0[j] + ld_s);
-            const float* src = (kin && iy < (unsigned)d.H && ix < (unsigned)d.W) ? d.x + a_off[j] + tap : zero;
-            __builtin_amdgcn_global_load_lds(src, As + ROWS * j * BK, 16, 0, 0);
+            const unsigned off = (kin && iy < (unsigned)d.H && ix < (unsigned)d.W) ? a_off[j] + tap : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(As + ROWS * j * BK), 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            const float* src = (kin && b_off[j] >= 0) ? d.w + b_off[j] : zero;
-            __builtin_amdgcn_global_load_lds(src, Bs + ROWS * j * BK, 16, 0, 0);
-            b_off[j] += b_off[j] >= 0 ? BK : 0;
+            const unsigned off = (kin && b_ok[j]) ? b_off[j] : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Bs + ROWS * j * BK), 16, (int)off, 0, 0, 0);
+            b_off[j] += BK * 4;
         }
         ld_c += BK;
         while (ld_c >= d.Cin) { ld_c -= d.Cin; if (++ld_s == d.KW) { ld_s = 0; ++ld_r; } }
@@ -533,7 +540,10 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8, splits), dim3(threads), 0, s, g);
     };
     static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
-    const bool glds = d.in_scale == nullptr && !no_glds;
+    // the direct-to-LDS kernels address x and w by 32-bit byte offsets: both extents (all splits included) must stay below 4 GB
+    const double x_extent = 4.0 * (((double)d.N * d.H * d.W - 1) * d.x_ld + d.Cin + (double)(splits - 1) * (double)g.x_zs);
+    const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(splits - 1) * (double)g.w_zs);
+    const bool glds = d.in_scale == nullptr && !no_glds && x_extent < 4.0e9 && w_extent < 4.0e9 && g.x_zs >= 0 && g.w_zs >= 0;
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288:
