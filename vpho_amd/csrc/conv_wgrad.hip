@@ -5,8 +5,8 @@
 //
 // The reduction runs over the pixel index, which is the SLOW index of both NHWC operands, so the tiles are staged k-major:
 // a stage is 32 pixels x (BM output channels of dY | BN input channels of the tap-shifted x), every pixel row one contiguous
-// 16-byte-chunked channel run moved by `global_load_lds_dwordx4` (out-of-image taps, pixel and channel tails read a zero
-// page).  The MFMA fragments are then single dwords at [k][lane & 31]: half-wave-contiguous ds_read_b32, conflict-free
+// 16-byte-chunked channel run moved by `buffer_load_dwordx4 ... lds` (out-of-image taps, pixel and channel tails carry an
+// out-of-range offset: the hardware writes zeros).  The MFMA fragments are then single dwords at [k][lane & 31]: half-wave-contiguous ds_read_b32, conflict-free
 // without padding or swizzle.  A workgroup owns one (Cout tile, tile of the flattened (tap, ci) axis) for one slice of the pixel
 // range (split-K over blockIdx.y); a 16-byte chunk never straddles taps (Cin % 4 == 0), so the tap is a per-lane constant and
 // narrow inputs (the 4-channel stem: 16 taps per 64-column tile) take the same path.  Slices are summed in a fixed order by a
@@ -20,7 +20,6 @@
 namespace {
 
 constexpr int BK = 32;
-__device__ __attribute__((aligned(256))) float g_wgrad_zero[64];
 
 struct WgArgs {
     const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
@@ -62,7 +61,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     for (int j = 0; j < A_LD; ++j) a_row[j] = (wave + NW * j) * (64 / A_CPR) + lane / A_CPR;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) b_row[j] = (wave + NW * j) * (64 / B_CPR) + lane / B_CPR;
-    const float* zero = g_wgrad_zero + 4 * (lane & 15);
+    // buffer addressing (32-bit byte offsets, extents < 4 GB checked by the host): offset 0xFFFFFFFF is out of range and makes the
+    // hardware write zeros -- out-of-image taps, pixel and channel tails (see conv_igemm.hip)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 
     auto fill = [&](int buf, int kt) {
         float* As = smem + buf * TILE;
@@ -71,20 +74,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const int m = mb + a_row[j];
-            const float* src = (a_ok && m < m_end) ? a.dy + (long long)m * a.dy_ld + a_col : zero;
-            __builtin_amdgcn_global_load_lds(src, As + (wave + NW * j) * 256, 16, 0, 0);
+            const unsigned off = (a_ok && m < m_end) ? ((unsigned)m * (unsigned)a.dy_ld + (unsigned)a_col) * 4u : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(As + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const int m = mb + b_row[j];
-            const float* src = zero;
+            unsigned off = 0xFFFFFFFFu;
             if (b_ok && m < m_end) {
                 const int n = m / ohw, rem = m - n * ohw;
                 const int oy = rem / a.OW, ox = rem - oy * a.OW;
                 const unsigned iy = (unsigned)(oy * a.stride + tr - a.pad_y), ix = (unsigned)(ox * a.stride + ts - a.pad_x);
-                if (iy < (unsigned)a.H && ix < (unsigned)a.W) src = a.x + ((long long)(n * a.H + (int)iy) * a.W + (int)ix) * a.x_ld + b_ci;
+                if (iy < (unsigned)a.H && ix < (unsigned)a.W) off = (((unsigned)(n * a.H + (int)iy) * (unsigned)a.W + ix) * (unsigned)a.x_ld + (unsigned)b_ci) * 4u;
             }
-            __builtin_amdgcn_global_load_lds(src, Bs + (wave + NW * j) * 256, 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(Bs + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
         }
     };
 
@@ -199,6 +202,7 @@ extern "C" int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, i
     VPHO_REQUIRE((OH - 1) * stride - pad_y < H && (OW - 1) * stride - pad_x < W, "vpho_conv2d_wgrad_nhwc_f32: output larger than input allows");
     const long long M = (long long)N * OH * OW;
     VPHO_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31), "vpho_conv2d_wgrad_nhwc_f32: too many pixels");
+    VPHO_REQUIRE((double)N * H * W * x_ld * 4.0 < 4.0e9 && (double)M * dy_ld * 4.0 < 4.0e9, "vpho_conv2d_wgrad_nhwc_f32: x and dy must each stay below 4 GB (32-bit buffer offsets)");
     const int taps = KH * KW;
     const WgPlan p = plan_wgrad(M, Cin, Cout, taps);
     VPHO_REQUIRE(p.splits == 1 || (workspace && ((uintptr_t)workspace & 15) == 0), "vpho_conv2d_wgrad_nhwc_f32: %d pixel slices need the workspace", p.splits);
