@@ -290,8 +290,6 @@ struct HeadArgs {
     const RkCtl* ctl; int ctl_mode, stage, out_slot; float* kbase; long long n_el;
 };
 
-__device__ __attribute__((aligned(256))) float g_head_zero_page[64];
-
 __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     // [2] stages x ([256][32] weights | [128][32] activations), unpadded rows filled by global_load_lds with the 16-B chunk
@@ -321,24 +319,27 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
     }
 
-    const float* wsrc[256 / RPP];
-    const float* psrc[128 / RPP];
-    int pstep[128 / RPP];
+    // tiles through buffer resources: per-lane byte offsets are loop constants, the k advance is the instruction's scalar offset;
+    // hypothesis rows beyond R carry an out-of-range offset (the hardware writes zeros)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wg), 0, 256 * 256 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p2), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int woff[256 / RPP], poff[128 / RPP];
 #pragma unroll
-    for (int j = 0; j < 256 / RPP; ++j) wsrc[j] = Wg + (lrow + RPP * j) * 256 + 4 * kq;
+    for (int j = 0; j < 256 / RPP; ++j) woff[j] = ((lrow + RPP * j) * 256 + 4 * kq) * 4;
 #pragma unroll
     for (int j = 0; j < 128 / RPP; ++j) {
         const int r = r0 + lrow + RPP * j;
-        psrc[j] = r < a.R ? a.p2 + (long long)r * 256 + 4 * kq : g_head_zero_page;
-        pstep[j] = r < a.R ? HB_K : 0;
+        poff[j] = r < a.R ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
     }
-    auto fill = [&](int buf) {
+    auto fill = [&](int buf, int kt) {
         float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
         float* Ps = smem + buf * STAGE + 256 * HB_K + wave * RPW * HB_K;
+        const int koff = kt * HB_K * 4;
 #pragma unroll
-        for (int j = 0; j < 256 / RPP; ++j) { __builtin_amdgcn_global_load_lds(wsrc[j], Ws + RPP * j * HB_K, 16, 0, 0); wsrc[j] += HB_K; }
+        for (int j = 0; j < 256 / RPP; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Ws + RPP * j * HB_K), 16, woff[j], koff, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 128 / RPP; ++j) { __builtin_amdgcn_global_load_lds(psrc[j], Ps + RPP * j * HB_K, 16, 0, 0); psrc[j] += pstep[j]; }
+        for (int j = 0; j < 128 / RPP; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)(Ps + RPP * j * HB_K), 16, poff[j], koff, 0, 0);
     };
 
     f32x16 acc[4];
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     // Two LDS stages.  The barrier of k-tile kt sits before its LAST 8-wide MFMA group: by then every wave has its
     // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
     // load has a whole k-tile of MFMA time to land before the next barrier needs it.
-    fill(0);
+    fill(0, 0);
     __syncthreads();
-    fill(1);
+    fill(1, 1);
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         const float* As = smem + buf * STAGE + (hh * 128 + li) * HB_K;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         for (int kk = 0; kk < NKK - 1; ++kk) { frags(kk); mfmas(); }
         frags(NKK - 1);
         __syncthreads();
-        if (kt + 2 < NK) fill(buf);
+        if (kt + 2 < NK) fill(buf, kt + 2);
         mfmas();
     }
     __syncthreads();
@@ -809,6 +810,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         hipLaunchKernelGGL(pose_encoder_kernel, dim3((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS)), dim3(512), pe_lds, c.s, pa);
         if (int e = vpho::check_launch("pose_encoder_kernel")) return e;
     }
+    VPHO_REQUIRE((double)c.R * 256.0 * 4.0 < 4.0e9, "score head: %lld hypothesis rows exceed the 32-bit buffer offsets", (long long)c.R);
     HeadArgs a;
     a.w1p = c.w->w1_p; a.p2 = c.ws.P2; a.cimg = c.ws.cimg; a.ct = c.ws.ct + (long long)ct_slot * c.NH; a.w2 = c.w->w2; a.b2 = c.w->b2;
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
