@@ -25,6 +25,7 @@ struct Geo {
     int w_ld;                       // floats between consecutive weight rows (K unless the launch reduces a K-slice)
     long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions; 0 for ordinary launches)
     int y_linear, r_linear, vec_epilogue;
+    int uni;   // Cin % 32 == 0: wave-uniform taps (direct-to-LDS kernel)
     int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores
 };
 
@@ -290,6 +291,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 // read.  Tiles are addressed through buffer resources: out-of-image taps / K and M tails carry an out-of-range offset, for which
 // the hardware writes zeros -- no masking, no 64-bit address arithmetic in the loop.
 
+// Geo::uni (Cin % 32 == 0): the 32 k of a stage lie in ONE tap: the tap is wave-uniform, the k / tap advance rides in the buffer
+// instruction's scalar offset and the per-lane offsets are loop constants (only the padding test of a 3x3 stays per stage; for 1x1
+// unpadded convolutions the loop has no per-lane address work at all).
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo g) {
     constexpr int NT = 64 * WM * WN;
@@ -370,6 +374,47 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
         while (ld_c >= d.Cin) { ld_c -= d.Cin; if (++ld_s == d.KW) { ld_s = 0; ++ld_r; } }
     };
 
+    // ---- UNI path state: offsets relative to a base shifted by the padding, so that every per-lane offset and the scalar tap
+    // offset are non-negative (the hardware adds them as unsigned 32-bit numbers)
+    const long long pad_shift = ((long long)d.pad_y * d.W + d.pad_x) * d.x_ld;
+    const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(d.x) - (uintptr_t)(pad_shift * 4)), 0, 0xFFFFFFF0u, 0x00020000);
+    int u_voff[A_LD], u_boff[B_LD];
+    int u_r = 0, u_s = 0, u_c = 0;                                  // wave-uniform tap of the stage being filled
+    const bool simple = d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0;
+    const bool UNI = g.uni != 0;
+    if (UNI) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const bool live = a_iy0[j] > -(1 << 27);
+            u_voff[j] = live ? (int)(a_off[j] + (unsigned)(pad_shift * 4) + 16u * (unsigned)kq) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) u_boff[j] = b_ok[j] ? (int)b_off[j] : -1;
+    }
+    auto fill_uni = [&](int buf, int kt) {
+        float* As = smem + buf * TILE + wave * 8 * BK;
+        float* Bs = smem + buf * TILE + BM * BK + wave * 8 * BK;
+        const int tap_s = ((u_r * d.W + u_s) * d.x_ld + u_c) * 4;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            int off = u_voff[j];
+            if (!simple) {
+                const unsigned iy = (unsigned)(a_iy0[j] + u_r), ix = (unsigned)(a_ix0[j] + u_s);
+                off = (iy < (unsigned)d.H && ix < (unsigned)d.W) ? off : -1;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xu, (lds_ptr)(As + ROWS * j * BK), 16, off, tap_s, 0, 0);
+        }
+        const int koff = kt * BK * 4;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int bo = u_boff[j];          // (a local: passing the array element straight to the builtin makes this hipcc drop the host stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Bs + ROWS * j * BK), 16, bo, koff, 0, 0);
+        }
+        u_c += BK;
+        if (u_c >= d.Cin) { u_c = 0; if (++u_s == d.KW) { u_s = 0; ++u_r; } }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -380,11 +425,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 
     const int nk = (g.K + BK - 1) / BK;
     const int sw = (li >> 1) & 7;                                   // (row >> 1) & 7 of every fragment row of this lane
-    fill(0);
+    if (UNI) fill_uni(0, 0); else fill(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fill(buf ^ 1);
+        if (kt + 1 < nk) { if (UNI) fill_uni(buf ^ 1, kt + 1); else fill(buf ^ 1); }
         const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * BK;
         const float* Bs = smem + buf * TILE + BM * BK + (wn * (BN / WN) + li) * BK;
 #pragma unroll
@@ -543,7 +588,9 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // the direct-to-LDS kernels address x and w by 32-bit byte offsets: both extents (all splits included) must stay below 4 GB
     const double x_extent = 4.0 * (((double)d.N * d.H * d.W - 1) * d.x_ld + d.Cin + (double)(splits - 1) * (double)g.x_zs);
     const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(splits - 1) * (double)g.w_zs);
-    const bool glds = d.in_scale == nullptr && !no_glds && x_extent < 4.0e9 && w_extent < 4.0e9 && g.x_zs >= 0 && g.w_zs >= 0;
+    const bool glds = d.in_scale == nullptr && !no_glds && x_extent < 3.9e9 && w_extent < 3.9e9 && g.x_zs >= 0 && g.w_zs >= 0;
+    static const int no_uni = getenv("VPHO_CONV_NO_UNI") ? atoi(getenv("VPHO_CONV_NO_UNI")) : 0;          // tuning aid
+    g.uni = (d.Cin % BK == 0 && d.pad_y >= 0 && d.pad_x >= 0 && !no_uni) ? 1 : 0;
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288:
