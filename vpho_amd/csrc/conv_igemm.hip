@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps the LDS destinations on the scalar unit
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = wave * 8 + (lane >> 3);                        // tile row filled by this lane (per pass: + ROWS*j)

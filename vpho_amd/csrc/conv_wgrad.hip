@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     const int co0 = tile_m * BM, c0 = tile_n * BN;                          // c0: column of the flattened (tap, ci) axis
     const int m_begin = blockIdx.y * a.m_chunk;
     const int m_end = m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int ohw = a.OH * a.OW;

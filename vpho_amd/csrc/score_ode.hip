@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     float* Eb = smem + 2 * STAGE;
     float* Ob = Eb + 256 * 4;
     const int n = blockIdx.y, r0 = blockIdx.x * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
     // one wave instruction fills 64 x 16 B = RPW whole tile rows; chunk swizzle f(row) = (row >> SW_SHIFT) & (CPR-1) keeps
     // the 16 lanes of every ds_read_b128 group on distinct 16-B slots of a 256-B bank row (rows of 128 B: 2 per bank row,
