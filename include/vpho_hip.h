@@ -306,6 +306,17 @@ int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows,
 long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
                                int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream);
+/* Training-mode tail of HeadMano for one batch of hands (lib/model/head_mano.py:60-87 forward + get_hand_verts, :89-133 get_loss,
+ * weights applied as lib/model/VPHO.py:214-219): rot6d [bs][96] (fc_pose output) -> rotation_6d_to_matrix -> ManoLayer -> root-centred
+ * vertices / joints in metres (optional outputs verts [bs][778][3], joints [bs][21][3], may be NULL); the four losses against
+ * gt_vert / gt_joint / gt_rot6d (= mano_aa_to_6D(gt pose)[:96]) / gt_shape (right hands only, is_right [bs]) and the gradient of
+ * w_vert*vert_loss + w_joint*joint_loss + w_pose*mano_pose_loss + w_shape*mano_shape_loss w.r.t. rot6d and shape.
+ * loss_parts [bs][4]: per-hand sums of squared differences (vert, joint, pose, shape) in fp64 -- the caller applies
+ * weight / (bs * 2334 | bs * 63 | bs * 96 | bs * 10).  Hands flagged is_ho3d (joint re-alignment, VPHO.py:150-153) are not supported. */
+int vpho_mano_train_f32(const vpho_mano_tables* t, const float* rot6d, const float* shape, const float* gt_vert, const float* gt_joint,
+                        const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, int bs,
+                        float w_vert, float w_joint, float w_pose, float w_shape,
+                        float* d_rot6d, float* d_shape, double* loss_parts, float* verts, float* joints, void* stream);
 /* JointsMSELoss (lib/model/head_inplane.py:191-203: nn.MSELoss, mean over all elements) times its loss weight
  * (VPHO.py:214-219): loss[0] = weight * mean((pd - gt)^2) in fp64, grad = weight * 2 (pd - gt) / n.  partial_ws: >= partial_cap doubles */
 int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws, int partial_cap,

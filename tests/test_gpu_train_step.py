@@ -14,18 +14,24 @@ BS, STRIDE = 12, 1999
 ZERO_GRAD = ('.conv1.bias', '.conv2.bias', '.conv_layers.1.bias')
 
 
-def load_case():
+def load_case(mano=False):
     from vpho_amd.assets import synthetic_assets
     from vpho_amd.synth import synth_state_dict, synth_batch
     from vpho_amd.model.VPHO import vpho_net
     assets = synthetic_assets(0)
     sd = synth_state_dict(vpho_net(assets), seed=1)
     batch = synth_batch(BS, assets, seed=5)
-    G = np.load(GOLD)
+    G = np.load(GOLD.replace('golden_diffusion_step', 'golden_mano_step') if mano else GOLD)
     g = np.random.default_rng(77)
     f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
     batch['hm_hand'] = f32(g.random(size=(BS, 21, 64, 64)) * 0.2)
     batch['hm_obj'] = f32(g.random(size=(BS, 27, 64, 64)) * 0.2)
+    if mano:                                             # same generator, same draw order as the fixture script
+        for shape in ((BS, 48), (BS, 10), (BS, 6), (BS, 3)):
+            g.normal(size=shape)                         # gt_mano / gt_obj: stored with the fixture
+        batch['gt_hand_vert_flip'] = f32(g.normal(size=(BS, 778, 3)) * 0.05)
+        batch['gt_hand_jt3d_flip'] = f32(g.normal(size=(BS, 21, 3)) * 0.05)
+        batch['gt_mano'] = torch.from_numpy(G['gt_mano'])
     data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
     draws = {k: torch.from_numpy(G[k]).cuda() for k in ('t_h', 'z_h', 't_o', 'z_o')}
     return sd, data, draws, G
@@ -127,3 +133,52 @@ def test_trainer_full_scope_runs_and_writes_back():
         assert k in changed, k
     assert not any(k.startswith(('head_mano', 'cross_', 'head_physics')) for k in changed)      # not on this step's path
     assert all(np.isfinite(list(h.values())).all() for h in hist) and set(hist[0]) >= {'total_loss', 'diff_hand_loss', 'hm_obj_loss'}
+
+
+def test_mano_head_losses_and_gradients_match_oracle_autograd():
+    """vpho_mano_train_f32 (Gram-Schmidt -> MANO -> four losses -> analytic backward) vs fp64 autograd through the oracle's
+    restatement of the reference's chain rot6d -> matrix -> axis-angle -> manopth layer (head_mano.py:60-133)."""
+    from oracle import mano as OM, rotations as OR
+    from vpho_amd import ops
+    from vpho_amd.assets import synthetic_assets
+    mano = synthetic_assets(0)['mano']
+    g = torch.Generator().manual_seed(3)
+    bs = 5
+    d6 = (torch.randn(bs, 16, 6, generator=g) * 0.5 + torch.tensor([1., 0, 0, 0, 1, 0])).double().requires_grad_(True)
+    beta = (torch.randn(bs, 10, generator=g) * 0.5).double().requires_grad_(True)
+    gt_v, gt_j = torch.randn(bs, 778, 3, generator=g).double() * 0.05, torch.randn(bs, 21, 3, generator=g).double() * 0.05
+    gt6, gtb = torch.randn(bs, 96, generator=g).double() * 0.5, torch.randn(bs, 10, generator=g).double() * 0.5
+    right = torch.tensor([1, 0, 1, 1, 0], dtype=torch.bool)
+    W = (1e4, 1e4, 10.0, 1.0)
+    Rm = OR.rotation_6d_to_matrix(d6)
+    aa = OR.matrix_to_axis_angle(Rm).reshape(bs, 48)
+    v, j = OM.get_hand_verts(mano, aa, beta)
+    pd6 = OR.matrix_to_rotation_6d(OR.axis_angle_to_matrix(aa.reshape(bs, 16, 3))).reshape(bs, 96)
+    L = dict(vert_loss=W[0] * ((v - gt_v) ** 2).mean(), joint_loss=W[1] * ((j - gt_j) ** 2).mean(), mano_pose_loss=W[2] * ((pd6 - gt6) ** 2).mean(),
+             mano_shape_loss=W[3] * ((beta[right] - gtb[right]) ** 2).mean() / bs * int(right.sum()))
+    g6, gb = torch.autograd.grad(sum(L.values()), [d6, beta])
+    M = ops.Mano(mano, 'cuda')
+    c = lambda t: t.float().contiguous().cuda()
+    Lk, k6, kb, kv, kj = M.train(c(d6.detach().reshape(bs, 96)), c(beta.detach()), c(gt_v), c(gt_j), c(gt6), c(gtb), right.to(torch.uint8).cuda(), W, want_outputs=True)
+    for k in L:
+        assert abs(float(Lk[k]) - float(L[k].detach())) <= 2e-5 * abs(float(L[k].detach())), (k, float(Lk[k]), float(L[k].detach()))
+    np.testing.assert_allclose(kv.cpu().numpy(), v.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(kj.cpu().numpy(), j.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(k6.cpu().numpy(), g6.reshape(bs, 96).numpy(), atol=2e-4 * float(g6.abs().max()), rtol=1e-3)
+    np.testing.assert_allclose(kb.cpu().numpy(), gb.numpy(), atol=2e-4 * float(gb.abs().max()), rtol=1e-3)
+
+
+def test_step_with_mano_losses_matches_reference_training_forward():
+    """the step with head_mano + the four MANO losses added (521 tensors) vs the reference's forward(mode='train') under autograd"""
+    from vpho_amd.assets import synthetic_assets
+    from vpho_amd.train_step import DiffusionTrainStep
+    sd, data, draws, G = load_case(mano=True)
+    step = DiffusionTrainStep(sd, 'cuda', loss_weights=dict(hm_hand=1e3, hm_obj=1e3, vert=1e4, joint=1e4, mano_pose=10.0, mano_shape=1.0),
+                              assets=synthetic_assets(0))
+    L, grads = step.loss_and_grads(data, torch.from_numpy(G['gt_hand6d']).cuda(), torch.from_numpy(G['gt_obj']).cuda(), draws)
+    for k in ('diff_hand_loss', 'diff_obj_loss', 'hm_hand_loss', 'hm_obj_loss', 'vert_loss', 'joint_loss', 'mano_pose_loss', 'mano_shape_loss'):
+        assert abs(float(L[k]) - float(G[k])) <= 2e-4 * abs(float(G[k])), (k, float(L[k]), float(G[k]))
+    bad, ours, theirs = compare_gradients(G, grads)
+    assert not bad, bad[:10]
+    assert ours <= 1.5 * theirs, (ours, theirs)
+    assert sum(k.startswith('head_mano.') for k in grads) == 8

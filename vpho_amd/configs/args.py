@@ -41,6 +41,10 @@ class Config:
         self.weight_diff_obj_loss = 1.0
         self.weight_hm_hand_loss = 1.0
         self.weight_hm_obj_loss = 1.0
+        self.weight_vert_loss = 1.0
+        self.weight_joint_loss = 1.0
+        self.weight_mano_pose_loss = 1.0
+        self.weight_mano_shape_loss = 1.0
 
 
 def _parser():
@@ -76,6 +80,10 @@ def _parser():
     p.add_argument('--weight_diff_obj_loss', type=float, default=1.0)
     p.add_argument('--weight_hm_hand_loss', type=float, default=1e3)
     p.add_argument('--weight_hm_obj_loss', type=float, default=1e3)
+    p.add_argument('--weight_vert_loss', type=float, default=1e4)
+    p.add_argument('--weight_joint_loss', type=float, default=1e4)
+    p.add_argument('--weight_mano_pose_loss', type=float, default=10)
+    p.add_argument('--weight_mano_shape_loss', type=float, default=1.0)
     return p
 
 

@@ -352,3 +352,44 @@ class HeatmapHeadTrain:
         G['conv_layers.0.bias'] = CB.conv2d_bias_grad(dc0)
         dx = CB.conv2d_dgrad(dc0, self.c0[0], S['x'].shape[1:3], 3, 3, 1, 1)
         return dx, G
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+class HeadManoTrain:
+    """Training-mode forward + backward of ``HeadMano`` (lib/model/head_mano.py:30-87) with its four losses (:89-133): two
+    Linear + LeakyReLU base layers, ``fc_pose`` (16 x rot6d) and ``fc_shape`` on the fp32-MFMA GEMM, then
+    ``vpho_mano_train_f32`` (Gram-Schmidt -> MANO -> losses -> gradient at the 96 + 10 outputs) and the MLP backward.
+    Parameters stay in the reference's (out, in) layout.  Gradients under the reference's names."""
+    NAMES = ('base_layer.0', 'base_layer.2', 'fc_pose', 'fc_shape')
+
+    def __init__(self, sd, prefix, mano, device):
+        import torch
+        self.dev, self.mano = device, mano
+        g = lambda k: sd[f'{prefix}.{k}'].detach().float().to(device).contiguous().clone()
+        self.p = {f'{n}.{s}': g(f'{n}.{s}') for n in self.NAMES for s in ('weight', 'bias')}
+        self._pad = torch.zeros((2, self.p['fc_pose.weight'].shape[1]), device=device)
+
+    def forward_backward(self, x, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights):
+        """x (bs,1024) encoding.  -> losses dict (weighted, 0-d fp64), d loss / d x (bs,1024), grads"""
+        import torch
+        from .train_score import _wgrad
+        P = self.p
+        h1 = ops.linear(x, P['base_layer.0.weight'], P['base_layer.0.bias'], out_slope=SLOPE)
+        h2 = ops.linear(h1, P['base_layer.2.weight'], P['base_layer.2.bias'], out_slope=SLOPE)
+        wcat = torch.cat([P['fc_pose.weight'], P['fc_shape.weight'], self._pad], 0).contiguous()             # (108, 512)
+        bcat = torch.cat([P['fc_pose.bias'], P['fc_shape.bias'], self._pad[:, 0]], 0).contiguous()
+        out = ops.linear(h2, wcat, bcat)
+        rot6d, shape = out[:, :96].contiguous(), out[:, 96:106].contiguous()
+        L, d6, ds = self.mano.train(rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights)
+        dout = torch.cat([d6, ds, torch.zeros_like(d6[:, :2])], 1).contiguous()                               # (bs, 108)
+        G = {}
+        dw = _wgrad(h2, dout)
+        db = ops.colsum(dout)
+        G['fc_pose.weight'], G['fc_shape.weight'] = dw[:96].contiguous(), dw[96:106].contiguous()
+        G['fc_pose.bias'], G['fc_shape.bias'] = db[:96].contiguous(), db[96:106].contiguous()
+        dh2 = ops.lrelu_bwd(ops.linear(dout, wcat.t().contiguous()), h2, SLOPE)
+        G['base_layer.2.weight'], G['base_layer.2.bias'] = _wgrad(h1, dh2), ops.colsum(dh2)
+        dh1 = ops.lrelu_bwd(ops.linear(dh2, P['base_layer.2.weight'].t().contiguous()), h1, SLOPE)
+        G['base_layer.0.weight'], G['base_layer.0.bias'] = _wgrad(x, dh1), ops.colsum(dh1)
+        dx = ops.linear(dh1, P['base_layer.0.weight'].t().contiguous())
+        return L, dx, G

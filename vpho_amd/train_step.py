@@ -4,8 +4,9 @@ every module on the path in training mode, ``loss.backward()`` through score net
 re-alignment -> RoIAlign -> the two-branch backbone, data-parallel gradient averaging and AdamW
 (lib/engine/train_diff_hand_obj.py:49-52,169-199).
 
-Not part of this step (the remaining losses of the reference's training forward and the modules only they reach): MANO and
-physics losses, ``head_mano``, the cross modules and ``head_physics``; gradient clipping is off as in the reference's default.
+With the MANO tables (``assets``) and the hand ground truth in the batch the step also carries ``head_mano`` and the four MANO
+losses (vert / joint / mano_pose / mano_shape, lib/model/head_mano.py:89-133).  Not part of this step: the physics losses and the
+modules only they reach (cross modules, ``head_physics``); gradient clipping is off as in the reference's default.
 Composition of ``train_blocks`` / ``train_score``; torch allocates, slices and, under ``torch.distributed``, all-reduces ONE
 flat gradient buffer (RCCL under backend 'nccl').
 """
@@ -15,12 +16,12 @@ import torch.distributed as dist
 from . import ops
 from .configs.args import cfg
 from .model.pack import pack_conv, pack_deconv4x4s2
-from .train_blocks import FPNTrain, EncoderTrain, HeatmapHeadTrain
+from .train_blocks import FPNTrain, EncoderTrain, HeatmapHeadTrain, HeadManoTrain
 from .train_score import ScoreTrainer, SUFFIXES
 
 
 class DiffusionTrainStep:
-    def __init__(self, state_dict, device, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, loss_weights=None):
+    def __init__(self, state_dict, device, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, loss_weights=None, assets=None):
         self.dev = torch.device(device)
         sd = state_dict
         lr = cfg.base_learning_rate if lr is None else lr
@@ -29,8 +30,11 @@ class DiffusionTrainStep:
         self.enc = dict(h=EncoderTrain(sd, 'encoder_hand', self.dev), o=EncoderTrain(sd, 'encoder_obj', self.dev))
         self.score = dict(h=ScoreTrainer(sd, 'denoiser_hand', self.dev, lr, betas, eps, weight_decay),
                           o=ScoreTrainer(sd, 'denoiser_obj', self.dev, lr, betas, eps, weight_decay))
+        # MANO losses (head_mano + the MANO layer) need the MANO tables: enabled when `assets` is given
+        self.mano_head = HeadManoTrain(sd, 'head_mano', ops.Mano(assets['mano'], self.dev), self.dev) if assets is not None else None
         self.w = dict(diff_hand=cfg.weight_diff_hand_loss, diff_obj=cfg.weight_diff_obj_loss, hm_hand=cfg.weight_hm_hand_loss,
-                      hm_obj=cfg.weight_hm_obj_loss)
+                      hm_obj=cfg.weight_hm_obj_loss, vert=cfg.weight_vert_loss, joint=cfg.weight_joint_loss, mano_pose=cfg.weight_mano_pose_loss,
+                      mano_shape=cfg.weight_mano_shape_loss)
         self.w.update(loss_weights or {})
         self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.steps = 0
@@ -106,6 +110,9 @@ class DiffusionTrainStep:
         for tr in self.score.values():
             for s in SUFFIXES:
                 vec(f'{tr.prefix}.{s}', tr.params[s])
+        if self.mano_head is not None:
+            for k, v in self.mano_head.p.items():
+                vec(f'head_mano.{k}', v)
         self.names = sorted(self.master)
         sizes = [self.master[k].numel() for k in self.names]
         self.flat_grad = torch.zeros(sum(sizes), device=self.dev)
@@ -151,6 +158,15 @@ class DiffusionTrainStep:
             L['hm_obj_loss'], d_hm_o = ops.mse_loss(hm_o, ops.nchw_to_nhwc(f32(data['hm_obj'])), self.w['hm_obj'])
             L['diff_hand_loss'] = L['diff_hand_loss'] * self.w['diff_hand']
             L['diff_obj_loss'] = L['diff_obj_loss'] * self.w['diff_obj']
+            d_enc_mano = None
+            if self.mano_head is not None and 'gt_hand_vert_flip' in data:
+                # head_mano -> MANO -> vert / joint / mano_pose / mano_shape losses (VPHO.py:147-148,197-204); gt_hand is
+                # mano_aa_to_6D(gt_mano)[..., :96], the shape ground truth are the last 10 entries of gt_mano
+                assert not bool(data['is_ho3d'].any()) if 'is_ho3d' in data else True, 'HO3D joint re-alignment is not part of this step'
+                Lm, d_enc_mano, gm = self.mano_head.forward_backward(
+                    enc_h, f32(data['gt_hand_vert_flip']), f32(data['gt_hand_jt3d_flip']), f32(gt_hand), f32(data['gt_mano'][:, 48:]),
+                    data['is_right'].to(torch.uint8).contiguous(), (self.w['vert'], self.w['joint'], self.w['mano_pose'], self.w['mano_shape']))
+                L.update(Lm)
             # ---- backward
             G = {}
             dfeat = {}
@@ -159,6 +175,8 @@ class DiffusionTrainStep:
                     ('o', 'obj', eo, self.hm['o'], d_enc_o, d_hm_o, self.w['diff_obj'], bb_or, bb_or, bb_o, left)):
                 if w_diff != 1.0:
                     d_enc = d_enc * w_diff
+                if br == 'h' and d_enc_mano is not None:
+                    d_enc = ops.add_lrelu(d_enc, d_enc_mano)
                 d_in, g = enc.backward(d_enc)
                 G.update({f'encoder_{long_}.{k}': v for k, v in g.items()})
                 nj = enc.cin - 256
@@ -173,7 +191,9 @@ class DiffusionTrainStep:
             G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o']).items()})
             for tr, w_diff in ((self.score['h'], self.w['diff_hand']), (self.score['o'], self.w['diff_obj'])):
                 G.update({f'{tr.prefix}.{s}': (tr.grads[s] if w_diff == 1.0 else tr.grads[s] * w_diff) for s in SUFFIXES})
-            L['total_loss'] = L['diff_hand_loss'] + L['diff_obj_loss'] + L['hm_hand_loss'] + L['hm_obj_loss']
+            if d_enc_mano is not None:
+                G.update({f'head_mano.{k}': v for k, v in gm.items()})
+            L['total_loss'] = sum(L.values())
         return L, G
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -187,10 +207,14 @@ class DiffusionTrainStep:
             u = lambda: torch.rand(reps, bs, device=self.dev) * (1. - eps) + eps
             draws = dict(t_h=u(), z_h=torch.randn(reps, bs, 96, device=self.dev), t_o=u(), z_o=torch.randn(reps, bs, 9, device=self.dev))
         losses, grads = self.loss_and_grads(data, gt_hand, gt_obj, draws)
-        mismatch = set(self.names) ^ set(grads)
-        assert not mismatch, sorted(mismatch)[:5]
+        unknown = set(grads) - set(self.names)
+        assert not unknown, sorted(unknown)[:5]
+        live = [k for k in self.names if k in grads]             # tensors no loss of this batch reached keep their value (grad None)
         for k in self.names:
-            self.grad_view[k].copy_(grads[k])
+            if k in grads:
+                self.grad_view[k].copy_(grads[k])
+            else:
+                self.grad_view[k].zero_()
         scale = 1.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
@@ -198,7 +222,7 @@ class DiffusionTrainStep:
         self.steps += 1
         hyper = dict(self.hyper, lr=self.hyper['lr'] if lr is None else lr)
         with torch.cuda.device(self.dev):
-            for k in self.names:
+            for k in live:
                 ops.adamw_(self.master[k], self.grad_view[k], self.m[k], self.v[k], self.steps, grad_scale=scale, **hyper)
                 if self._repack[k] is not None:
                     self._repack[k](self.master[k])
