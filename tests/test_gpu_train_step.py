@@ -129,10 +129,10 @@ def test_trainer_full_scope_runs_and_writes_back():
     after = {k: v.cpu() for k, v in tr.model.state_dict().items()}
     changed = {k for k in before if not torch.equal(before[k], after[k])}
     for k in ('feature_extractor.layer0_h.0.weight', 'feature_extractor.layer3_o.0.2.bn2.running_var', 'head_hm_obj.deconv_layers.0.weight',
-              'encoder_hand.project.weight', 'denoiser_obj.head.head.2.bias'):
+              'encoder_hand.project.weight', 'denoiser_obj.head.head.2.bias', 'head_mano.fc_pose.weight', 'head_mano.base_layer.0.bias'):
         assert k in changed, k
-    assert not any(k.startswith(('head_mano', 'cross_', 'head_physics')) for k in changed)      # not on this step's path
-    assert all(np.isfinite(list(h.values())).all() for h in hist) and set(hist[0]) >= {'total_loss', 'diff_hand_loss', 'hm_obj_loss'}
+    assert not any(k.startswith(('cross_', 'head_physics')) for k in changed)                    # not on this step's path
+    assert all(np.isfinite(list(h.values())).all() for h in hist) and set(hist[0]) >= {'total_loss', 'diff_hand_loss', 'hm_obj_loss', 'vert_loss', 'mano_shape_loss'}
 
 
 def test_mano_head_losses_and_gradients_match_oracle_autograd():

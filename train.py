@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P train.py --gpus N
 
 One step = the reference's ``accel.backward(loss) + optimizer.step()`` (lib/engine/train_diff_hand_obj.py:169-199) with the loss
-restricted to diff_hand + diff_obj + hm_hand + hm_obj (lib/model/VPHO.py:190-195): training-mode two-branch ResNet-50/FPN,
-RoIAlign, heat-map heads and re-alignment, the two encoders, repeat_num DSM draws per score network, the whole backward,
-one all-reduce of the flat gradient buffer (RCCL) under data parallelism, AdamW on all 513 tensors.  One JSON line on rank 0.
+restricted to diff_hand + diff_obj + hm_hand + hm_obj + the four MANO losses (lib/model/VPHO.py:190-204): training-mode two-branch
+ResNet-50/FPN, RoIAlign, heat-map heads and re-alignment, the two encoders, repeat_num DSM draws per score network, head_mano +
+MANO layer, the whole backward, one all-reduce of the flat gradient buffer (RCCL) under data parallelism, AdamW on all 521 tensors.  One JSON line on rank 0.
 """
 import argparse
 import json
@@ -44,13 +44,17 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     assets = synthetic_assets(0)
     sd = synth_state_dict(vpho_net(assets), seed=1)
-    step = DiffusionTrainStep(sd, dev)
+    step = DiffusionTrainStep(sd, dev, assets=assets)
     bs = args.bs
     data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth_batch(bs, assets, seed=11, rank=rank).items()}
     g = torch.Generator().manual_seed(100 + rank)
     data['hm_hand'] = (torch.rand(bs, 21, 64, 64, generator=g) * 0.2).to(dev)
     data['hm_obj'] = (torch.rand(bs, 27, 64, 64, generator=g) * 0.2).to(dev)
-    gt_h, gt_o = (torch.randn(bs, 96, generator=g) * 0.5).to(dev), (torch.randn(bs, 9, generator=g) * 0.5).to(dev)
+    # ground truth: 16 x rot6d spread around the identity (one pose for the DSM target and the MANO losses), object rot6d + translation
+    gt_h = (torch.randn(bs, 96, generator=g) * 0.5).to(dev) + torch.tensor([1., 0, 0, 0, 1, 0], device=dev).repeat(16)
+    gt_o = (torch.randn(bs, 9, generator=g) * 0.5).to(dev)
+    from vpho_amd.trainer import synthetic_mano_targets
+    data.update(synthetic_mano_targets(step.mano_head.mano, gt_h, (torch.randn(bs, 10, generator=g) * 0.5).to(dev), data['is_right']))
 
     first = None
     for _ in range(args.warmup):
@@ -66,7 +70,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    res = {'metric': 'end-to-end training images/s (diffusion + heat-map losses, all modules on the path trained)',
+    res = {'metric': 'end-to-end training images/s (diffusion + heat-map + MANO losses, all modules on the path trained)',
            'value': world * args.steps * bs / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
            'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
            'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),

@@ -19,6 +19,15 @@ from .assets import load_assets
 from .synth import synth_state_dict, synth_batch
 
 
+def synthetic_mano_targets(mano, gt_rot6d, gt_shape, is_right):
+    """ground-truth vertices / joints of a synthetic hand pose: the MANO forward of the training kernel with zero loss weights"""
+    bs = gt_rot6d.shape[0]
+    z = lambda *s: torch.zeros(s, device=gt_rot6d.device)
+    _, _, _, gv, gj = mano.train(gt_rot6d.contiguous(), gt_shape.contiguous(), z(bs, 778, 3), z(bs, 21, 3), gt_rot6d.contiguous(), gt_shape.contiguous(),
+                                 is_right.to(torch.uint8).contiguous(), (0.0, 0.0, 0.0, 0.0), want_outputs=True)
+    return dict(gt_hand_vert_flip=gv, gt_hand_jt3d_flip=gj, gt_mano=torch.cat([z(bs, 48), gt_shape], 1))
+
+
 class Trainer:
     def __init__(self, cfg):
         self.cfg = cfg
@@ -72,7 +81,7 @@ class Trainer:
         from .train_step import DiffusionTrainStep
         cfg, bs = self.cfg, self.cfg.batch_size
         n_batches = cfg.num_batches if n_batches is None else n_batches
-        step = DiffusionTrainStep(self.model.state_dict(), self.device)
+        step = DiffusionTrainStep(self.model.state_dict(), self.device, assets=self.assets)
         hist = []
         for i in range(n_batches):
             batch = {k: (v.to(self.device) if torch.is_tensor(v) else v)
@@ -80,6 +89,7 @@ class Trainer:
             gt_hand, gt_obj, g = self._synthetic_targets(bs, i)
             batch['hm_hand'] = (torch.rand(bs, 21, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
             batch['hm_obj'] = (torch.rand(bs, 27, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
+            batch.update(synthetic_mano_targets(step.mano_head.mano, gt_hand, (torch.randn(bs, 10, generator=g) * 0.5).to(self.device), batch['is_right']))
             L = step.step(batch, gt_hand, gt_obj)
             hist.append({k: float(v) for k, v in L.items()})
             if self.rank == 0 and i % max(1, getattr(cfg, 'print_freq', 10)) == 0:
