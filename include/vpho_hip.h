@@ -56,6 +56,7 @@ typedef struct {
     int w_ld, splits;
     long long x_split, w_split, y_split;
 } vpho_conv_desc;
+/* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -97,3 +97,26 @@ def test_bad_arguments_raise():
         ops.conv2d_nhwc(x, torch.zeros((8, 6), device='cuda'))           # Cin % 4 != 0
     with pytest.raises(ops.VphoError):
         ops.conv2d_nhwc(torch.zeros((1, 4, 4, 8)), torch.zeros((8, 8)))  # CPU tensors: no fallback
+
+
+def test_tensors_beyond_4gb_are_refused():
+    """The kernels address x / w with 32-bit byte offsets: an operand of 4.3 GB is refused with an error before any launch"""
+    from vpho_amd import ops
+    x = torch.empty(2, 8192, 8192, 8, device='cuda')
+    assert x.numel() * 4 > 4.2e9
+    w = torch.zeros(8, 8, device='cuda')
+    with pytest.raises(ops.VphoError, match='3.9 GB'):
+        ops.conv2d_nhwc(x, w, None)
+
+
+def test_mixed_uniform_and_generic_tap_paths_agree():
+    """Cin % 32 == 0 takes the wave-uniform tap path, the same layer with VPHO-independent channel padding (Cin = 36 of ld 64) the
+    generic one: both against torch, with padding on all four sides, stride 2 and a ragged pixel count."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    for cin in (64, 36):
+        x = _rand((3, cin, 15, 11), 7)
+        w = _rand((40, cin, 3, 3), 8, (2.0 / (cin * 9)) ** 0.5)
+        ref = F.conv2d(x, w, None, 2, 1)
+        y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), None, kh=3, kw=3, stride=2, pad=1)
+        _close(y.permute(0, 3, 1, 2), ref)

@@ -76,7 +76,8 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=Non
     """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights."""
     N, OH, OW, cout = dy.shape
     c_in = x.shape[-1] if cin is None else cin
-    if USE_TN_WGRAD and c_in % 4 == 0 and cout % 4 == 0 and x.shape[-1] % 4 == 0:
+    small = x.numel() * 4 < 3.9e9 and dy.numel() * 4 < 3.9e9          # the TN kernel addresses its operands by 32-bit byte offsets
+    if USE_TN_WGRAD and small and c_in % 4 == 0 and cout % 4 == 0 and x.shape[-1] % 4 == 0:
         return ops.conv2d_wgrad_nhwc(x, dy.contiguous(), kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, cin=cin)
     xg_t = ops.im2col_t(x, kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, OH, OW, cin=cin)   # (kh*kw*cin, P4)
     dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns

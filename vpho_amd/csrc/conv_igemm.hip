@@ -586,9 +586,12 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     };
     static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
     // the direct-to-LDS kernels address x and w by 32-bit byte offsets: both extents (all splits included) must stay below 4 GB
+    // (the largest activation of the reference's configurations is 0.27 GB)
     const double x_extent = 4.0 * (((double)d.N * d.H * d.W - 1) * d.x_ld + d.Cin + (double)(splits - 1) * (double)g.x_zs);
     const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(splits - 1) * (double)g.w_zs);
-    const bool glds = d.in_scale == nullptr && !no_glds && x_extent < 3.9e9 && w_extent < 3.9e9 && g.x_zs >= 0 && g.w_zs >= 0;
+    VPHO_REQUIRE(x_extent < 3.9e9 && w_extent < 3.9e9 && g.x_zs >= 0 && g.w_zs >= 0,
+                 "vpho_conv2d_nhwc_f32: input (%.2f GB) and weights (%.2f GB) must each stay below 3.9 GB", x_extent * 1e-9, w_extent * 1e-9);
+    const bool glds = d.in_scale == nullptr && !no_glds;
     static const int no_uni = getenv("VPHO_CONV_NO_UNI") ? atoi(getenv("VPHO_CONV_NO_UNI")) : 0;          // tuning aid
     g.uni = (d.Cin % BK == 0 && d.pad_y >= 0 && d.pad_x >= 0 && !no_uni) ? 1 : 0;
     switch (variant) {
