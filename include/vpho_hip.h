@@ -55,6 +55,11 @@ typedef struct {
      * partial sums of a long reduction (the pixel dimension of a weight gradient) for the caller to add; no bias / res. */
     int w_ld, splits;
     long long x_split, w_split, y_split;
+    /* Optional (NULL = off; ABI version 4): y = gate > 0 ? y : y * gate_slope after the epilogue, `gate` laid out like y (same
+     * strides, pointing at the element that corresponds to y[0]) -- the backward of a LeakyReLU given its output, fused into the
+     * input-gradient convolution (torch autograd of nn.LeakyReLU in Bottleneck / Residual, backbone_FPN_HFL.py:326, encoding.py:21-36). */
+    const float* gate;
+    float gate_slope;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
@@ -345,11 +350,13 @@ int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, in
  * variance (fp64 two-level reduction), y = lrelu((x - mean) * invstd * gamma + beta, slope) (slope 1 = no activation), running
  * statistics updated with `momentum` and the unbiased variance; save_mean / save_invstd feed the backward:
  * dbeta = sum dy, dgamma = sum dy * xhat, dx = gamma * invstd / rows * (rows * dy - dbeta - xhat * dgamma).
- * (For a fused activation pass its backward first: vpho_lrelu_bwd_f32 on y.)  workspace: vpho_bn_workspace_bytes(C). */
+ * (For a fused activation pass its backward first: vpho_lrelu_bwd_f32 on y.)  res (may be NULL; ABI version 4): the residual
+ * branch of a bottleneck, y = lrelu(bn(x) + res, slope) (Bottleneck.forward, backbone_FPN_HFL.py:347-349); its gradient is the
+ * gradient of the sum.  workspace: vpho_bn_workspace_bytes(C). */
 long long vpho_bn_workspace_bytes(int C);
 int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
-                              float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* y,
-                              void* workspace, void* stream);
+                              float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* res,
+                              float* y, void* workspace, void* stream);
 int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
                                const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */

@@ -28,9 +28,10 @@ def _flip_transpose(w_packed, cout, cin, kh, kw):
     return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
 
 
-def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None):
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None):
     """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
-    asymmetric top/left paddings of the transposed-convolution phases, stride 1 only)."""
+    asymmetric top/left paddings of the transposed-convolution phases, stride 1 only).  ``gate`` = (y, slope): the result is
+    additionally passed through the backward of the LeakyReLU that produced y = lrelu(x) (fused into the kernel's epilogue)."""
     N, OH, OW, cout = dy.shape
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
@@ -43,7 +44,7 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     px = pad if pad_x is None else pad_x
     if stride == 1:
         return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1,
-                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W))
+                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate)
     assert py == px == pad
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
     w4 = w_packed.view(cout, kh, kw, cin)
@@ -68,7 +69,7 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
                     sub[:, offy - oy0, offx - ox0, :] = w4[:, r, s, :].t()
             # phase output (a, b) reads dY rows a + oy0 .. : a stride-1 convolution with padding -oy0 / -ox0
             ops.conv2d_nhwc(dy, sub.reshape(cin, khp * kwp * cout).contiguous(), None, kh=khp, kw=kwp, stride=1, pad_y=-oy0, pad_x=-ox0,
-                            out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin))
+                            out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin), gate=gate)
     return dx
 
 

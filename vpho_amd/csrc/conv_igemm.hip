@@ -256,6 +256,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+            if (d.gate) {                                            // backward of a LeakyReLU whose output is `gate` (same layout as y)
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(d.gate + yo[it]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = gt[k] > 0.f ? o[k] : o[k] * d.gate_slope;
+            }
             *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
         }
         return;
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
                 float v = acc[i][j][e] + bv;
                 if (d.res) v += d.res[ro + col];
                 v = v > 0.f ? v : v * d.out_slope;
+                if (d.gate) v = d.gate[yo + col] > 0.f ? v : v * d.gate_slope;
                 d.y[yo + col] = v;
             }
         }
@@ -503,6 +509,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+            if (d.gate) {                                            // backward of a LeakyReLU whose output is `gate` (same layout as y)
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(d.gate + yo[it]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = gt[k] > 0.f ? o[k] : o[k] * d.gate_slope;
+            }
             *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
         }
         return;
@@ -524,6 +535,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
                 float v = acc[i][j][e] + bv;
                 if (d.res) v += d.res[ro + col];
                 v = v > 0.f ? v : v * d.out_slope;
+                if (d.gate) v = d.gate[yo + col] > 0.f ? v : v * d.gate_slope;
                 d.y[yo + col] = v;
             }
         }
@@ -555,13 +567,14 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.w_ld = d.w_ld > 0 ? d.w_ld : g.K;
     g.x_zs = splits > 1 ? d.x_split : 0; g.w_zs = splits > 1 ? d.w_split : 0; g.y_zs = splits > 1 ? d.y_split : 0;
     VPHO_REQUIRE(g.w_ld >= g.K && g.w_ld % 4 == 0 && g.x_zs % 4 == 0 && g.w_zs % 4 == 0, "vpho_conv2d_nhwc_f32: w_ld / split strides must be multiples of 4, w_ld >= K");
-    VPHO_REQUIRE(splits == 1 || (!d.res && !d.bias && !d.in_scale), "vpho_conv2d_nhwc_f32: split launches produce plain partial sums (no bias / residual / prologue)");
+    VPHO_REQUIRE(splits == 1 || (!d.res && !d.bias && !d.in_scale && !d.gate), "vpho_conv2d_nhwc_f32: split launches produce plain partial sums (no bias / residual / prologue / gate)");
     g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
     g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
     // 16-byte epilogue when every output pixel's channel run (and the residual's) is 16-byte addressable
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     g.vec_epilogue = (d.Cout % 4 == 0 && al16(d.y) && d.y_sx % 4 == 0 && d.y_sy % 4 == 0 && d.y_sn % 4 == 0 &&
                       (!d.bias || al16(d.bias)) &&
+                      (!d.gate || al16(d.gate)) &&
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
     static const int dbg = getenv("VPHO_CONV_DBG") ? atoi(getenv("VPHO_CONV_DBG")) : 0;
     g.dbg = dbg;

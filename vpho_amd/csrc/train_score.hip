@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void bn_finish_grads_kernel(const double* __re
 // y = lrelu((x - mean) * invstd * gamma + beta, slope); a thread handles V consecutive channels of a row
 template <int V>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, long long rows, int C, int ld, float slope, float* __restrict__ y) {
+                                const float* __restrict__ beta, const float* __restrict__ res, long long rows, int C, int ld, float slope,
+                                float* __restrict__ y) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cq = C / V;
     if (i >= rows * cq) return;
@@ -372,8 +373,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     const int c = (int)(i - r * cq) * V;
     float xv[V], m[V], is[V], ga[V], be[V], o[V];
     ldv<V>(x + r * ld + c, xv); ldv<V>(mean + c, m); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga); ldv<V>(beta + c, be);
+    float rv[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) { const float t = (xv[v] - m[v]) * is[v] * ga[v] + be[v]; o[v] = t > 0.f ? t : t * slope; }
+    for (int v = 0; v < V; ++v) rv[v] = 0.f;
+    if (res) ldv<V>(res + r * ld + c, rv);                       // residual branch of a bottleneck, added before the activation
+#pragma unroll
+    for (int v = 0; v < V; ++v) { const float t = ((xv[v] - m[v]) * is[v] * ga[v] + be[v]) + rv[v]; o[v] = t > 0.f ? t : t * slope; }
     stv<V>(y + r * ld + c, o);
 }
 // dx = gamma * invstd / rows * (rows * dy - dbeta - xhat * dgamma)
@@ -665,18 +670,19 @@ extern "C" int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, i
 extern "C" long long vpho_bn_workspace_bytes(int C) { return C > 0 ? (long long)256 * 2 * C * 8 : -1; }
 
 extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
-                                         float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* y,
-                                         void* workspace, void* stream) {
+                                         float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* res,
+                                         float* y, void* workspace, void* stream) {
     VPHO_REQUIRE(x && gamma && beta && save_mean && save_invstd && y && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_forward_f32: bad argument");
     VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_f32: running_mean/var must come together");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = launch_col_reduce(BnRedArgs{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace}, s);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
                        running_mean, running_var);
-    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd))
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
+    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd) &&
+        (!res || aligned16(res)))
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, rows, C, ld, slope, y);
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
     return vpho::check_launch("bn_train_forward kernels");
 }
 

@@ -57,7 +57,8 @@ class ConvDesc(C.Structure):
                 ('y_sn', C.c_longlong), ('y_sy', C.c_longlong), ('y_sx', C.c_longlong),
                 ('r_sn', C.c_longlong), ('r_sy', C.c_longlong), ('r_sx', C.c_longlong),
                 ('in_slope', C.c_float), ('out_slope', C.c_float),
-                ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong)]
+                ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong),
+                ('gate', C.c_void_p), ('gate_slope', C.c_float)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -68,11 +69,12 @@ def _addr(t):
 
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
-                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None):
+                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
 
     ``out_view`` = (tensor, y_sn, y_sy, y_sx, element_offset) writes into a strided destination (concat buffers,
-    transposed-convolution phases).  ``res`` is a contiguous (N,OH,OW,Cout) tensor."""
+    transposed-convolution phases).  ``res`` is a contiguous (N,OH,OW,Cout) tensor.  ``gate`` = (tensor shaped like the
+    destination, slope): y = gate > 0 ? y : slope * y (LeakyReLU backward fused into an input-gradient convolution)."""
     N, H, W, x_ld = x.shape
     cin = x_ld if cin is None else cin
     cout = w.shape[0]
@@ -93,6 +95,9 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
         _ptr(yt, torch.float32)
         d.y = yt.data_ptr() + 4 * off
         ret = yt
+        if gate is not None:
+            assert gate[0].shape == yt.shape and gate[0].is_contiguous() and yt.is_contiguous()
+            d.gate, d.gate_slope = _ptr(gate[0], torch.float32).value + 4 * off, gate[1]
     else:
         if out is None:
             out = torch.empty((N, OH, OW, cout), device=x.device, dtype=torch.float32)
@@ -100,6 +105,9 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
         ld = out.shape[-1]
         d.y, d.y_sx, d.y_sy, d.y_sn = out.data_ptr(), ld, ld * OW, ld * OW * OH
         ret = out
+        if gate is not None:
+            assert gate[0].shape == out.shape
+            d.gate, d.gate_slope = _ptr(gate[0], torch.float32).value, gate[1]
     if res is not None:
         assert res.shape == (N, OH, OW, cout)
         d.r_sx, d.r_sy, d.r_sn = cout, cout * OW, cout * OW * OH
@@ -723,14 +731,14 @@ def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None):
     return dw
 
 
-def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0):
+def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0, res=None):
     """x (..., C) NHWC -> y, (save_mean, save_invstd); running stats updated in place (nn.BatchNorm2d.train())"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y, mean, invstd = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
     ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
     _call('vpho_bn_train_forward_f32', _f32(x), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(beta), F(eps), F(momentum), F(slope),
-          _f32(running_mean), _f32(running_var), _f32(mean), _f32(invstd), _f32(y), _ptr(ws))
+          _f32(running_mean), _f32(running_var), _f32(mean), _f32(invstd), _f32(res), _f32(y), _ptr(ws))
     return y, (mean, invstd)
 
 

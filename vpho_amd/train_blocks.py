@@ -15,9 +15,9 @@ class BottleneckTrain:
     def __init__(self, params, stride=1):
         self.p, self.stride = params, stride
 
-    def _bn(self, name, x, slope):
+    def _bn(self, name, x, slope, res=None):
         b = self.p[name]
-        return ops.bn_train_forward(x, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=slope)
+        return ops.bn_train_forward(x, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=slope, res=res)
 
     def forward(self, x):
         p, s = self.p, self.stride
@@ -26,13 +26,12 @@ class BottleneckTrain:
         c2 = ops.conv2d_nhwc(a1, p['conv2'], kh=3, kw=3, stride=s, pad=1)
         a2, s2 = self._bn('bn2', c2, SLOPE)
         c3 = ops.conv2d_nhwc(a2, p['conv3'])
-        b3, s3 = self._bn('bn3', c3, 1.0)
         if 'down' in p:
             cd = ops.conv2d_nhwc(x, p['down'], stride=s)
             res, sd = self._bn('bnd', cd, 1.0)
         else:
             cd, res, sd = None, x, None
-        out = ops.add_lrelu(b3, res, SLOPE)
+        out, s3 = self._bn('bn3', c3, SLOPE, res=res)                  # lrelu(bn3(c3) + shortcut): the add rides in the BatchNorm apply
         self.saved = dict(x=x, c1=c1, a1=a1, s1=s1, c2=c2, a2=a2, s2=s2, c3=c3, s3=s3, cd=cd, sd=sd, out=out)
         return out
 
@@ -44,10 +43,10 @@ class BottleneckTrain:
         dsum = ops.lrelu_bwd(dout, S['out'], SLOPE)
         dc3, g['bn3.gamma'], g['bn3.beta'] = ops.bn_train_backward(S['c3'], dsum, p['bn3']['gamma'], S['s3'])
         g['conv3'] = CB.conv2d_wgrad(S['a2'], dc3, 1, 1)
-        da2 = ops.lrelu_bwd(CB.conv2d_dgrad(dc3, p['conv3'], S['a2'].shape[1:3], 1, 1), S['a2'], SLOPE)
+        da2 = CB.conv2d_dgrad(dc3, p['conv3'], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], SLOPE))
         dc2, g['bn2.gamma'], g['bn2.beta'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'])
         g['conv2'] = CB.conv2d_wgrad(S['a1'], dc2, 3, 3, s, 1)
-        da1 = ops.lrelu_bwd(CB.conv2d_dgrad(dc2, p['conv2'], (H, W), 3, 3, s, 1), S['a1'], SLOPE)
+        da1 = CB.conv2d_dgrad(dc2, p['conv2'], (H, W), 3, 3, s, 1, gate=(S['a1'], SLOPE))
         dc1, g['bn1.gamma'], g['bn1.beta'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
         g['conv1'] = CB.conv2d_wgrad(S['x'], dc1, 1, 1)
         dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1)
@@ -270,15 +269,15 @@ class EncoderTrain:
             # out = conv3(a2) + h
             G[f'{k}.conv3.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dh, 1, 1), *self.shapes[f'{k}.conv3.weight'])
             G[f'{k}.conv3.bias'] = CB.conv2d_bias_grad(dh)
-            da2 = ops.lrelu_bwd(CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1), S['a2'], SLOPE)
+            da2 = CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1, gate=(S['a2'], SLOPE))
             dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'])
             G[f'{k}.conv2.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a1'], dc2, 3, 3, 1, 1), *self.shapes[f'{k}.conv2.weight'])
             G[f'{k}.conv2.bias'] = CB.conv2d_bias_grad(dc2)
-            da1 = ops.lrelu_bwd(CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1), S['a1'], SLOPE)
+            da1 = CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1, gate=(S['a1'], SLOPE))
             dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
             G[f'{k}.conv1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a0'], dc1, 1, 1), *self.shapes[f'{k}.conv1.weight'])
             G[f'{k}.conv1.bias'] = CB.conv2d_bias_grad(dc1)
-            da0 = ops.lrelu_bwd(CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1), S['a0'], SLOPE)
+            da0 = CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1, gate=(S['a0'], SLOPE))
             dmain, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'] = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'])
             dh = ops.add_lrelu(dmain, dh)                                 # identity shortcut
         x = self.saved['x']
@@ -330,7 +329,7 @@ class HeatmapHeadTrain:
         N, H, W, _ = S['a1'].shape
         G['final_layer.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dout, 1, 1), *self.shapes['final_layer.weight'])
         G['final_layer.bias'] = CB.conv2d_bias_grad(dout)
-        da2 = ops.lrelu_bwd(CB.conv2d_dgrad(dout, self.final[0], S['a2'].shape[1:3], 1, 1), S['a2'], 0.0)
+        da2 = CB.conv2d_dgrad(dout, self.final[0], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], 0.0))
         dup, G['deconv_layers.1.weight'], G['deconv_layers.1.bias'] = ops.bn_train_backward(S['up'], da2, self.bn2['gamma'], S['s2'])
         cin, co = self.shapes['deconv_layers.0.weight'][:2]
         dwt = torch.zeros(self.shapes['deconv_layers.0.weight'], device=dout.device)
