@@ -28,10 +28,11 @@ def _flip_transpose(w_packed, cout, cin, kh, kw):
     return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
 
 
-def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None):
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None):
     """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
     asymmetric top/left paddings of the transposed-convolution phases, stride 1 only).  ``gate`` = (y, slope): the result is
-    additionally passed through the backward of the LeakyReLU that produced y = lrelu(x) (fused into the kernel's epilogue)."""
+    additionally passed through the backward of the LeakyReLU that produced y = lrelu(x) (fused into the kernel's epilogue).
+    ``res`` (stride 1): a gradient of the same shape added to the result (the other branch of a residual sum)."""
     N, OH, OW, cout = dy.shape
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
@@ -44,8 +45,8 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     px = pad if pad_x is None else pad_x
     if stride == 1:
         return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1,
-                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate)
-    assert py == px == pad
+                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate, res=res)
+    assert py == px == pad and res is None
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
     w4 = w_packed.view(cout, kh, kw, cin)
     dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)

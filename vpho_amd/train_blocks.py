@@ -49,13 +49,13 @@ class BottleneckTrain:
         da1 = CB.conv2d_dgrad(dc2, p['conv2'], (H, W), 3, 3, s, 1, gate=(S['a1'], SLOPE))
         dc1, g['bn1.gamma'], g['bn1.beta'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
         g['conv1'] = CB.conv2d_wgrad(S['x'], dc1, 1, 1)
-        dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1)
         if 'down' in p:
+            dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1)
             dcd, g['bnd.gamma'], g['bnd.beta'] = ops.bn_train_backward(S['cd'], dsum, p['bnd']['gamma'], S['sd'])
             g['down'] = CB.conv2d_wgrad(S['x'], dcd, 1, 1, s, 0)
-            dx = ops.add_lrelu(dx, CB.conv2d_dgrad(dcd, p['down'], (H, W), 1, 1, s, 0))
+            dx = CB.conv2d_dgrad(dcd, p['down'], (H, W), 1, 1, 1, 0, res=dx) if s == 1 else ops.add_lrelu(dx, CB.conv2d_dgrad(dcd, p['down'], (H, W), 1, 1, s, 0))
         else:
-            dx = ops.add_lrelu(dx, dsum)
+            dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1, res=dsum)      # identity shortcut: the sum rides in the dgrad epilogue
         return dx, g
 
 
