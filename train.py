@@ -37,11 +37,18 @@ def main():
     from vpho_amd.train_step import DiffusionTrainStep
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus
+    # rehearsal aid for a 1-GPU box: VPHO_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (timings meaningless)
+    rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     assets = synthetic_assets(0)
     sd = synth_state_dict(vpho_net(assets), seed=1)
     step = DiffusionTrainStep(sd, dev, assets=assets)
@@ -89,6 +96,12 @@ def main():
             step.fpn.forward(data['rgb'])
         torch.cuda.synchronize()
         res['ms_backbone_forward'] = 1e3 * (time.perf_counter() - t0) / 3
+    if world > 1:                                       # data parallelism keeps the replicas identical: compare parameter checksums
+        chk = torch.stack([step.master[k].double().sum() for k in step.names]).sum().reshape(1)
+        chk = chk.cpu() if rehearse else chk
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        res['replicas_in_sync'] = bool(all(float(c) == float(allc[0]) for c in allc))
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

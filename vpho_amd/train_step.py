@@ -217,7 +217,12 @@ class DiffusionTrainStep:
                 self.grad_view[k].zero_()
         scale = 1.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == 'gloo' and self.flat_grad.is_cuda:      # CPU rehearsal backend: stage through host memory
+                host = self.flat_grad.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat_grad.copy_(host)
+            else:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             scale = 1.0 / dist.get_world_size()
         self.steps += 1
         hyper = dict(self.hyper, lr=self.hyper['lr'] if lr is None else lr)
