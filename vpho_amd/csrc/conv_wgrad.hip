@@ -166,7 +166,10 @@ struct WgPlan { int bm, bn, tiles_m, tiles_n, splits, m_chunk; };
 WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     WgPlan p;
     const int K = Cin * taps;
-    const bool big = K >= 128 && Cout >= 128;
+    static const int tile_env = getenv("VPHO_WGRAD_TILE") ? atoi(getenv("VPHO_WGRAD_TILE")) : 0;          // tuning aid
+    // 128x128 tiles pay off only for the largest products (measured: 3x3 256->256 on 64x64x64 pixels 100 vs 87 TF/s); everywhere else
+    // the 64x64 tile wins or ties (3x3 128->128: 79 vs 53 TF/s) -- more tiles, hence fewer, longer pixel slices and less partial-sum traffic
+    const bool big = tile_env ? tile_env == 128 : (K >= 128 && Cout >= 128 && (double)M * K * Cout >= 5e10);
     p.bm = p.bn = big ? 128 : 64;
     p.tiles_m = (Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
