@@ -182,3 +182,21 @@ def test_step_with_mano_losses_matches_reference_training_forward():
     assert not bad, bad[:10]
     assert ours <= 1.5 * theirs, (ours, theirs)
     assert sum(k.startswith('head_mano.') for k in grads) == 8
+
+
+def test_gradient_clipping_matches_torch_clip_grad_norm(setup):
+    """cfg.gradient_clip > 0 (accel.clip_grad_norm_, train_diff_hand_obj.py:182-183): the flat gradient buffer after clipping equals
+    torch.nn.utils.clip_grad_norm_ applied to the same gradients"""
+    from vpho_amd.train_step import DiffusionTrainStep
+    sd, data, draws, G = setup
+    step = DiffusionTrainStep(sd, 'cuda', lr=0.0, weight_decay=0.0, loss_weights=dict(hm_hand=1e3, hm_obj=1e3))
+    gt_h, gt_o = torch.from_numpy(G['gt_hand6d']).cuda(), torch.from_numpy(G['gt_obj']).cuda()
+    step.step(data, gt_h, gt_o, draws, gradient_clip=-1.0)
+    raw = step.flat_grad.clone()
+    step2 = DiffusionTrainStep(sd, 'cuda', lr=0.0, weight_decay=0.0, loss_weights=dict(hm_hand=1e3, hm_obj=1e3))
+    step2.step(data, gt_h, gt_o, draws, gradient_clip=5.0)
+    params = [torch.nn.Parameter(torch.zeros_like(raw))]
+    params[0].grad = raw.clone()
+    total = torch.nn.utils.clip_grad_norm_(params, 5.0)
+    assert float(total) > 5.0                                     # the clip is active on this batch
+    np.testing.assert_allclose(step2.flat_grad.cpu().numpy(), params[0].grad.cpu().numpy(), rtol=2e-3, atol=1e-6 * float(raw.abs().max()))

@@ -36,6 +36,7 @@ class Config:
         self.topk_obj = 5
         self.asset_root = 'asset'
         self.base_learning_rate = 2e-4
+        self.gradient_clip = -1.0
         self.train_scope = 'full'     # 'full': backbone + heads + encoders + score networks; 'score': score networks on frozen features
         self.weight_diff_hand_loss = 1.0
         self.weight_diff_obj_loss = 1.0
@@ -75,6 +76,7 @@ def _parser():
     p.add_argument('--topk_obj', type=int, default=5)
     p.add_argument('--asset_root', type=str, default='asset')
     p.add_argument('--base_learning_rate', type=float, default=2e-4)
+    p.add_argument('--gradient_clip', type=float, default=-1.)
     p.add_argument('--train_scope', type=str, default='full', choices=['full', 'score'])
     p.add_argument('--weight_diff_hand_loss', type=float, default=1.0)
     p.add_argument('--weight_diff_obj_loss', type=float, default=1.0)

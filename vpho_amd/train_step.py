@@ -6,7 +6,8 @@ re-alignment -> RoIAlign -> the two-branch backbone, data-parallel gradient aver
 
 With the MANO tables (``assets``) and the hand ground truth in the batch the step also carries ``head_mano`` and the four MANO
 losses (vert / joint / mano_pose / mano_shape, lib/model/head_mano.py:89-133).  Not part of this step: the physics losses and the
-modules only they reach (cross modules, ``head_physics``); gradient clipping is off as in the reference's default.
+modules only they reach (cross modules, ``head_physics``).  ``cfg.gradient_clip`` > 0 clips the global gradient norm (off by default,
+as in the reference).
 Composition of ``train_blocks`` / ``train_score``; torch allocates, slices and, under ``torch.distributed``, all-reduces ONE
 flat gradient buffer (RCCL under backend 'nccl').
 """
@@ -198,7 +199,7 @@ class DiffusionTrainStep:
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, data, gt_hand, gt_obj, draws=None, repeat_num=None, eps=1e-5, lr=None):
+    def step(self, data, gt_hand, gt_obj, draws=None, repeat_num=None, eps=1e-5, lr=None, gradient_clip=None):
         """loss_and_grads + gradient average over the ranks (one all-reduce of the flat buffer) + AdamW on every tensor.
         Without `draws` they are made like loss_fn's (torch.rand / torch.randn on the device, score_based_model.py:24,31)."""
         bs = data['rgb'].shape[0]
@@ -224,6 +225,13 @@ class DiffusionTrainStep:
             else:
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             scale = 1.0 / dist.get_world_size()
+        clip = cfg.gradient_clip if gradient_clip is None else gradient_clip
+        if clip > 0:                                       # accel.clip_grad_norm_ (train_diff_hand_obj.py:182-183): global L2 norm of the averaged gradients
+            if scale != 1.0:
+                self.flat_grad.mul_(scale)
+                scale = 1.0
+            coef = (clip / (self.flat_grad.norm(2) + 1e-6)).clamp(max=1.0)            # torch.nn.utils.clip_grad_norm_, no host sync
+            self.flat_grad.mul_(coef)
         self.steps += 1
         hyper = dict(self.hyper, lr=self.hyper['lr'] if lr is None else lr)
         with torch.cuda.device(self.dev):
