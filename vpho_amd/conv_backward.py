@@ -1,13 +1,14 @@
-"""Backward of the NHWC convolutions (building blocks for the backbone backward; not yet wired into a
-training step).  Both gradients reuse the forward fp32-MFMA implicit-GEMM kernel ``vpho_conv2d_nhwc_f32``:
+"""Backward of the NHWC convolutions (driven by ``train_blocks`` / ``train_step``).
 
 * ``conv2d_dgrad``: the gradient w.r.t. the input of a stride-1 convolution is a stride-1 convolution of dY with the spatially
-  flipped, channel-transposed weights; for stride 2 every output-pixel parity (iy%2, ix%2) only sees the taps r with
-  r = (iy + pad) mod 2, so dX is four small convolutions of dY written to interleaved positions (the same phase trick as the
-  forward ConvTranspose);
-* ``conv2d_wgrad``: dW[co][(r,s,ci)] = sum_p dY[p][co] * x_gathered[p][(r,s,ci)] is the GEMM dY^T . im2col(x)^T with the
-  pixel index as the reduction dimension; both operands are brought into the kernel's [row][K] layout by a transpose and by
-  ``vpho_im2col_t_f32`` (9x the input for a 3x3 -- memory, not a fused gather; adequate for the 288 GB part, to be fused).
+  flipped, channel-transposed weights -- the forward fp32-MFMA implicit-GEMM kernel ``vpho_conv2d_nhwc_f32``, whose epilogue also
+  carries the LeakyReLU backward (``gate``) and the other branch of a residual sum (``res``); for stride 2 every output-pixel
+  parity (iy%2, ix%2) only sees the taps r with r = (iy + pad) mod 2, so dX is four small convolutions of dY written to
+  interleaved positions (the same phase trick as the forward ConvTranspose);
+* ``conv2d_wgrad``: dW[co][(r,s,ci)] = sum_p dY[p][co] * x_gathered[p][(r,s,ci)] with the pixel index as the reduction dimension:
+  ``vpho_conv2d_wgrad_nhwc_f32`` (csrc/conv_wgrad.hip), an implicit TN GEMM that stages both NHWC operands k-major and gathers
+  the taps itself -- no im2col, no transposes.  Channel counts that are not multiples of 4 (the 21 / 27-channel heat-map outputs)
+  take the explicit path: a transpose, ``vpho_im2col_t_f32`` and split launches of the forward kernel.
 
 Weights are in the forward kernel's packed layout (Cout, KH*KW*Cin), activations NHWC fp32.  torch only allocates and permutes.
 Reference semantics: torch.nn.functional.conv2d's autograd (what ``loss.backward()`` does for every ``nn.Conv2d`` of

@@ -1,7 +1,7 @@
 """Training-mode forward + backward of a ResNet bottleneck (SURVEY.md 8f row 4 building block): the composition of the
 convolution, BatchNorm(train) and LeakyReLU kernels for ``Bottleneck.forward`` (lib/model/backbone_FPN_HFL.py:330-350) under
 ``model.train()`` and ``loss.backward()``.  Activations NHWC fp32, weights in the forward kernel's packed layout
-(Cout, KH*KW*Cin); torch only allocates.  Not yet driven by a full training step."""
+(Cout, KH*KW*Cin); torch only allocates.  Composed into the end-to-end step by ``train_step.DiffusionTrainStep``."""
 from . import ops
 from . import conv_backward as CB
 
