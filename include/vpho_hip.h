@@ -369,7 +369,9 @@ int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int
  * dy [N][OH][OW][C] -> dx [N][H][W][C] */
 int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);
 /* torchvision.ops.roi_align backward (VPHO.py:125-128 under loss.backward()): dy [N][P][P][ldo] (channel slice c_off..c_off+C, optionally
- * W-flipped like the forward) scattered into dfeat [N][H][W][C] += ...; dfeat must be zero-initialised (fp32 atomics) */
+ * W-flipped like the forward) accumulated into dfeat [N][H][W][C] (+=; zero-initialise it, or pass another gradient of the same
+ * map to sum both).  One RoI per image (box n belongs to image n).  Channel counts / strides that are multiples of 4 take a gather
+ * with a fixed summation order (each feature pixel sums the few bins that reach it); other shapes scatter with fp32 atomics. */
 int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                 int out_size, const unsigned char* flip_w, float* dfeat, void* stream);
 /* backward of vpho_align_heatmap_nhwc_f32 (align_hm_to_bbox_rectangle + flip, VPHO.py:333-346,139): dout [N][S][S][C] -> dhm [N][S][S][C]

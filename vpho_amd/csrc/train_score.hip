@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -538,6 +539,83 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ dy, int ldo, int 
     }
 }
 
+// The same gradient as a GATHER (one RoI per image, so every feature pixel has one owner): bilinear sampling is separable,
+//   dfeat[n,y,x,c] += 1/count * sum_ph sum_pw WY[y][ph] * WX[x][pw] * dy[n,ph,pw,c],
+// WY[y][ph] = total weight the samples of bin row ph put on feature row y (same border rules as the forward), WX likewise.
+// A workgroup owns one feature row of one image: it builds WY (one row) and WX (W x P) in LDS, then every thread accumulates
+// channel quads of its pixels over the few bins that reach them.  No atomics: fixed summation order, each output written once.
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ dy, int ldo, int c_off, int H, int W, int C,
+                                                                   const float* __restrict__ boxes, float scale, int P,
+                                                                   const unsigned char* __restrict__ flip_w, float* __restrict__ dfeat) {
+    extern __shared__ float sm[];
+    float* wy = sm;                       // [P]
+    float* wx = sm + P;                   // [W][P]
+    int* rng = reinterpret_cast<int*>(wx + W * P);      // [2] ph range, then [W][2] pw ranges
+    const int y = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float x1 = boxes[n * 4 + 0] * scale, y1 = boxes[n * 4 + 1] * scale;
+    const float x2 = boxes[n * 4 + 2] * scale, y2 = boxes[n * 4 + 3] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = fmaxf((float)(gh * gw), 1.f);
+    // weight of one sample coordinate on integer position `pos` of an axis of length L (forward's clamping rules)
+    auto axis_w = [](float s, int pos, int L) -> float {
+        if (s < -1.0f || s > (float)L) return 0.f;
+        if (s <= 0.f) s = 0.f;
+        int lo = (int)s, hi;
+        if (lo >= L - 1) { hi = lo = L - 1; s = (float)lo; } else hi = lo + 1;
+        const float l = s - (float)lo;
+        return (pos == lo ? 1.f - l : 0.f) + (pos == hi ? l : 0.f);
+    };
+    if (tid < P) {
+        float s = 0.f;
+        for (int iy = 0; iy < gh; ++iy) s += axis_w(y1 + tid * bh + ((float)iy + 0.5f) * bh / (float)gh, y, H);
+        wy[tid] = s;
+    }
+    for (int i = tid; i < W * P; i += 256) {
+        const int x = i / P, pw = i - x * P;
+        float s = 0.f;
+        for (int ix = 0; ix < gw; ++ix) s += axis_w(x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw, x, W);
+        wx[i] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int lo = P, hi = -1;
+        for (int k = 0; k < P; ++k) if (wy[k] != 0.f) { if (lo == P) lo = k; hi = k; }
+        rng[0] = lo; rng[1] = hi;
+    }
+    if (tid >= 64 && tid < 64 + W) {                 // W <= 192 checked by the host
+        const int x = tid - 64;
+        int lo = P, hi = -1;
+        for (int k = 0; k < P; ++k) if (wx[x * P + k] != 0.f) { if (lo == P) lo = k; hi = k; }
+        rng[2 + 2 * x] = lo; rng[3 + 2 * x] = hi;
+    }
+    __syncthreads();
+    const int plo = rng[0], phi = rng[1];
+    if (phi < plo) return;                             // no sample of this RoI touches this row
+    const bool flip = flip_w && flip_w[n];
+    const int C4 = C >> 2;
+    const float inv = 1.f / cnt;
+    for (int it = tid; it < W * C4; it += 256) {
+        const int x = it / C4, c = (it - x * C4) * 4;
+        const int qlo = rng[2 + 2 * x], qhi = rng[3 + 2 * x];
+        if (qhi < qlo) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ph = plo; ph <= phi; ++ph) {
+            const float a = wy[ph];
+            if (a == 0.f) continue;
+            for (int pw = qlo; pw <= qhi; ++pw) {
+                const float w = a * wx[x * P + pw];
+                if (w == 0.f) continue;
+                const int ow = flip ? P - 1 - pw : pw;
+                acc += w * *reinterpret_cast<const f32x4*>(dy + (((long long)n * P + ph) * P + ow) * ldo + c_off + c);
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(dfeat + (((long long)n * H + y) * W + x) * C + c);
+        *o = *o + acc * inv;
+    }
+}
+
 // backward of vpho_align_heatmap_nhwc_f32 (VPHO.py:333-346 + the W-flip of :139): out[b,i,j] = bilinear_zero(hm[b]; x(i), y(j)),
 // so d hm[b, y0..y0+1, x0..x0+1] += weights * d out[b, i, flip ? S-1-j : j]; fp32 atomics (d hm zero-initialised)
 __global__ void align_heatmap_bwd_kernel(const float* __restrict__ dout, int N, int S, int C, const float* __restrict__ bbox,
@@ -730,6 +808,13 @@ extern "C" int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH,
 extern "C" int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                            int out_size, const unsigned char* flip_w, float* dfeat, void* stream) {
     VPHO_REQUIRE(dy && boxes && dfeat && N > 0 && H > 0 && W > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_bwd_nhwc_f32: bad argument");
+    const size_t lds = (size_t)(out_size + W * out_size) * sizeof(float) + (size_t)(2 + 2 * W) * sizeof(int);
+    static const int force_atomic = getenv("VPHO_ROI_BWD_ATOMIC") ? atoi(getenv("VPHO_ROI_BWD_ATOMIC")) : 0;      // tuning aid
+    if (!force_atomic && C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && aligned16(dy) && aligned16(dfeat) && W <= 192 && out_size <= 256 && lds <= 48 * 1024) {
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(H, N), dim3(256), lds, (hipStream_t)stream, dy, ldo, c_off, H, W, C, boxes, spatial_scale, out_size,
+                           flip_w, dfeat);
+        return vpho::check_launch("roi_align_bwd_gather_kernel");
+    }
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(nblk((long long)N * out_size * out_size * C)), dim3(256), 0, (hipStream_t)stream, dy, ldo, c_off, N, H, W, C,
                        boxes, spatial_scale, out_size, flip_w, dfeat);
     return vpho::check_launch("roi_align_bwd_kernel");
