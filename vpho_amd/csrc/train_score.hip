@@ -427,37 +427,52 @@ __global__ void add_lrelu_kernel(const float* __restrict__ a, const float* __res
 // ------------------------------------------------------------------------------------------------ pooling / resize backward
 // nn.MaxPool2d backward as a gather (deterministic): input pixel (iy, ix) receives dy of every window whose arg-max it is --
 // the first maximum in row-major window order, as torch's CPU/GPU kernels pick it.
+template <int V>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int H, int W, int C, int k, int stride, int pad,
                                    int OH, int OW, float* __restrict__ dx) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)N * H * W * C) return;
-    const int c = (int)(i % C);
-    long long p = i / C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // V consecutive channels of one input pixel
+    const int CV = C / V;
+    if (i >= (long long)N * H * W * CV) return;
+    const int c = (int)(i % CV) * V;
+    long long p = i / CV;
     const int ix = (int)(p % W); p /= W;
     const int iy = (int)(p % H);
     const long long n = p / H;
     const float* xb = x + n * H * W * (long long)C + c;
-    float g = 0.f;
+    float g[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) g[v] = 0.f;
     // windows covering iy: oy*stride - pad <= iy <= oy*stride - pad + k - 1
     const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
     const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            float m = -INFINITY;
-            int ay = -1, ax = -1;
+            float m[V];
+            bool mine[V];                                  // is (iy, ix) the FIRST maximum of this window (row-major order)?
+#pragma unroll
+            for (int v = 0; v < V; ++v) { m[v] = -INFINITY; mine[v] = false; }
+            bool first = true;
             for (int r = 0; r < k; ++r) {
                 const int yy = oy * stride - pad + r;
                 if (yy < 0 || yy >= H) continue;
                 for (int q = 0; q < k; ++q) {
                     const int xx = ox * stride - pad + q;
                     if (xx < 0 || xx >= W) continue;
-                    const float v = xb[((long long)yy * W + xx) * C];
-                    if (v > m || ay < 0) { m = v; ay = yy; ax = xx; }
+                    float xv[V];
+                    ldv<V>(xb + ((long long)yy * W + xx) * C, xv);
+                    const bool here = yy == iy && xx == ix;
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        if (xv[v] > m[v] || first) { m[v] = xv[v]; mine[v] = here; }
+                    first = false;
                 }
             }
-            if (ay == iy && ax == ix) g += dy[((n * OH + oy) * OW + ox) * (long long)C + c];
+            float dv[V];
+            ldv<V>(dy + ((n * OH + oy) * OW + ox) * (long long)C + c, dv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[v] += mine[v] ? dv[v] : 0.f;
         }
-    dx[i] = g;
+    stv<V>(dx + ((n * H + iy) * W + ix) * (long long)C + c, g);
 }
 
 __device__ inline void lin_src_t(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
@@ -795,7 +810,10 @@ extern "C" int vpho_add_lrelu_f32(const float* a, const float* b, long long n, f
 extern "C" int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream) {
     VPHO_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, "vpho_maxpool_bwd_nhwc_f32: bad argument");
     const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H, W, C, k, stride, pad, OH, OW, dx);
+    if (C % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx))
+        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(nblk((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, dy, N, H, W, C, k, stride, pad, OH, OW, dx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H, W, C, k, stride, pad, OH, OW, dx);
     return vpho::check_launch("maxpool_bwd_kernel");
 }
 
