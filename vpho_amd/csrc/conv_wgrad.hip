@@ -61,6 +61,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     for (int j = 0; j < A_LD; ++j) a_row[j] = (wave + NW * j) * (64 / A_CPR) + lane / A_CPR;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) b_row[j] = (wave + NW * j) * (64 / B_CPR) + lane / B_CPR;
+    // pixel (n, oy, ox) of each x row of the FIRST stage (stages are filled in order kt = 0, 1, ...: fill() advances them)
+    int b_n[B_LD], b_oy[B_LD], b_ox[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int m = m_begin + b_row[j];
+        b_n[j] = m / ohw;
+        const int rem = m - b_n[j] * ohw;
+        b_oy[j] = rem / a.OW; b_ox[j] = rem - b_oy[j] * a.OW;
+    }
     // buffer addressing (32-bit byte offsets, extents < 4 GB checked by the host): offset 0xFFFFFFFF is out of range and makes the
     // hardware write zeros -- out-of-image taps, pixel and channel tails (see conv_igemm.hip)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0xFFFFFFF0u, 0x00020000);
@@ -82,12 +91,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
             const int m = mb + b_row[j];
             unsigned off = 0xFFFFFFFFu;
             if (b_ok && m < m_end) {
-                const int n = m / ohw, rem = m - n * ohw;
-                const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                const unsigned iy = (unsigned)(oy * a.stride + tr - a.pad_y), ix = (unsigned)(ox * a.stride + ts - a.pad_x);
-                if (iy < (unsigned)a.H && ix < (unsigned)a.W) off = (((unsigned)(n * a.H + (int)iy) * (unsigned)a.W + ix) * (unsigned)a.x_ld + (unsigned)b_ci) * 4u;
+                const unsigned iy = (unsigned)(b_oy[j] * a.stride + tr - a.pad_y), ix = (unsigned)(b_ox[j] * a.stride + ts - a.pad_x);
+                if (iy < (unsigned)a.H && ix < (unsigned)a.W) off = (((unsigned)(b_n[j] * a.H + (int)iy) * (unsigned)a.W + ix) * (unsigned)a.x_ld + (unsigned)b_ci) * 4u;
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(Bs + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
+            // this row's pixel for the next stage: BK pixels further, (n, oy, ox) advanced without a division
+            b_ox[j] += BK;
+            while (b_ox[j] >= a.OW) { b_ox[j] -= a.OW; if (++b_oy[j] == a.OH) { b_oy[j] = 0; ++b_n[j]; } }
         }
     };
 
