@@ -96,8 +96,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(Bs + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
             // this row's pixel for the next stage: BK pixels further, (n, oy, ox) advanced without a division
-            b_ox[j] += BK;
-            while (b_ox[j] >= a.OW) { b_ox[j] -= a.OW; if (++b_oy[j] == a.OH) { b_oy[j] = 0; ++b_n[j]; } }
+            if (a.OW >= 8) {
+                b_ox[j] += BK;
+                while (b_ox[j] >= a.OW) { b_ox[j] -= a.OW; if (++b_oy[j] == a.OH) { b_oy[j] = 0; ++b_n[j]; } }
+            } else {                                       // narrow maps / rows as 1x1 images: the wrap loop would run up to BK times
+                const int m2 = m + BK;
+                b_n[j] = m2 / ohw;
+                const int rem = m2 - b_n[j] * ohw;
+                b_oy[j] = rem / a.OW; b_ox[j] = rem - b_oy[j] * a.OW;
+            }
         }
     };
 
