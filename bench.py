@@ -40,7 +40,7 @@ def parse():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
     p.add_argument('--cpu_images', type=int, default=4)
-    p.add_argument('--pipeline', type=int, default=2, help='evaluation batches kept in flight (1 = sequential loop)')
+    p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
     return p.parse_args()
 
 

@@ -85,7 +85,7 @@ class PipelinedPredictor:
     The CPU prior draws are made by the submitting thread, in submission order (hand then object per batch), so a seeded
     run draws exactly what the sequential loop of the reference would (sde.py:26-28)."""
 
-    def __init__(self, model, depth=2):
+    def __init__(self, model, depth=3):
         import threading
         from concurrent.futures import ThreadPoolExecutor
         from .model.engine import Engine

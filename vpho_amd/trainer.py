@@ -130,9 +130,9 @@ class Trainer:
         cfg, bs = self.cfg, self.cfg.eval_batch_size
         rows = []
         t0 = time.perf_counter()
-        # two batches in flight (independent images; see evaluate.PipelinedPredictor); batch 0 also provides the synthetic
+        # three batches in flight (independent images; see evaluate.PipelinedPredictor); batch 0 also provides the synthetic
         # ground truth (its own regression output), so it is evaluated first
-        pipe = E.PipelinedPredictor(self.model, depth=2)
+        pipe = E.PipelinedPredictor(self.model, depth=3)
         make = lambda i: {k: (v.to(self.device) if torch.is_tensor(v) else v)
                           for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
         b0 = make(0)
