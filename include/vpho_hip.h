@@ -375,7 +375,7 @@ int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, in
 int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                 int out_size, const unsigned char* flip_w, float* dfeat, void* stream);
 /* backward of vpho_align_heatmap_nhwc_f32 (align_hm_to_bbox_rectangle + flip, VPHO.py:333-346,139): dout [N][S][S][C] -> dhm [N][S][S][C]
- * (+=, fp32 atomics: zero-initialise dhm) */
+ * (+=: zero-initialise dhm; a gather with a fixed summation order for S <= 120, fp32 atomics beyond) */
 int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                     const unsigned char* flip_w, float* dhm, void* stream);
 /* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */

@@ -200,3 +200,19 @@ def test_gradient_clipping_matches_torch_clip_grad_norm(setup):
     total = torch.nn.utils.clip_grad_norm_(params, 5.0)
     assert float(total) > 5.0                                     # the clip is active on this batch
     np.testing.assert_allclose(step2.flat_grad.cpu().numpy(), params[0].grad.cpu().numpy(), rtol=2e-3, atol=1e-6 * float(raw.abs().max()))
+
+
+def test_gradients_are_bitwise_reproducible(setup):
+    """every reduction of the step has a fixed order (gathers instead of atomic scatters, ordered slice sums): two passes over the same
+    batch give bit-identical losses and gradients"""
+    from vpho_amd.train_step import DiffusionTrainStep
+    sd, data, draws, G = setup
+    step = DiffusionTrainStep(sd, 'cuda', loss_weights=dict(hm_hand=1e3, hm_obj=1e3))
+    gt_h, gt_o = torch.from_numpy(G['gt_hand6d']).cuda(), torch.from_numpy(G['gt_obj']).cuda()
+    L1, g1 = step.loss_and_grads(data, gt_h, gt_o, draws)
+    L1 = {k: float(v) for k, v in L1.items()}
+    g1 = {k: v.clone() for k, v in g1.items()}
+    L2, g2 = step.loss_and_grads(data, gt_h, gt_o, draws)
+    assert all(float(L2[k]) == L1[k] for k in L1)
+    differing = [k for k in g1 if not torch.equal(g1[k], g2[k])]
+    assert not differing, differing[:5]

@@ -658,6 +658,62 @@ __global__ void align_heatmap_bwd_kernel(const float* __restrict__ dout, int N, 
     add(y0 + 1, x0, (1.f - tx) * ty); add(y0 + 1, x0 + 1, tx * ty);
 }
 
+// The same gradient as a gather (the resampling grid is separable: ix depends on i only, iy on j only): a workgroup owns one row yy of
+// one image, builds WY[j] (weight of sample row j on yy) and WX[xx][i] in LDS and sums, per pixel and channel, the few samples that
+// reach it in a fixed order -- no atomics.
+__global__ __launch_bounds__(256) void align_heatmap_bwd_gather_kernel(const float* __restrict__ dout, int S, int C, const float* __restrict__ bbox,
+                                                                       const float* __restrict__ bbox_rect, const unsigned char* __restrict__ flip_w,
+                                                                       float* __restrict__ dhm) {
+    extern __shared__ float sm[];
+    float* wy = sm;                        // [S]
+    float* wx = sm + S;                    // [S (xx)][S (i)]
+    int* rng = reinterpret_cast<int*>(wx + S * S);     // [2] j range, [S][2] i ranges
+    const int yy = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float relw = (bbox_rect[n * 4 + 2] - bbox_rect[n * 4 + 0]) / (bbox[n * 4 + 2] - bbox[n * 4 + 0]);
+    const float relh = (bbox_rect[n * 4 + 3] - bbox_rect[n * 4 + 1]) / (bbox[n * 4 + 3] - bbox[n * 4 + 1]);
+    auto axis_w = [S](int k, float rel, int pos) -> float {        // weight of sample k of an axis on integer position pos
+        const float g = ((float)k / (float)(S - 1) * 2.f - 1.f) * rel;
+        const float t = ((g + 1.f) * (float)S - 1.f) / 2.f;
+        const float f = floorf(t);
+        const int p0 = (int)f;
+        const float fr = t - f;
+        return (pos == p0 ? 1.f - fr : 0.f) + (pos == p0 + 1 ? fr : 0.f);
+    };
+    if (tid < S) wy[tid] = axis_w(tid, relh, yy);
+    for (int e = tid; e < S * S; e += 256) { const int xx = e / S, i = e - xx * S; wx[e] = axis_w(i, relw, xx); }
+    __syncthreads();
+    if (tid == 0) {
+        int lo = S, hi = -1;
+        for (int k = 0; k < S; ++k) if (wy[k] != 0.f) { if (lo == S) lo = k; hi = k; }
+        rng[0] = lo; rng[1] = hi;
+    }
+    if (tid >= 64 && tid < 64 + S) {                   // S <= 192 checked by the host
+        const int xx = tid - 64;
+        int lo = S, hi = -1;
+        for (int k = 0; k < S; ++k) if (wx[xx * S + k] != 0.f) { if (lo == S) lo = k; hi = k; }
+        rng[2 + 2 * xx] = lo; rng[3 + 2 * xx] = hi;
+    }
+    __syncthreads();
+    const int jlo = rng[0], jhi = rng[1];
+    const bool flip = flip_w && flip_w[n];
+    for (int e = tid; e < S * C; e += 256) {
+        const int xx = e / C, c = e - xx * C;
+        const int ilo = rng[2 + 2 * xx], ihi = rng[3 + 2 * xx];
+        float acc = 0.f;
+        for (int i = ilo; i <= ihi; ++i) {
+            const float a = wx[xx * S + i];
+            if (a == 0.f) continue;
+            for (int j = jlo; j <= jhi; ++j) {
+                const float w = a * wy[j];
+                if (w == 0.f) continue;
+                const int oj = flip ? S - 1 - j : j;
+                acc += w * dout[(((long long)n * S + i) * S + oj) * C + c];
+            }
+        }
+        dhm[(((long long)n * S + yy) * S + xx) * C + c] += acc;
+    }
+}
+
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, then bias-corrected moments
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              float lr, float beta1, float beta2, float eps, float wd, float step_size, float sqrt_bc2, float grad_scale) {
@@ -841,6 +897,11 @@ extern "C" int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, 
 extern "C" int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                                const unsigned char* flip_w, float* dhm, void* stream) {
     VPHO_REQUIRE(dout && bbox && bbox_rect && dhm && N > 0 && size > 1 && C > 0, "vpho_align_heatmap_bwd_nhwc_f32: bad argument");
+    const size_t lds = (size_t)(size + size * size) * sizeof(float) + (size_t)(2 + 2 * size) * sizeof(int);
+    if (size <= 192 && lds <= 60 * 1024) {
+        hipLaunchKernelGGL(align_heatmap_bwd_gather_kernel, dim3(size, N), dim3(256), lds, (hipStream_t)stream, dout, size, C, bbox, bbox_rect, flip_w, dhm);
+        return vpho::check_launch("align_heatmap_bwd_gather_kernel");
+    }
     hipLaunchKernelGGL(align_heatmap_bwd_kernel, dim3(nblk((long long)N * size * size * C)), dim3(256), 0, (hipStream_t)stream, dout, N, size, C, bbox, bbox_rect, flip_w, dhm);
     return vpho::check_launch("align_heatmap_bwd_kernel");
 }
