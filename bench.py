@@ -2,7 +2,7 @@
 """Headline benchmark: eval images/s of ``vpho_net.forward(mode='predict')`` at the README config
 (bs=64 per GPU, sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.65) on synthetic 256x256 crops.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps 10 --warmup 2        # N > 1: starts its N rank processes itself (vpho_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one forward pass over one per-rank batch (inputs resident in HBM), incl. the CPU prior draw the reference
@@ -46,6 +46,8 @@ def parse():
 
 def main():
     args = parse()
+    from vpho_amd.launch import maybe_spawn, world_from_env
+    maybe_spawn(args.gpus)             # N > 1 from a bare shell: start the N rank processes (before any GPU call) and exit with their code
     sys.argv = sys.argv[:1]
     import torch
     import torch.distributed as dist
@@ -55,10 +57,7 @@ def main():
     from vpho_amd.assets import synthetic_assets, ANCHOR_SKELETON
     from vpho_amd import ops, evaluate as E
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1'
+    world, rank, local_rank = world_from_env(args.gpus)
     # rehearsal aid for a 1-GPU box: VPHO_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (timings meaningless)
     rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
     dev_index = 0 if rehearse else local_rank

@@ -10,6 +10,8 @@ import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 
 def main():
     p = argparse.ArgumentParser()
@@ -17,7 +19,10 @@ def main():
     p.add_argument('--batch_size', type=int, default=64)
     p.add_argument('--iters', type=int, default=3000)
     p.add_argument('--phase1', type=int, default=300)
+    p.add_argument('--gpus', type=int, default=int(os.environ.get('WORLD_SIZE', '1')))
     args = p.parse_args()
+    from vpho_amd.launch import maybe_spawn, world_from_env
+    maybe_spawn(args.gpus)             # N > 1 from a bare shell: start the N rank processes (before any GPU call)
     sys.argv = sys.argv[:1]
     import torch
     import torch.distributed as dist
@@ -25,12 +30,15 @@ def main():
     from vpho_amd.assets import load_assets, ANCHOR_SKELETON
     from vpho_amd.evaluate import shard_range
 
-    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    world, rank, local = world_from_env(args.gpus)
+    rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'    # every rank on cuda:0 over gloo (1-GPU box; timings meaningless)
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('gloo' if rehearse else 'nccl', **({} if rehearse else {'device_id': dev}))
     assets = load_assets('asset')
     n_batches = (args.pairs + args.batch_size - 1) // args.batch_size
     lo, hi = shard_range(n_batches, rank, world)
@@ -59,6 +67,8 @@ def main():
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     tot = torch.tensor([float(n)], device=dev, dtype=torch.float64)
     if world > 1:
+        if rehearse:
+            dt, tot = dt.cpu(), tot.cpu()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot)
     if rank == 0:

@@ -27,7 +27,10 @@ def main():
     ap.add_argument('--bs', type=int, default=64)
     ap.add_argument('--repeat_num', type=int, default=20)
     ap.add_argument('--breakdown', action='store_true', help='also time forward+backward and the optimiser separately')
+    ap.add_argument('--seed', type=int, default=206)
     args = ap.parse_args()
+    from vpho_amd.launch import maybe_spawn, world_from_env
+    maybe_spawn(args.gpus)             # N > 1 from a bare shell: start the N rank processes (before any GPU call)
     sys.argv = sys.argv[:1]
     import torch
     import torch.distributed as dist
@@ -35,8 +38,7 @@ def main():
     from vpho_amd.model.VPHO import vpho_net
     from vpho_amd.synth import synth_state_dict, synth_batch
     from vpho_amd.train_step import DiffusionTrainStep
-    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus
+    world, rank, local = world_from_env(args.gpus)
     # rehearsal aid for a 1-GPU box: VPHO_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (timings meaningless)
     rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
     if rehearse:
@@ -49,6 +51,9 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+    # base_trainer.py:39-50: seed + rank * 1e8 -- every rank draws its own DSM times / noise from the device generator
+    torch.manual_seed(args.seed + rank * 100000000)
+    torch.cuda.manual_seed(args.seed + rank * 100000000)
     assets = synthetic_assets(0)
     sd = synth_state_dict(vpho_net(assets), seed=1)
     step = DiffusionTrainStep(sd, dev, assets=assets)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--bs', type=int, default=64)
     ap.add_argument('--repeat_num', type=int, default=20)
     args = ap.parse_args()
+    from vpho_amd.launch import maybe_spawn, world_from_env
+    maybe_spawn(args.gpus)             # N > 1 from a bare shell: start the N rank processes (before any GPU call)
     sys.argv = sys.argv[:1]
     import torch
     import torch.distributed as dist
@@ -34,8 +36,9 @@ def main():
     from vpho_amd.model.VPHO import vpho_net
     from vpho_amd.synth import synth_state_dict
     from vpho_amd.train_score import ScoreTrainer
-    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus
+    world, rank, local = world_from_env(args.gpus)
+    torch.manual_seed(206 + rank * 100000000)             # base_trainer.py:39-50
+    torch.cuda.manual_seed(206 + rank * 100000000)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:

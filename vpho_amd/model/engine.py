@@ -5,7 +5,6 @@ replays the reference's data flow (VPHO.py:112-304, aggregation.py:1167-1353) as
 HIP stream.  Torch is used for allocation, views and dtype/flag conversion only.
 """
 import os
-import threading
 
 import torch
 
@@ -110,6 +109,10 @@ class Engine:
         self.last_info = {}
         self._obj_stream = None
         self._pin = {}
+        # ONE persistent host thread drives the object sampler of every predict() call: the C side keeps its pinned
+        # staging block and blocking event per thread (score_ode.hip), so a thread per call would leak both
+        from concurrent.futures import ThreadPoolExecutor
+        self._obj_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vpho-obj-sampler')
         # launch-bound, sync-free phases are replayed as HIP graphs (VPHO_GRAPHS=0: plain launches, same kernels)
         self.use_graphs = os.environ.get('VPHO_GRAPHS', '1') != '0'
         from .graphs import GraphedCall
@@ -339,19 +342,13 @@ class Engine:
                 self._obj_stream = torch.cuda.Stream(device=self.dev)
             obj_stream = self._obj_stream
             obj_stream.wait_stream(main)
-            box = {}
 
             def run_obj():
-                try:
-                    with torch.cuda.device(self.dev), torch.cuda.stream(obj_stream):
-                        box['res'] = self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
-                except BaseException as e:          # re-raised on the caller's thread
-                    box['err'] = e
+                with torch.cuda.device(self.dev), torch.cuda.stream(obj_stream):
+                    return self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
 
             concurrent = os.environ.get('VPHO_SERIAL_SAMPLERS', '0') != '1'
-            th = threading.Thread(target=run_obj, name='vpho-obj-sampler') if concurrent else None
-            if th is not None:
-                th.start()
+            fut = self._obj_worker.submit(run_obj) if concurrent else None
             # hand hypotheses
             xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h, S, T0, steps, xs_f64=False, x_f64=False)
             inproc = torch.empty((bs * S * steps, 58), device=self.dev)
@@ -370,13 +367,7 @@ class Engine:
             out['diff_final_hand_vert'] = fv.view(bs, S, 778, 3)
             out['diff_final_hand_joint'] = fj.view(bs, S, 21, 3)
             # object hypotheses (stay fp64, quirk Q5)
-            if th is not None:
-                th.join()
-            else:
-                run_obj()
-            if 'err' in box:
-                raise box['err']
-            xs_o, x_o, st_o = box['res']
+            xs_o, x_o, st_o = fut.result() if fut is not None else run_obj()      # a worker exception re-raises here
             main.wait_stream(obj_stream)
             for t in (xs_o, x_o):
                 t.record_stream(main)
