@@ -39,7 +39,8 @@ def parse():
     p.add_argument('--sample_T0', type=float, default=0.65)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
-    p.add_argument('--cpu_images', type=int, default=4)
+    p.add_argument('--cpu_images', type=int, default=64, help='images of the oracle / parity leg (one batch)')
+    p.add_argument('--weights', choices=('conditioned', 'random'), default='conditioned', help='synthetic weight set (vpho_amd.synth)')
     p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
     return p.parse_args()
 
@@ -74,7 +75,10 @@ def main():
         args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj, args.sample_T0
     assets = synthetic_assets(0)
     model = vpho_net(assets)
-    sd = synth_state_dict(model, seed=1)
+    from vpho_amd.synth import HM_GAIN_CONTRAST, HM_GAIN_FLAT, bench_state_dict
+    # default: heat-maps with contrast + conditioned score networks (vpho_amd.synth.bench_state_dict); `--weights random` is the
+    # round-1 set (flat heat-maps, unconditioned score networks: nfev 57/57 instead of 51/51)
+    sd = bench_state_dict(model, seed=1) if args.weights == 'conditioned' else synth_state_dict(model, seed=1, hm_gain=HM_GAIN_FLAT)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     torch.manual_seed(206 + rank * 100000000)            # base_trainer.py:39-50 (seed + rank*1e8)
@@ -201,7 +205,7 @@ def main():
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'pipeline_depth': args.pipeline,
-                       'weights': 'seeded random (vpho_amd.synth), synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
+                       'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS,
@@ -244,10 +248,13 @@ def pmc_traffic(kernel):
 
 
 def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload + MPJPE delta of the HIP path
-    against it on identical inputs and identical prior draws."""
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload -- ONE batch of `cpu_images` images
+    (default 64 = the per-GPU batch, so the batch-coupled quirks Q3/Q5 see the benchmark's own batch size) -- and the parity of
+    the HIP path against it on identical inputs and identical prior draws, reported selection by selection (oracle/compare.py)."""
     import torch
     from oracle import vpho as OV
+    from oracle.compare import parity_summary, TIE_REL, E2E_TIE_REL
+    from oracle.aggregation import hoi_aggregate
     from vpho_amd.synth import synth_batch
     n = args.cpu_images
     data = synth_batch(n, assets, seed=777)
@@ -262,14 +269,14 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     gdata = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
     out = model._engine.predict(gdata, noise_hand=nh, noise_obj=no)
     torch.cuda.synchronize()
-    d = (out['agg_hand_joint'].double().cpu() - ref['agg_hand_joint'].double())
-    mpjpe_delta_mm = float(d.norm(dim=-1).mean() * 1000)
+    eng_info = model._engine.last_info
     mx = lambda a, b: float((a.double().cpu() - b.double()).abs().max())
-    # The aggregation is a chain of top-k selections: with random weights many hypotheses score within float rounding of
-    # each other, so a 1e-6 difference upstream can swap a selected index and move the fused pose by millimetres.  The
-    # second comparison removes that conditioning: the oracle's aggregation is fed the HIP path's own candidates.
-    from oracle.aggregation import hoi_aggregate
-    gf = model._engine.last_info['features']
+    upstream = {k: mx(out[k], ref[k]) for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint',
+                                                'diff_final_hand_mano', 'diff_final_obj_6d')}
+    end_to_end, _ = parity_summary(out, ref, eng_info['agg'], info['agg'], args.sample_num, bound=E2E_TIE_REL)
+    # second comparison: the oracle's aggregation fed the HIP path's OWN candidates, heat-maps and forces -- isolates the
+    # aggregation kernels (identical inputs on both sides; what remains is the fp32 rounding of FK / projection / bicubic sums)
+    gf = eng_info['features']
     c = lambda t: t.detach().cpu()
     fl = c(out['diff_final_hand_mano']).reshape(-1, 58)
     same = hoi_aggregate(assets, skeleton, cam_intrinsic=data['cam_intr_crop_flip'], root_joint_flip=data['root_joint_flip'],
@@ -278,43 +285,22 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                          hand_shape=fl[:, 48:], hand_heatmap=c(gf['hand_heatmap']), hand_bbox=data['bbox_hand'],
                          hand_topk=args.topk_hand, obj_pose6d=c(out['diff_final_obj_6d']), obj_heatmap=c(gf['obj_heatmap']),
                          obj_bbox=data['bbox_obj_rect'], obj_topk=args.topk_obj, obj_name=data['obj_name'])
-    given_same = {'max_abs_agg_hand_joint': mx(out['agg_hand_joint'], same['hand_agg_joint']),
-                  'max_abs_agg_hand_vert': mx(out['agg_hand_vert'], same['hand_agg_vert']),
-                  'max_abs_agg_obj_6d': mx(out['agg_obj_6d'], same['obj_agg_6d'])}
-    upstream = {k: mx(out[k], ref[k]) for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint',
-                                                'diff_final_hand_mano', 'diff_final_obj_6d')}
-    # where do selected indices differ, and how close were the competing scores?  (oracle values, sorted descending:
-    # a swap between ranks k and k+1 whose scores agree to ~1e-7 relative is a tie below fp32 resolution)
-    gd, od = model._engine.last_info['agg'], same['dbg']
-    mism, gap, per_image = 0, 0.0, torch.zeros(n, dtype=torch.long)
-    for lvl in range(4):
-        gi, oi, ov = c(gd['hand_topk'][lvl]).long(), od['hand']['topk'][lvl].long(), od['hand']['val'][lvl]
-        # per-finger levels are (bs,5,k) here and (bs,k,5) in the oracle
-        gi = gi.reshape(n, 5, -1).transpose(1, 2) if oi.dim() == 3 else gi.reshape(oi.shape)
-        ne = gi != oi
-        mism += int(ne.sum())
-        per_image += ne.reshape(n, -1).sum(1)
-        if ne.any():
-            nxt = torch.minimum((ov - ov.roll(-1, 1)).abs(), (ov - ov.roll(1, 1)).abs()) / ov.abs().clamp_min(1e-30)
-            gap = max(gap, float(nxt[ne].max()))
-    dj = (c(out['agg_hand_joint']).double() - same['hand_agg_joint'].double()).abs().amax(dim=(1, 2))
-    obj_eq = all(bool((c(gd[k]).long().reshape(od[k].shape) == od[k].long()).all()) for k in ('transl_topk', 'rot_topk', 'phys_topk', 'heat_topk'))
-    ties = {'object_topk_indices_equal': obj_eq, 'hand_cascade_index_mismatches': mism, 'max_rel_score_gap_at_mismatch': gap,
-            'images_without_mismatch': int((per_image == 0).sum()),
-            'max_abs_agg_hand_joint_on_those': float(dj[per_image == 0].max()) if (per_image == 0).any() else None}
+    same_out = dict(agg_hand_joint=same['hand_agg_joint'], agg_hand_vert=same['hand_agg_vert'], agg_hand_mano=same['hand_agg_mano'],
+                    agg_obj_6d=same['obj_agg_6d'])
+    given_same, _ = parity_summary(out, same_out, eng_info['agg'], same['dbg'], args.sample_num, bound=TIE_REL)
     return {'cpu_baseline': {'value': n / t_cpu, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-                             'sample': f'{n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
+                             'sample': f'one batch of {n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
                                        f'(torch-CPU + host RK45), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
-            'parity': {'mpjpe_delta_mm': mpjpe_delta_mm,
-                       'max_abs_agg_hand_joint': float(d.abs().max()),
-                       'max_abs_agg_hand_vert': float((out['agg_hand_vert'].double().cpu() - ref['agg_hand_vert'].double()).abs().max()),
-                       'max_abs_agg_obj_6d': float((out['agg_obj_6d'].double().cpu() - ref['agg_obj_6d'].double()).abs().max()),
-                       'nfev_equal': [model._engine.last_info['hand_ode']['nfev'] == info['hand_ode']['nfev'],
-                                      model._engine.last_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
+            'parity': {'sample': f'{n} images in one batch, identical inputs and prior draws; bar: 1e-3 on joints / vertices / 6-DoF, selected '
+                                 'indices equal.  A top-k chain is discontinuous, so parity = (everything upstream of the aggregation agrees: '
+                                 'upstream_max_abs) x (the aggregation kernels select the same indices as the oracle on IDENTICAL candidates, '
+                                 'ties below 1e-6 relative excepted: aggregation_given_identical_candidates); end_to_end_vs_oracle reports what '
+                                 'the composition gives (each side ranks its own hypotheses, reproduced to ~1e-5)',
+                       'nfev_equal': [eng_info['hand_ode']['nfev'] == info['hand_ode']['nfev'],
+                                      eng_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
                        'upstream_max_abs': upstream,
-                       'aggregation_given_identical_candidates': given_same,
-                       'near_tie_report': ties,
-                       'sample': f'{n} images, identical inputs and prior draws'}}
+                       'end_to_end_vs_oracle': end_to_end,
+                       'aggregation_given_identical_candidates': given_same}}
 
 
 if __name__ == '__main__':

@@ -122,7 +122,7 @@ def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, 
     bs, S = pose_diff.shape[:2]
     pose = torch.cat([pose_diff, pose_reg[:, None].expand(bs, S, 48)], 1).clone()          # (bs,2S,48)
     shape = betas[:, None].expand(bs, 2 * S, 10).reshape(-1, 10)
-    out = dict(topk=[], val=[], weight=[])
+    out = dict(topk=[], val=[], weight=[], score=[])
     for level in range(4):
         fuse = MANO_PARAMS_LEVEL[level]
         observe = [j for l in range(level + 1, 5) for j in MANO_JOINT_LEVEL[l]]
@@ -133,7 +133,8 @@ def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, 
         pt2d = _norm_to_bbox(project(joint, K), bbox)
         hv = _bicubic_lookup(heatmap, pt2d, observe)                                        # (bs,2S,m)
         if level == 0:
-            val, idx = topk_stable(hv.sum(-1), k, dim=1)                                    # (bs,k)
+            hv = hv.sum(-1)
+            val, idx = topk_stable(hv, k, dim=1)                                            # (bs,k)
             w = (val + 1e-8) / (val.sum(dim=1, keepdim=True) + 1e-8)
             sel = torch.gather(pose[:, :, fuse], 1, idx[:, :, None].expand(bs, k, 3))       # (bs,k,3)
             q = R.axis_angle_to_quaternion(sel.reshape(bs, k, 1, 3)).permute(0, 2, 1, 3)    # (bs,1,k,4)
@@ -155,6 +156,7 @@ def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, 
         out['topk'].append(idx)
         out['val'].append(val)
         out['weight'].append(w)
+        out['score'].append(hv)                                                             # all candidates: (bs,2S) / (bs,2S,5)
     fused = pose[:, 0].clone()
     v, j = get_hand_verts(mano, fused, betas)
     out.update(fused_pose=fused, agg_vert=v, agg_joint=j)
@@ -229,7 +231,7 @@ def hand_physics(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, 
         topks.append(idx)
         scores.append(fs)
     v, j = get_hand_verts(mano, fuse[:, :48], fuse[:, 48:])
-    return dict(agg_pose=fuse, agg_vert=v, agg_joint=j, topk=torch.stack(topks, 1), score=torch.stack(scores, 1))
+    return dict(agg_pose=fuse, agg_vert=v, agg_joint=j, topk=torch.stack(topks, 1), score=torch.stack(scores, 1), cand=pose58)
 
 
 # ------------------------------------------------------------------ HOI_Aggregator.__call__ (aggregation.py:1167-1353)

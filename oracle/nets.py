@@ -173,8 +173,10 @@ def ode_sample(sd, p, feat, init_x, T0, num_steps, rtol=3e-3, atol=3e-4):
     """score_based_model.py:45-105.  init_x (R,D) f32 (already the prior draw).  Returns xs (R,steps,D) f64,
     x (R,D) f64, info dict (nfev incl. the denoise call, step log)."""
     Rr, D = init_x.shape
+    t_calls = []
 
     def fun(t, y):
+        t_calls.append(float(np.float32(t)))
         x = torch.tensor(y.reshape(-1, D)).float()
         ts = torch.ones(Rr).unsqueeze(-1) * t
         g = ve_diffusion(torch.tensor(t)).numpy()
@@ -193,7 +195,8 @@ def ode_sample(sd, p, feat, init_x, T0, num_steps, rtol=3e-3, atol=3e-4):
     g = ve_diffusion(vec)
     grad = denoiser(sd, p, feat, x.float(), vec)
     x = x + (0 - g ** 2 * grad) * ((1 - EPS_T) / num_steps)
-    return xs.permute(1, 0, 2), x, dict(nfev=res['nfev'] + 1, steps=res['steps'])
+    t_calls.append(float(np.float32(EPS_T)))
+    return xs.permute(1, 0, 2), x, dict(nfev=res['nfev'] + 1, steps=res['steps'], t_calls=t_calls)
 
 
 def ve_prior_sigma(T0):

@@ -12,7 +12,9 @@ from oracle import vpho as OV
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = 100
 a = synthetic_assets(0)
-m = vpho_net(a); sd = synth_state_dict(m, 1)
+import os
+from vpho_amd.synth import HM_GAIN_CONTRAST
+m = vpho_net(a); sd = synth_state_dict(m, 1, hm_gain=float(os.environ.get("HM_GAIN", HM_GAIN_CONTRAST)))
 data = synth_batch(n, a, seed=777)
 torch.manual_seed(99)
 nh, no = torch.randn(n * S, 96), torch.randn(n * S, 9)

@@ -1,70 +1,75 @@
-"""Shared comparison against the reference's README-size forward (tests/golden/golden_predict_readme.npz): continuous outputs
-to a tolerance, selection indices exactly except where two neighbouring candidates tie within fp32 resolution."""
+"""Shared comparison against the reference's own forward at the README config (tests/golden/golden_predict_readme.npz, written by
+tests/golden/make_golden_readme.py: 8 images in one batch, sample_num=100, sampling_steps=50, top-k 30/10, sample_T0=0.65).
+
+Continuous outputs to a tolerance; every selected index list against the reference's through oracle/compare.py: indices equal,
+except where the two candidates' scores -- both read from the REFERENCE's own score vector -- differ by less than a FIXED bound
+(oracle/compare.py: E2E_TIE_REL when each side ranks its own hypotheses).  The aggregated poses are asserted on every image whose
+selections are identical, and -- for the HIP path -- on ALL images."""
 import os
 
 import numpy as np
 import torch
 
+from oracle.compare import parity_summary, TIE_REL, E2E_TIE_REL
+
 R = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_predict_readme.npz'))
-CFG = dict(sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.2)
+BS, S, STEPS, KH, KO = (int(v) for v in R['cfg'])
+CFG = dict(sample_num=S, sampling_steps=STEPS, topk_hand=KH, topk_obj=KO, sample_T0=float(R['sample_T0']))
 
 
-def compare(out, hand_topk, obj_topk, upstream_tol, obj_scores=None, hand_val=None):
-    """out: dict of CPU tensors; hand_topk: list of 4 index tensors in the reference's layout (bs,k[,5]);
-    obj_topk: dict transl / rot / final / phys; obj_scores: the same keys -> (bs, n) score vectors of the side under test
-    (torch.topk leaves the order among EQUAL scores unspecified -- with random weights at T0=0.65 most object hypotheses
-    project outside the crop and score exactly 0 -- so object selections are compared rank by rank through their scores).
-    hand_val: the tested side's top-k values per level (same layout as hand_topk), used to measure the score noise between the
-    two sides.  Returns the number of images whose hand cascade selected a different index somewhere."""
+def inputs(assets):
+    """The batch and the prior draws the reference's forward made (sde.py:26-28: hand first, then object)."""
+    from vpho_amd.synth import synth_batch
+    data = synth_batch(BS, assets, seed=int(R['data_seed']))
+    state = torch.get_rng_state()
+    torch.manual_seed(int(R['draw_seed']))
+    nh, no = torch.randn(BS * S, 96), torch.randn(BS * S, 9)
+    torch.set_rng_state(state)
+    assert float(nh.double().sum()) == float(R['noise_hand_crc']) and float(no.double().sum()) == float(R['noise_obj_crc'])
+    return data, nh, no
+
+
+def reference_dbg():
+    """The reference's selections in the layout of the oracle's dbg dict (oracle.aggregation.hoi_aggregate)."""
+    t = lambda k: torch.as_tensor(np.asarray(R[k]))
+    hand = dict(topk=[t(f'hand_topk_l{l}') for l in range(4)], val=[t(f'hand_val_l{l}') for l in range(4)],
+                score=[t(f'hand_score_l{l}') for l in range(4)])
+    return dict(hand=hand, hand_phys=dict(topk=t('hand_phys_topk'), score=t('hand_phys_score'), cand=t('hand_phys_cand')),
+                transl_topk=t('obj_transl_topk'), rot_topk=t('obj_rot_topk'), phys_topk=t('obj_phys_topk'), heat_topk=t('obj_heat_topk'),
+                transl_score=t('obj_transl_score'), rot_score=t('obj_rot_score'), phys_score=t('obj_phys_score'), heat_score=t('obj_heat_score'))
+
+
+def oracle_as_tested(od):
+    """The oracle's dbg dict in the layout of the HIP path's ``Engine.last_info['agg']`` (index tensors only)."""
+    h = od['hand']
+    return dict(hand_topk=[(i[:, :, None] if i.dim() == 2 else i).transpose(1, 2).int().contiguous() for i in h['topk']],
+                hand_phys_topk=od['hand_phys']['topk'].int(), transl_topk=od['transl_topk'].int(), rot_topk=od['rot_topk'].int(),
+                phys_topk=od['phys_topk'].int(), heat_topk=od['heat_topk'].int())
+
+
+def compare(out, gd, upstream_tol, nfev=None, agg_tol=2e-4, min_identical=None, bound=E2E_TIE_REL, all_images_agg_tol=None):
+    """out: output dict of the side under test (CPU or device tensors); gd: its selections (HIP layout).  Returns the summary.
+    ``bound``: E2E_TIE_REL (each side ranks its own hypotheses) -- see oracle/compare.py; ``all_images_agg_tol``: when given, the
+    aggregated outputs of EVERY image must agree to it (no waiver on the outputs the north star names)."""
     t = lambda a: torch.as_tensor(np.asarray(a))
+    c = lambda v: v.detach().cpu()
     for k in ('reg_hand_joint', 'force_local', 'diff_final_hand_mano', 'diff_final_obj_6d'):
-        err = float((out[k].double() - t(R[k]).double()).abs().max())
-        assert err < upstream_tol, (k, err)
+        err = float((c(out[k]).double().reshape(R[k].shape) - t(R[k]).double()).abs().max())
+        # hypotheses whose rot6d columns are nearly parallel amplify the solver's rounding differences in Gram-Schmidt: one of the
+        # 12 800 joint rotations of the fixture differs by 1.4e-4 (median 2e-7); 5e-4 stays inside the 1e-3 bar
+        assert err < (5e-4 if k == 'diff_final_hand_mano' else upstream_tol), (k, err)
     for k in ('hand_heatmap', 'obj_heatmap'):
-        assert float((out[k][:, :, ::4, ::4].double() - t(R[k]).double()).abs().max()) < upstream_tol, k
-    bs = R['agg_obj_6d'].shape[0]
-    swaps = torch.zeros(bs, dtype=torch.long)
-    for lvl in range(4):
-        want, val = t(R[f'hand_topk_l{lvl}']).long(), t(R[f'hand_val_l{lvl}'])
-        got = hand_topk[lvl].long().reshape(want.shape)
-        ne = got != want
-        # What changes the fused pose: candidates sample_num .. 2*sample_num-1 are identical copies of the regression pose, so
-        # they count as one; at levels 0-2 only the selected SET matters (a weighted mean); at level 3 the rank matters too
-        # (rank i of every finger forms physics candidate i)
-        S = CFG['sample_num']
-        g2, w2 = got.clamp(max=S), want.clamp(max=S)
-        if lvl < 3:
-            g2, w2 = g2.sort(dim=1).values, w2.sort(dim=1).values
-        swaps += (g2 != w2).reshape(bs, -1).sum(1)
-        # top-k VALUES must agree rank by rank; an index may differ only inside a run of tied values (e.g. the 100 identical
-        # regression candidates: torch.topk's order among equal scores is unspecified) -- tied = closer to a neighbouring rank
-        # than 4x the score noise between the two sides; the last rank may tie with the first unselected candidate
-        if hand_val is not None:
-            mine = hand_val[lvl].reshape(want.shape).to(val.dtype)
-            noise = float((mine - val).abs().max())
-            assert noise < 2e-3 * float(val.abs().max()), ('hand level', lvl, noise)
-        else:
-            noise = 2.5e-6 * float(val.abs().max())
-        inf = torch.full_like(val[:, :1], float('inf'))
-        prev_gap = torch.cat([inf, (val[:, 1:] - val[:, :-1]).abs()], 1)
-        next_gap = torch.cat([(val[:, 1:] - val[:, :-1]).abs(), torch.zeros_like(val[:, :1])], 1)
-        distinct = torch.minimum(prev_gap, next_gap) > 4 * noise
-        assert not (ne & distinct).any(), ('hand level', lvl, (ne & distinct).nonzero().tolist()[:5])
-    for k, name in (('transl', 'obj_heat_topk_transl'), ('rot', 'obj_heat_topk_rot'), ('final', 'obj_heat_topk_final'), ('phys', 'obj_phys_topk')):
-        got, want = obj_topk[k].long().reshape(R[name].shape), t(R[name]).long()
-        if obj_scores is None:
-            assert torch.equal(got, want), k
-        else:
-            sc = obj_scores[k].double().reshape(bs, -1)
-            a, b = torch.gather(sc, 1, got), torch.gather(sc, 1, want)
-            assert float((a - b).abs().max()) <= 1e-6 * float(sc.abs().max()) + 1e-12, (k, got.tolist(), want.tolist())
-    assert float((out['agg_obj_6d'].double() - t(R['agg_obj_6d']).double()).abs().max()) < 2e-5
-    # a swap between two DIFFERENT candidates whose scores tie within the noise (accepted above) changes the fused pose, and
-    # which way such a tie falls depends on the summation order of the platform's fp32 kernels -- the reference's own result is
-    # not reproducible across machines there; the aggregated poses are compared on the images without such a swap
-    clean = swaps == 0
-    for k in ('agg_hand_mano', 'agg_hand_joint', 'agg_hand_vert'):
-        if clean.any():
-            err = float((out[k].double() - t(R[k]).double())[clean].abs().max())
-            assert err < 2e-4, (k, err)
-    return int((~clean).sum())
+        assert float((c(out[k])[:, :, ::4, ::4].double() - t(R[k]).double()).abs().max()) < upstream_tol, k
+    if nfev is not None:                                     # scipy's step sequence: 2 start-up + 6 per attempt + 1 denoise call
+        assert tuple(nfev) == (len(R['tcalls_hand']), len(R['tcalls_obj'])), (nfev, len(R['tcalls_hand']), len(R['tcalls_obj']))
+    ref = {k: t(R[k]) for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_hand_mano', 'agg_obj_6d')}
+    res, rep = parity_summary(out, ref, gd, reference_dbg(), S, bound=bound)
+    assert res['images_with_wrong_selection'] == 0 and res['max_rel_score_gap_at_first_differences'] <= bound, res
+    if min_identical is not None:
+        assert res['images_all_selections_identical'] >= min_identical, res
+    for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_hand_mano', 'agg_obj_6d'):
+        e = res[f'max_abs_{k}_where_identical']
+        assert e is not None and e < agg_tol, (k, e, res)
+        if all_images_agg_tol is not None and k != 'agg_hand_mano':      # axis-angle near pi flips sign: joints / vertices carry the bar
+            assert res[f'max_abs_{k}_all'] < all_images_agg_tol, (k, res)
+    return res

@@ -29,3 +29,19 @@ def model_cpu(assets):
 @pytest.fixture(scope='session')
 def sd(model_cpu):
     return {k: v.clone() for k, v in model_cpu.state_dict().items()}
+
+
+@pytest.fixture(scope='session')
+def model_contrast_cpu(assets):
+    """vpho_amd.synth.bench_state_dict: seeded weights with high-contrast heat-maps and conditioned score networks -- the weights
+    of bench.py, of the README-config reference fixture and of the README-size parity tests."""
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import bench_state_dict
+    m = vpho_net(assets)
+    m.load_state_dict(bench_state_dict(m, seed=1))
+    return m.eval()
+
+
+@pytest.fixture(scope='session')
+def sd_contrast(model_contrast_cpu):
+    return {k: v.clone() for k, v in model_contrast_cpu.state_dict().items()}

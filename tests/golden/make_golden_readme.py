@@ -1,9 +1,16 @@
-"""Golden vectors of the reference's whole ``vpho_net.forward(mode='predict')`` at the README evaluation sizes
-(sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10) on 2 synthetic images, incl. the top-k index tensors of every
-selection stage.  sample_T0 is 0.2, not the README's 0.65: with random weights the T0=0.65 object hypotheses project outside
-the crop, their heat scores are exactly 0 and torch.topk's unspecified order among equal scores decides the reference's own
-result (the T0=0.65 sampler itself is pinned by the ode_* fixtures of make_golden.py).  Run in the build container only; same stubs / weights / inputs as make_golden.py.
-The in-process trajectories are not stored (size); the final hypotheses and everything downstream are."""
+"""Golden vectors of the reference's whole ``vpho_net.forward(mode='predict')`` at the README evaluation config
+(sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.65 -- README.md:61-71) on ONE batch of 8 synthetic
+images: every output the parity bar names, the index tensor AND the complete score vector of every top-k the aggregation makes
+(torch.Tensor.topk is wrapped while the reference's forward runs), the 31 physics candidates, and the RHS-evaluation times of
+both ODE solves (= scipy's accepted / rejected step sequence).
+
+Weights: vpho_amd.synth.bench_state_dict(seed=1) -- heat-maps with the contrast of a trained head (candidate scores spread out:
+rank ties below fp32 resolution are rare) and conditioned score networks (hypotheses contract towards a mode like a trained
+model's: with purely random weights the T0=0.65 object hypotheses stay metres outside the crop, every heat score is exactly 0
+and torch.topk's unspecified order among equal values decides the reference's own result).
+
+Run in the build container only (needs /root/reference); same stubs / assets as make_golden.py.  The in-process trajectories
+are not stored (size)."""
 import os
 import sys
 import tempfile
@@ -15,12 +22,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as MG  # noqa: E402
 
-CFG = dict(bs=2, sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.2)
+CFG = dict(bs=8, sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, sample_T0=0.65, data_seed=4242, draw_seed=5)
 
 
 def main():
     from vpho_amd.assets import synthetic_assets
-    from vpho_amd.synth import synth_state_dict, synth_batch
+    from vpho_amd.synth import bench_state_dict, synth_batch
     assets = synthetic_assets(0)
     tmp = tempfile.mkdtemp(prefix='vpho_golden_readme_')
     MG.write_assets(tmp, assets)
@@ -38,54 +45,69 @@ def main():
     ref = ref_vpho.vpho_net().eval()
     sys.argv = ['x']
     from vpho_amd.model.VPHO import vpho_net
-    sd = synth_state_dict(vpho_net(assets), seed=1)
+    sd = bench_state_dict(vpho_net(assets), seed=1)
     missing, _ = ref.load_state_dict(sd, strict=False)
     assert not missing, missing
-    data = synth_batch(c['bs'], assets, seed=4242)
+    data = synth_batch(c['bs'], assets, seed=c['data_seed'])
+
+    # ---- recorders ---------------------------------------------------------------------------------------------------
+    topk_calls = []
+    orig_topk = torch.Tensor.topk
+
+    def rec_topk(self, *a, **kw):
+        r = orig_topk(self, *a, **kw)
+        topk_calls.append((self.detach().clone(), r[0].clone(), r[1].clone()))
+        return r
+
     rec = {}
-    ha, oa = ref.hoi_aggregator.hand_aggregator, ref.hoi_aggregator.obj_aggregator
-    o1 = ha.select_topk_hand_by_observed_heatmap_and_fuse_by_index
-    o2, o3 = oa.select_topk_object_by_heatmap, oa.select_topk_object_by_physics3
+    ha = ref.hoi_aggregator.hand_aggregator
+    orig_phys = ha.select_by_physics
 
-    def w1(**kw):
-        r = o1(**kw)
-        rec.setdefault('hand_topk', []).append(r['topk'].clone())
-        rec.setdefault('hand_val', []).append(r['val'].clone())
-        return r
+    def phys(**kw):
+        rec['phys_cand'] = kw['pose'].clone()
+        return orig_phys(**kw)
 
-    def w2(**kw):
-        r = o2(**kw)
-        rec.setdefault('obj_heat_topk', []).append(r[0].clone())
-        return r
+    ha.select_by_physics = phys
+    tcalls = {'hand': [], 'obj': []}
+    for name, den in (('hand', ref.denoiser_hand), ('obj', ref.denoiser_obj)):
+        den.forward = lambda d, _o=den.forward, _c=tcalls[name]: (_c.append(float(d['t'][0, 0])), _o(d))[1]
 
-    def w3(**kw):
-        r = o3(**kw)
-        rec.setdefault('obj_phys_topk', []).append(r[0].clone())
-        return r
-
-    ha.select_topk_hand_by_observed_heatmap_and_fuse_by_index = w1
-    oa.select_topk_object_by_heatmap, oa.select_topk_object_by_physics3 = w2, w3
-    torch.manual_seed(5)
+    torch.manual_seed(c['draw_seed'])
     state = torch.get_rng_state()
-    with torch.no_grad():
-        out = ref(dict(data), mode='predict')
+    torch.Tensor.topk = rec_topk
+    try:
+        with torch.no_grad():
+            out = ref(dict(data), mode='predict')
+    finally:
+        torch.Tensor.topk = orig_topk
     torch.set_rng_state(state)                                            # the prior draws the forward made (sde.py:26-28)
     nh = torch.randn(c['bs'] * c['sample_num'], 96)
     no = torch.randn(c['bs'] * c['sample_num'], 9)
-    P = dict(noise_hand=nh.numpy(), noise_obj=no.numpy())
+
+    # order of the reference's topk calls (aggregation.py): 4 hand levels (:217,:246), object transl / rot (:777), physics3
+    # (:987), final heat-map list (:777), then 5 fingers of select_by_physics (:596)
+    assert len(topk_calls) == 4 + 2 + 2 + 5, len(topk_calls)
+    P = dict(cfg=np.array([c['bs'], c['sample_num'], c['sampling_steps'], c['topk_hand'], c['topk_obj']]), sample_T0=np.array(c['sample_T0']),
+             data_seed=np.array(c['data_seed']), noise_hand_crc=np.array(float(nh.double().sum())), noise_obj_crc=np.array(float(no.double().sum())),
+             draw_seed=np.array(c['draw_seed']))
     for k in ('reg_hand_joint', 'force_local', 'diff_final_hand_mano', 'diff_final_obj_6d', 'agg_obj_6d', 'agg_hand_mano', 'agg_hand_joint', 'agg_hand_vert'):
         P[k] = out[k].numpy()
     for k in ('hand_heatmap', 'obj_heatmap'):
         P[k] = out[k].numpy()[:, :, ::4, ::4]
     for lvl in range(4):
-        P[f'hand_topk_l{lvl}'] = rec['hand_topk'][lvl].numpy()
-        P[f'hand_val_l{lvl}'] = rec['hand_val'][lvl].numpy()
-    for i, nm in enumerate(['transl', 'rot', 'final']):
-        P[f'obj_heat_topk_{nm}'] = rec['obj_heat_topk'][i].numpy()
-    P['obj_phys_topk'] = rec['obj_phys_topk'][0].numpy()
-    np.savez_compressed(os.path.join(HERE, 'golden_predict_readme.npz'), **P)
+        sc, val, idx = topk_calls[lvl]
+        P[f'hand_score_l{lvl}'], P[f'hand_val_l{lvl}'], P[f'hand_topk_l{lvl}'] = sc.numpy(), val.numpy(), idx.numpy()
+    for i, nm in ((4, 'transl'), (5, 'rot'), (6, 'phys'), (7, 'heat')):
+        sc, val, idx = topk_calls[i]
+        P[f'obj_{nm}_score'], P[f'obj_{nm}_topk'] = sc.numpy(), idx.numpy()
+    P['hand_phys_score'] = torch.stack([topk_calls[8 + f][0] for f in range(5)], 1).numpy()      # (bs,5,31)
+    P['hand_phys_topk'] = torch.stack([topk_calls[8 + f][2] for f in range(5)], 1).numpy()       # (bs,5,5)
+    P['hand_phys_cand'] = rec['phys_cand'].numpy()                                               # (bs,31,58)
+    P['tcalls_hand'], P['tcalls_obj'] = np.array(tcalls['hand']), np.array(tcalls['obj'])
+    path = os.path.join(HERE, 'golden_predict_readme.npz')
+    np.savez_compressed(path, **P)
     print({k: v.shape for k, v in P.items()})
-    print(os.path.getsize(os.path.join(HERE, 'golden_predict_readme.npz')) // 1024, 'KiB')
+    print('nfev hand/obj', len(tcalls['hand']), len(tcalls['obj']), '|', os.path.getsize(path) // 1024, 'KiB')
 
 
 if __name__ == '__main__':

@@ -20,12 +20,14 @@ CASES = {
 
 
 @pytest.mark.parametrize('name', list(CASES))
-def test_predict_edge_case_matches_oracle(model_cpu, sd, assets, name):
+def test_predict_edge_case_matches_oracle(model_cpu, sd, model_contrast_cpu, sd_contrast, assets, name):
     from oracle import vpho as OV
     from vpho_amd.assets import ANCHOR_SKELETON
     from vpho_amd.configs.args import cfg
     from vpho_amd.synth import synth_batch
     bs, S, steps, kh, ko, T0, over = CASES[name]
+    if T0 > 0.2:                                  # the README's T0 needs score networks that pull hypotheses into the crop
+        model_cpu, sd = model_contrast_cpu, sd_contrast
     data = synth_batch(bs, assets, seed=300 + bs)
     for k, v in over.items():
         data[k] = torch.tensor(v if isinstance(v, list) else [v] * bs)
@@ -75,6 +77,10 @@ def test_predict_edge_case_matches_oracle(model_cpu, sd, assets, name):
         for k in ('agg_obj_6d', 'agg_hand_mano', 'agg_hand_vert', 'agg_hand_joint'):
             err = float((out[k].double().cpu() - ref[k].double()).abs().max())
             assert err < 1e-4, (name, k, err)
-    else:
-        for k in ('agg_obj_6d', 'agg_hand_mano', 'agg_hand_vert', 'agg_hand_joint'):
-            assert torch.isfinite(out[k]).all(), (name, k)
+    else:                                         # T0 = 0.65: selections against the oracle's with the fixed tie bound
+        from oracle.compare import parity_summary, E2E_TIE_REL
+        res, _ = parity_summary(out, ref, ga, ra, S, bound=E2E_TIE_REL)
+        assert res['images_with_wrong_selection'] == 0 and res['max_rel_score_gap_at_first_differences'] <= E2E_TIE_REL, res
+        assert res['images_all_selections_identical'] >= bs - 1, res
+        for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d'):
+            assert res[f'max_abs_{k}_where_identical'] < 1e-4, (name, k, res)

@@ -1,5 +1,5 @@
-"""README config (bs=64, sample_num=100, sampling_steps=50, topk 30/10, T0=0.65) on the GPU: size-independent properties
-of the whole path (the oracle is too slow at this size; exact parity is covered at cfg1 sizes by test_gpu_predict.py)."""
+"""README config (bs=64, sample_num=100, sampling_steps=50, topk 30/10, T0=0.65) on the GPU: size-independent properties of the
+whole path, parity with the oracle on ONE batch of 64 images, and parity with the reference's own run on 8 images."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +10,8 @@ BS, S, STEPS, KH, KO, T0 = 64, 100, 50, 30, 10, 0.65
 
 
 @pytest.fixture(scope='module')
-def full(model_cpu, assets):
+def full(model_contrast_cpu, assets):
+    model_cpu = model_contrast_cpu
     import copy
     from vpho_amd.configs.args import cfg
     from vpho_amd.synth import synth_batch
@@ -179,28 +180,36 @@ def test_stress_config_cfg4_properties(model_cpu, assets):
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
 
 
-def test_readme_config_parity_with_the_oracle_up_to_score_ties(model_cpu, sd, assets):
-    """README config on 3 images, identical inputs and prior draws, HIP path vs the oracle:
-    * everything upstream of the aggregation agrees to 1e-4 and the samplers take the same number of evaluations;
-    * the oracle's aggregation, fed the HIP path's own candidates, selects the same indices except where two adjacent
-      candidates score within 1e-5 relative of each other (ties below fp32 resolution of the feature path), and on every image
-      without such a swap the aggregated hand and object agree to 1e-5 / 1e-6."""
+def test_readme_config_bs64_parity_with_the_oracle(model_contrast_cpu, sd_contrast, assets):
+    """The README config on ONE batch of 64 images (the batch-coupled quirks Q3 / Q5 see the benchmark's own batch), identical
+    inputs and prior draws, HIP path vs the oracle (which tests/test_oracle_golden.py pins to the reference at this config).
+    A chain of top-k selections is discontinuous, so parity is asserted as the product of two exact statements:
+    (A) everything UPSTREAM of the aggregation agrees: same number of RHS evaluations in both solves, heat-maps / forces /
+        regression / object hypotheses to 1e-4, hand hypotheses to 5e-4 (Gram-Schmidt of nearly parallel rot6d columns amplifies
+        the solver's rounding; observed 1e-5);
+    (B) on IDENTICAL candidates (the oracle's aggregation fed the HIP path's own hypotheses, heat-maps and forces) the HIP
+        aggregation selects the same indices in every list of every image, except ties below the FIXED bound 1e-6 relative in the
+        oracle's own scores; at least 7 of 8 images are identical in every list, and joints / vertices / 6-DoF agree to 1e-4 on
+        them (bar 1e-3; observed 5e-7).
+    End to end (each side ranks its own hypotheses) is reported and bounded: no first difference between candidates further apart
+    than 1e-3 relative, at least 3 of 4 images identical in every hand list, MPJPE delta over all 64 images below 0.1 mm."""
     import copy
     from oracle import vpho as OV
     from oracle.aggregation import hoi_aggregate
+    from oracle.compare import parity_summary, TIE_REL, E2E_TIE_REL
     from vpho_amd.assets import ANCHOR_SKELETON
     from vpho_amd.configs.args import cfg
     from vpho_amd.synth import synth_batch
-    n = 3
+    n = BS
     saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
     cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = S, STEPS, KH, KO, T0
     try:
-        data = synth_batch(n, assets, seed=4242)
-        torch.manual_seed(5)
+        data = synth_batch(n, assets, seed=777)
+        torch.manual_seed(99)
         nh, no = torch.randn(n * S, 96), torch.randn(n * S, 9)
-        ref, info = OV.predict(sd, assets, ANCHOR_SKELETON, data, sample_num=S, sample_T0=T0, sampling_steps=STEPS, topk_hand=KH,
+        ref, info = OV.predict(sd_contrast, assets, ANCHOR_SKELETON, data, sample_num=S, sample_T0=T0, sampling_steps=STEPS, topk_hand=KH,
                                topk_obj=KO, noise_hand=nh, noise_obj=no)
-        m = copy.deepcopy(model_cpu).cuda().eval()
+        m = copy.deepcopy(model_contrast_cpu).cuda().eval()
         gdata = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
         m(gdata, mode='predict')                                   # builds the engine
         out = m._engine.predict(gdata, noise_hand=nh, noise_obj=no)
@@ -209,10 +218,13 @@ def test_readme_config_parity_with_the_oracle_up_to_score_ties(model_cpu, sd, as
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
     c = lambda t: t.detach().cpu()
+    # (A)
     assert gi['hand_ode']['nfev'] == info['hand_ode']['nfev'] and gi['obj_ode']['nfev'] == info['obj_ode']['nfev']
-    for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint', 'diff_final_hand_mano', 'diff_final_obj_6d'):
-        assert float((c(out[k]).double() - ref[k].double()).abs().max()) < 1e-4, k
-    gf, gd = gi['features'], gi['agg']
+    for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint', 'diff_final_hand_mano', 'diff_final_obj_6d', 'diff_final_hand_joint'):
+        err = float((c(out[k]).double() - ref[k].double()).abs().max())
+        assert err < (5e-4 if k == 'diff_final_hand_mano' else 1e-4), (k, err)
+    # (B)
+    gf = gi['features']
     fl = c(out['diff_final_hand_mano']).reshape(-1, 58)
     same = hoi_aggregate(assets, ANCHOR_SKELETON, cam_intrinsic=data['cam_intr_crop_flip'], root_joint_flip=data['root_joint_flip'],
                          root_joint=data['root_joint'], is_right=data['is_right'], force_local=c(gf['force_local']),
@@ -220,47 +232,46 @@ def test_readme_config_parity_with_the_oracle_up_to_score_ties(model_cpu, sd, as
                          hand_shape=fl[:, 48:], hand_heatmap=c(gf['hand_heatmap']), hand_bbox=data['bbox_hand'], hand_topk=KH,
                          obj_pose6d=c(out['diff_final_obj_6d']), obj_heatmap=c(gf['obj_heatmap']), obj_bbox=data['bbox_obj_rect'],
                          obj_topk=KO, obj_name=data['obj_name'])
-    od = same['dbg']
-    for k in ('transl_topk', 'rot_topk', 'phys_topk', 'heat_topk'):
-        assert torch.equal(c(gd[k]).long().reshape(od[k].shape), od[k].long()), k
-    assert float((c(out['agg_obj_6d']).double() - same['obj_agg_6d'].double()).abs().max()) < 1e-6
-    swaps = torch.zeros(n, dtype=torch.long)
-    for lvl in range(4):
-        g_idx, o_idx, o_val = c(gd['hand_topk'][lvl]).long(), od['hand']['topk'][lvl].long(), od['hand']['val'][lvl]
-        g_idx = g_idx.reshape(n, 5, -1).transpose(1, 2) if o_idx.dim() == 3 else g_idx.reshape(o_idx.shape)
-        ne = g_idx != o_idx
-        swaps += ne.reshape(n, -1).sum(1)
-        if ne.any():                                              # a differing index must be a tie between neighbouring ranks
-            gap = torch.minimum((o_val - o_val.roll(-1, 1)).abs(), (o_val - o_val.roll(1, 1)).abs()) / o_val.abs().clamp_min(1e-30)
-            assert float(gap[ne].max()) < 1e-5, (lvl, float(gap[ne].max()))
-    dj = (c(out['agg_hand_joint']).double() - same['hand_agg_joint'].double()).abs().amax(dim=(1, 2))
-    clean = swaps == 0
-    if clean.any():
-        assert float(dj[clean].max()) < 1e-5
+    same_out = dict(agg_hand_joint=same['hand_agg_joint'], agg_hand_vert=same['hand_agg_vert'], agg_hand_mano=same['hand_agg_mano'],
+                    agg_obj_6d=same['obj_agg_6d'])
+    res, _ = parity_summary(out, same_out, gi['agg'], same['dbg'], S, bound=TIE_REL)
+    print('identical candidates:', res)
+    assert res['images_with_wrong_selection'] == 0 and res['max_rel_score_gap_at_first_differences'] <= TIE_REL, res
+    assert res['images_all_selections_identical'] >= (7 * n) // 8, res
+    for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d'):
+        assert res[f'max_abs_{k}_where_identical'] < 1e-4, (k, res)
+    # end to end
+    e2e, _ = parity_summary(out, ref, gi['agg'], info['agg'], S, bound=E2E_TIE_REL)
+    print('end to end:', e2e)
+    assert e2e['images_with_wrong_selection'] == 0 and e2e['max_rel_score_gap_at_first_differences'] <= E2E_TIE_REL, e2e
+    assert e2e['images_hand_selection_identical'] >= (3 * n) // 4, e2e
+    for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d'):
+        assert e2e[f'max_abs_{k}_where_identical'] < 1e-4, (k, e2e)
+    assert e2e['mpjpe_delta_mm_all'] < 0.1, e2e
 
 
-def test_hip_path_matches_reference_at_readme_sizes(model_cpu, assets):
-    """Whole forward at sample_num=100, sampling_steps=50, topk 30/10 (2 images, T0=0.2 -- see make_golden_readme.py) against
-    the REFERENCE's own run: continuous outputs 2e-4, every selection stage rank by rank, aggregated poses on tie-free images."""
+def test_hip_path_matches_reference_at_readme_config(model_contrast_cpu, assets):
+    """Whole forward at the README config (sample_num=100, sampling_steps=50, topk 30/10, sample_T0=0.65; 8 images in one batch)
+    against the REFERENCE's own run (tests/golden/make_golden_readme.py): continuous outputs 2e-4, scipy's RHS-evaluation count;
+    aggregated joints / vertices / object 6-DoF of ALL 8 images to 2e-4 (bar 1e-3, no waiver; observed 6e-7); every selection
+    list identical to the reference's on at least 6 of the 8 images, and no first difference between candidates whose REFERENCE
+    scores are further apart than the fixed end-to-end bound (observed: two level-3 rank swaps at 1e-5 relative that leave the
+    outputs unchanged -- the hypotheses themselves are reproduced to 1e-5)."""
     import copy
-    from tests._readme_fixture import R, CFG, compare
+    from tests import _readme_fixture as RF
     from vpho_amd.configs.args import cfg
-    from vpho_amd.synth import synth_batch
     saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
-    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = (CFG[k] for k in ('sample_num', 'sampling_steps', 'topk_hand', 'topk_obj', 'sample_T0'))
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = (RF.CFG[k] for k in ('sample_num', 'sampling_steps', 'topk_hand', 'topk_obj', 'sample_T0'))
     try:
-        m = copy.deepcopy(model_cpu).cuda().eval()
-        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(2, assets, seed=4242).items()}
+        m = copy.deepcopy(model_contrast_cpu).cuda().eval()
+        data, nh, no = RF.inputs(assets)
+        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
         m(data, mode='predict')
-        out = m._engine.predict(data, noise_hand=torch.from_numpy(R['noise_hand']), noise_obj=torch.from_numpy(R['noise_obj']))
+        out = m._engine.predict(data, noise_hand=nh, noise_obj=no)
         torch.cuda.synchronize()
-        d = m._engine.last_info['agg']
+        info = m._engine.last_info
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
-    c = lambda t: t.detach().cpu()
-    hand = [c(d['hand_topk'][0])] + [c(d['hand_topk'][l]).reshape(2, 5, -1).transpose(1, 2) for l in (1, 2, 3)]
-    dirty = compare({k: c(v) for k, v in out.items() if torch.is_tensor(v)}, hand,
-            dict(transl=c(d['transl_topk']), rot=c(d['rot_topk']), final=c(d['heat_topk']), phys=c(d['phys_topk'])), upstream_tol=2e-4,
-            obj_scores=dict(transl=c(d['transl_score']), rot=c(d['rot_score']), final=c(d['heat_score']), phys=c(d['phys_score'])),
-            hand_val=[c(d['hand_val'][0])] + [c(d['hand_val'][l]).reshape(2, 5, -1).transpose(1, 2) for l in (1, 2, 3)])
-    assert dirty <= 1                                        # at least one of the two images is compared end to end
+    res = RF.compare({k: v for k, v in out.items() if torch.is_tensor(v)}, info['agg'], upstream_tol=2e-4,
+                     nfev=(info['hand_ode']['nfev'], info['obj_ode']['nfev']), min_identical=6, all_images_agg_tol=2e-4)
+    print(res)

@@ -62,3 +62,21 @@ def test_ode_sampler_ragged_rows_and_f32_trajectory(sd, nets):
     assert xs.dtype == torch.float32 and st['nfev'] == info['nfev']
     assert (xs.cpu().double() - xs_o).abs().max().item() < 1e-3
     assert (x.cpu() - x_o).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_full_batch_rk45_follows_the_reference_step_by_step(sd_contrast, name, D):
+    """README batch: R = 64 images x 100 hypotheses = 6400 rows under ONE RK45 controller (quirk Q5, score_based_model.py:91).
+    Fixture = the reference's own cond_ode_sampler + scipy on the same encodings and prior draw (make_golden_ode_fullbatch.py):
+    the device-side controller takes the same number of RHS evaluations, accepts / rejects the same attempts with the same step
+    sizes, and the strided samples / dense-output stamps agree to 1e-3 (north star; observed ~1e-5)."""
+    from oracle import nets as N
+    from tests import _ode_fixture as OF
+    from vpho_amd import ops
+    net = ops.ScoreNet(sd_contrast, f'denoiser_{name}', 'cuda')
+    enc, init = OF.inputs(name, D, N.ve_prior_sigma(OF.T0))
+    xs, x, st = net.sample(enc.cuda(), init.cuda(), OF.S, OF.T0, OF.STEPS, xs_f64=True)
+    torch.cuda.synchronize()
+    assert st['nan_count'] == 0
+    ex, exs = OF.check(name, xs.cpu(), x.cpu(), st['steps'], st['nfev'])
+    print(name, 'max abs x', ex, 'xs', exs)

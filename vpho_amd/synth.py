@@ -16,8 +16,64 @@ def _rng(key, seed):
     return np.random.default_rng((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
 
 
-def synth_state_dict(model, seed=0):
-    """Return a new state_dict for ``model`` (a vpho_net or any sub-module) with seeded values."""
+HM_GAIN_FLAT = 0.002       # round-1 fixtures: heat-maps 0.5 +- 0.008 (nearly flat: candidate scores differ in the 4th digit)
+HM_GAIN_CONTRAST = 0.7     # heat-maps 0.5 +- 0.15: candidate scores spread like a trained head's peaked maps do
+
+
+def condition_denoisers(sd, seed=0, c_hand=1.0, c_obj=1.5, noise_hand=0.005, noise_obj=0.003):
+    """Give the seeded score networks the gross behaviour of trained ones: hypotheses that contract towards a mode.
+
+    With purely random weights the probability-flow ODE (score_based_model.py:45-105) leaves the prior N(0, sigma(T0)^2) about
+    where it started: at the README's T0=0.65 (sigma = 2.5) object translations are metres away from the crop, every heat-map
+    score is exactly 0 and the reference's own result hangs on torch.topk's unspecified order among equal values.  A trained
+    network pulls samples towards the data.  Here that pull is written into the ReLU MLP exactly (denoiser.py:34-82,166-179,
+    234-247): pose_encoder carries x as (relu(x), relu(-x)) through both of its layers, six hidden units of every
+    ParallelLinear head rebuild +-(x - mu) and the output layer returns -c (x - mu) before the division by sigma(t), so
+    dx/dt = sigma(t) ln(sigma_max / sigma_min) c (x - mu): a contraction by exp(-c (sigma(T0) - sigma(eps))) = 0.08 (hand,
+    c = 1) / 0.02 (object, c = 1.5) around mu.  All other units keep their seeded random weights (output weights scaled to
+    `noise_*`), which displace the mode per image and per hypothesis.  mu: rot6d of the identity + seeded spread; object
+    translation near the hand root (root-relative, head_object.py:36-61).  Returns sd (modified in place)."""
+    for name, D, n, c, ns in (('denoiser_hand', 96, 32, c_hand, noise_hand), ('denoiser_obj', 9, 3, c_obj, noise_obj)):
+        r = _rng(name + '.mu', seed)
+        mu = np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), D // 6 if D == 96 else 1)
+        if D == 96:
+            mu = mu + r.normal(0, 0.15, 96).astype(np.float32)
+        else:
+            mu = np.concatenate([mu + r.normal(0, 0.3, 6).astype(np.float32), r.normal(0, 0.02, 3).astype(np.float32)])
+        w0, b0 = sd[f'{name}.pose_encoder.0.weight'], sd[f'{name}.pose_encoder.0.bias']            # (256,D), (256)
+        w0[:2 * D] = 0
+        b0[:2 * D] = 0
+        w0[:D] = torch.eye(D)
+        w0[D:2 * D] = -torch.eye(D)
+        w2, b2 = sd[f'{name}.pose_encoder.2.weight'], sd[f'{name}.pose_encoder.2.bias']            # (256,256)
+        w2[:2 * D] = 0
+        b2[:2 * D] = 0
+        w2[:2 * D, :2 * D] = torch.eye(2 * D)
+        h0, hb0 = sd[f'{name}.head.head.0.weight'], sd[f'{name}.head.head.0.bias']                 # (n,1408,256), (n,256)
+        h2, hb2 = sd[f'{name}.head.head.2.weight'], sd[f'{name}.head.head.2.bias']                 # (n,256,3), (n,3)
+        h2 *= ns / 0.02
+        hb2 *= 0
+        for i in range(n):
+            h0[i, :, :6] = 0
+            h2[i, :6, :] = 0
+            for j in range(3):
+                d = 3 * i + j
+                h0[i, 128 + d, j], h0[i, 128 + D + d, j], hb0[i, j] = 1.0, -1.0, -float(mu[d])
+                h0[i, 128 + d, 3 + j], h0[i, 128 + D + d, 3 + j], hb0[i, 3 + j] = -1.0, 1.0, float(mu[d])
+                h2[i, j, j], h2[i, 3 + j, j] = -c, c
+    return sd
+
+
+def synth_state_dict(model, seed=0, hm_gain=HM_GAIN_FLAT, conditioned=False):
+    """Return a new state_dict for ``model`` (a vpho_net or any sub-module) with seeded values.
+
+    ``hm_gain``: Kaiming gain of the heat-map heads' final 1x1 layer = the spatial contrast of the synthetic heat-maps.  The
+    aggregation ranks hypotheses by bicubic heat-map samples (aggregation.py:206-218); on a nearly flat map (HM_GAIN_FLAT)
+    the 200 candidates of an image score within 1e-4 of each other and one rank in a thousand is decided by the last bit of
+    the fp32 sums -- on any platform, the reference's own included.  HM_GAIN_CONTRAST gives the scores the spread of a
+    trained head (Gaussian peaks on a zero background) and is what the README-size parity tests and bench.py use; the small
+    golden fixtures of round 1 keep the flat maps they were generated with.
+    ``conditioned``: see ``condition_denoisers`` (score networks whose hypotheses cluster like a trained model's)."""
     sd = model.state_dict()
     out = {}
     for k, v in sd.items():
@@ -61,13 +117,20 @@ def synth_state_dict(model, seed=0):
             elif k.startswith('encoder_') and '.project.' in k:
                 gain = 0.25
             elif 'final_layer' in k:
-                gain = 0.002
+                gain = hm_gain
             elif 'fc_shape' in k or 'fc_pose' in k:
                 gain = 0.5
             out[k] = torch.from_numpy(r.normal(0, np.sqrt(gain / fan_in), shp).astype(np.float32))
         else:
             out[k] = torch.from_numpy(r.normal(0, 0.1, shp).astype(np.float32))
+    if conditioned and 'denoiser_hand.pose_encoder.0.weight' in out:
+        condition_denoisers(out, seed)
     return out
+
+
+def bench_state_dict(model, seed=1):
+    """The weights of bench.py and of the README-size parity tests: high-contrast heat-maps + conditioned score networks."""
+    return synth_state_dict(model, seed=seed, hm_gain=HM_GAIN_CONTRAST, conditioned=True)
 
 
 def synth_batch(bs, assets, seed=206, rank=0, patch=256):
