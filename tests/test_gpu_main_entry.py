@@ -1,0 +1,75 @@
+"""`main.py --mode eval --model vpho_net ...` end to end (BASELINE.json configs[0] sizes: sample_num=4, sampling_steps=5, topk 8/3),
+as its own process like the reference's `accelerate launch main.py` (README.md:61-72), with a checkpoint in accelerate's
+directory layout (base_trainer.py:81-89).  The table it prints must equal an in-process evaluation with the same weights."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ['--sample_num', '4', '--sampling_steps', '5', '--topk_hand', '8', '--topk_obj', '3', '--sample_T0', '0.2',
+        '--eval_batch_size', '2', '--num_batches', '2', '--random_seed', '7']
+
+
+def _run_main(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--mode', 'eval', '--model', 'vpho_net'] + ARGS + extra,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('EVAL_JSON ')]
+    assert len(line) == 1, r.stdout[-2000:]
+    return json.loads(line[0][len('EVAL_JSON '):]), r.stdout
+
+
+def test_main_eval_with_accelerate_checkpoint(tmp_path, assets):
+    from safetensors.torch import save_file
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_state_dict
+    m = vpho_net(assets)
+    sd = synth_state_dict(m, seed=3)                         # NOT the default seed: the numbers below prove the file was used
+    d = tmp_path / 'checkpoint' / 'epoch_45.state'
+    d.mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / 'model.safetensors'))
+    (d / 'optimizer.bin').write_bytes(b'')                   # accelerate writes these next to the model; they must be ignored
+    (d / 'random_states_0.pkl').write_bytes(b'')
+    got, stdout = _run_main(['--checkpoint', str(d)])
+    assert 'model.safetensors: 0 missing, 0 unexpected keys' in stdout, stdout[-1500:]
+    assert got['images'] == 4 and got['world'] == 1
+    # in-process evaluation with the same weights, batches and seeds (Trainer.eval's loop, sequential)
+    from vpho_amd.configs.args import cfg
+    from vpho_amd import evaluate as E
+    from vpho_amd.synth import synth_batch
+    saved = {k: getattr(cfg, k) for k in ('sample_num', 'sampling_steps', 'topk_hand', 'topk_obj', 'sample_T0')}
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 4, 5, 8, 3, 0.2
+    try:
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        torch.manual_seed(7)                                  # base_trainer.py:39-50 with rank 0
+        rows, gt = [], None
+        for i in range(2):
+            b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(2, assets, seed=7 + i, rank=0).items()}
+            out = m(b, mode='predict')
+            if gt is None:
+                gt = (out['reg_hand_joint'] + b['root_joint'][:, None], out['reg_hand_vert'] + b['root_joint'][:, None])
+            rows.append(E.metric_rows(out, b, gt[0], gt[1], i * 2, assets))
+        want = E.summarize(torch.cat(rows, 0).cpu())
+    finally:
+        for k, v in saved.items():
+            setattr(cfg, k, v)
+    for side in want:
+        for k, v in want[side].items():
+            assert got['table'][side][k] == pytest.approx(v, rel=1e-5, abs=1e-6), (side, k, got['table'][side][k], v)
+    # and the default weights give a different table: the checkpoint was really loaded
+    other, _ = _run_main([])
+    assert abs(other['table']['both']['MJE_agg'] - got['table']['both']['MJE_agg']) > 1e-3
+
+
+def test_main_eval_bad_checkpoint_path_fails_loudly(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--mode', 'eval'] + ARGS + ['--checkpoint', str(tmp_path / 'missing.state')],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'FileNotFoundError' in r.stderr

@@ -4,9 +4,10 @@
 prints the MJE/MVE tables after ONE all-gather of fixed-layout metric rows.  One process per GPU: launch with
 ``python -m torch.distributed.run --nproc-per-node N main.py --mode eval ...`` (or ``accelerate launch``, which sets the
 same RANK/LOCAL_RANK/WORLD_SIZE variables).  There is no dataset in this build: batches are synthetic (vpho_amd.synth).
-``run`` (``--mode train``) trains the two score networks on frozen features (first slice; the backbone
-backward is not built): per batch the feature path runs in inference mode and ``ScoreTrainer.step`` makes the reference's
-``repeat_num`` DSM draws, the backward, the data-parallel gradient average and the AdamW update for each denoiser.
+``run`` (``--mode train``): ``--train_scope full`` (default) runs the end-to-end training step (train_step.DiffusionTrainStep:
+backbone, heat-map heads, encoders, MANO head and score networks are all updated); ``--train_scope score`` trains the two score
+networks on frozen features (``ScoreTrainer.step``: the reference's ``repeat_num`` DSM draws, backward, data-parallel gradient
+average and AdamW per denoiser).
 """
 import os
 import time
@@ -17,6 +18,31 @@ import torch.distributed as dist
 from . import evaluate as E
 from .assets import load_assets
 from .synth import synth_state_dict, synth_batch
+
+
+def load_checkpoint_state_dict(path):
+    """The state_dict of a checkpoint written by the reference: ``accel.save_state(<save_dir>/checkpoint/epoch_N.state)`` --
+    a DIRECTORY holding ``model.safetensors`` (accelerate's default) or ``pytorch_model.bin`` next to optimizer / scheduler /
+    RNG files (base_trainer.py:81-89) -- or ``final_model.pt`` / any plain ``state_dict`` file (base_trainer.py:91-96).
+    Keys of a DistributedDataParallel wrapper (``module.`` prefix) are accepted."""
+    if os.path.isdir(path):
+        cand = [os.path.join(path, f) for f in ('model.safetensors', 'pytorch_model.bin', 'model.bin', 'pytorch_model.safetensors')]
+        found = [c for c in cand if os.path.exists(c)]
+        if not found:
+            raise FileNotFoundError(f'{path} is a directory but holds no model file of an accelerate state (looked for: '
+                                    + ', '.join(os.path.basename(c) for c in cand) + f'); it contains: {sorted(os.listdir(path))[:20]}')
+        path = found[0]
+    elif not os.path.exists(path):
+        raise FileNotFoundError(f'checkpoint {path} does not exist')
+    if path.endswith('.safetensors'):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    else:
+        sd = torch.load(path, map_location='cpu', weights_only=True)
+    if isinstance(sd, dict) and 'state_dict' in sd and not any(torch.is_tensor(v) for v in sd.values()):
+        sd = sd['state_dict']
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+    return sd, path
 
 
 def synthetic_mano_targets(mano, gt_rot6d, gt_shape, is_right):
@@ -51,15 +77,7 @@ class Trainer:
         from .model.VPHO import vpho_net
         model = vpho_net(self.assets)
         if self.cfg.checkpoint:
-            path = self.cfg.checkpoint
-            if os.path.isdir(path):                                    # accelerate.save_state directory (epoch_N.state)
-                cand = [os.path.join(path, f) for f in ('pytorch_model.bin', 'model.safetensors')]
-                path = next(p for p in cand if os.path.exists(p))
-            if path.endswith('.safetensors'):
-                from safetensors.torch import load_file
-                sd = load_file(path)
-            else:
-                sd = torch.load(path, map_location='cpu')
+            sd, path = load_checkpoint_state_dict(self.cfg.checkpoint)
             missing, unexpected = model.load_state_dict(sd, strict=False)      # base_trainer.py:81-83 (strict=False)
             if self.rank == 0:
                 print(f'loaded {path}: {len(missing)} missing, {len(unexpected)} unexpected keys')
@@ -155,6 +173,8 @@ class Trainer:
                 if name != 'object':
                     print(f'{name:>5s}: n={r["n"]:5d}  MJE reg {r["MJE_reg"]:.2f}  first {r["MJE_first"]:.2f}  agg {r["MJE_agg"]:.2f}  MVE agg {r["MVE_agg"]:.2f}  (mm)')
             print('object (aggregated pose): ' + '  '.join(f'{k} {v:.2f}' for k, v in table['object'].items()))
+            import json
+            print('EVAL_JSON ' + json.dumps({'images': int(rows.shape[0]), 'world': self.world, 'table': table}))
         if self.world > 1:
             dist.barrier()
         return rows
