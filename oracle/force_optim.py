@@ -1,8 +1,8 @@
 """Pseudo-force label optimisation -- torch-CPU restatement of the inner loop of the reference's
 ForceOptimizer.optimize_batch (lib/engine/force_optimization.py:110-207) with HeadForce.get_local_force
-(lib/model/physics.py:277-288) and from_local_to_global (:362-371).  The reference file itself is not runnable as shipped
-(it imports lib.dataset.dexycb4 / ho3d2, which are not in the tree, force_optimization.py:12-13), so the loop as a whole is
-*parity unpinned*; its building blocks (get_local_force, ForceAnchor) are pinned by tests/golden/golden_blocks.npz.
+(lib/model/physics.py:277-288) and from_local_to_global (:362-371).  Pinned by tests/golden/golden_force_optim.npz: the reference's
+own optimize_batch run unchanged for its 3000 iterations (tests/golden/make_golden_force_optim.py stubs only the two dataset
+modules the file imports but the tree lacks, force_optimization.py:12-13, and the accelerate object).
 TEST INFRASTRUCTURE -- see oracle/__init__.py."""
 import torch
 import torch.nn.functional as F

@@ -240,3 +240,24 @@ def test_oracle_rk45_at_the_full_batch_matches_reference(sd_contrast):
     feat = enc[:, None].repeat(1, OF.S, 1).reshape(-1, 1024)
     xs, x, info = N.ode_sample(sd_contrast, 'denoiser_obj', feat, init, OF.T0, OF.STEPS)
     ex, exs = OF.check('obj', xs, x, info['steps'], info['nfev'], x_tol=1e-4)
+
+
+def test_oracle_force_optimisation_loop_matches_reference(assets):
+    """oracle.force_optim.optimize vs the reference's OWN ForceOptimizer.optimize_batch (tests/golden/make_golden_force_optim.py:
+    the real loop, 3000 AdamW iterations with torch.optim.AdamW, HeadForce and VERT2ANCHOR): parameters after 40 / 400 / 1000 /
+    400 steps (both phases, both optimiser states).  Both sides are torch-CPU autograd: 1e-6 after 40 steps, 1e-4 after 400."""
+    from oracle import force_optim as FO
+    sys_path = os.path.join(os.path.dirname(__file__), 'golden')
+    g = np.load(os.path.join(sys_path, 'golden_force_optim.npz'))
+    B = int(g['B'])
+    gen = torch.Generator().manual_seed(int(g['seed']))
+    v = torch.as_tensor(assets['mano']['v_template'])[None] + torch.randn(B, 778, 3, generator=gen) * 0.002 + torch.tensor([0.0, 0.0, 0.7])
+    grav = torch.nn.functional.normalize(torch.randn(B, 1, 3, generator=gen), dim=-1)
+    com = torch.tensor([0.05, 0.0, 0.7]) + torch.randn(B, 1, 3, generator=gen) * 0.02
+    fc = torch.rand(B, 32, generator=gen)
+    grasped = torch.rand(B, generator=gen) < 0.8
+    for iters, tol in ((40, 1e-6), (400, 1e-4)):         # 400 fp32 AdamW steps amplify summation-order differences to ~2e-5
+        r = FO.optimize(assets['anchor'], ANCHOR_SKELETON, v, grav, com, fc, grasped, iters=iters, phase1=300)
+        assert float((r['scale'] - torch.as_tensor(g[f'scale_{iters}'])).abs().max()) < tol, iters
+        assert float((r['weight'] - torch.as_tensor(g[f'weight_{iters}'])).abs().max()) < tol, iters
+    close(r['force_point'], g['force_point'], 1e-5, 1e-7)
