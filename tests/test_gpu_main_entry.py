@@ -29,7 +29,9 @@ def test_main_eval_with_accelerate_checkpoint(tmp_path, assets):
     from safetensors.torch import save_file
     from vpho_amd.model.VPHO import vpho_net
     from vpho_amd.synth import synth_state_dict
-    m = vpho_net(assets)
+    torch.manual_seed(7)                                     # base_trainer.py:39-50 (rank 0): the seed is set BEFORE the model is
+    m = vpho_net(assets)                                     # built, and building it draws from the same CPU generator (Trainer order)
+    rng_after_build = torch.get_rng_state()
     sd = synth_state_dict(m, seed=3)                         # NOT the default seed: the numbers below prove the file was used
     d = tmp_path / 'checkpoint' / 'epoch_45.state'
     d.mkdir(parents=True)
@@ -48,7 +50,7 @@ def test_main_eval_with_accelerate_checkpoint(tmp_path, assets):
     try:
         m.load_state_dict(sd)
         m = m.cuda().eval()
-        torch.manual_seed(7)                                  # base_trainer.py:39-50 with rank 0
+        torch.set_rng_state(rng_after_build)
         rows, gt = [], None
         for i in range(2):
             b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(2, assets, seed=7 + i, rank=0).items()}
