@@ -24,6 +24,9 @@ os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FEATURE_GFLOP_PER_IMAGE = 37.09
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk_kernel', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
+                    'roi_align': 'roi_align_nhwc_kernel', 'resize_bilinear': 'resize_bilinear_nhwc_kernel'}
 
 
 def parse():
@@ -168,7 +171,8 @@ def main():
         print('per-step ms:', ' '.join(f'{t:.1f}' for t in step_ms_seq), file=sys.stderr)
     # ---- roofline leg: the same K steps again with HIP events recorded around every launch of the timed kernel
     # classes on their launch streams (kept out of the timed region: ~500 event pairs per step perturb it by 10-15 %)
-    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head')
+    hbm_classes = ('mano_fk', 'obj_physics', 'hand_fuse', 'roi_align', 'resize_bilinear')
+    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head') + hbm_classes
     prof = {c: dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0) for c in timed_classes}
     if not args.no_kernel_timing:
         for c in timed_classes:
@@ -215,7 +219,7 @@ def main():
                          'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),
                                                'kernel_ms_per_step': v['total_ms'] / max(args.steps, 1),
                                                'launches_per_step': v['launches'] / max(args.steps, 1)}
-                                           for k, v in prof.items() if k not in ('conv_igemm_128x128', 'score_head')},
+                                           for k, v in prof.items() if k in ('conv_igemm_128x64', 'conv_igemm_64x64')},
                          'launches_per_step': conv['launches'] / max(args.steps, 1),
                          'avg_launch_us': conv['total_ms'] * 1e3 / max(conv['launches'], 1),
                          'flop_per_launch_avg': conv['flops'] / max(conv['launches'], 1),
@@ -224,6 +228,17 @@ def main():
                                         'kernel_ms_per_step': head['total_ms'] / max(args.steps, 1),
                                         'launches_per_step': head['launches'] / max(args.steps, 1)},
                          'feature_path_gflop_per_image_ref': FEATURE_GFLOP_PER_IMAGE},
+            # HBM-bound kernels of the path (north star: MANO skinning, distance kernels, top-k as GB/s against the chip's HBM peak):
+            # achieved = ALGORITHMIC bytes (operands read once + results written once, stated at the launch site) / HIP-event kernel time
+            'hbm': {'peak_GBps': HBM_PEAK_GBPS, 'note': 'achieved = algorithmic bytes / kernel time (HIP events, instrumented repeat of the K steps); '
+                                                          'traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE), null when absent',
+                    'kernels': {k: {'GB/s': (prof[k]['bytes'] / (prof[k]['total_ms'] * 1e-3) / 1e9 if prof[k]['total_ms'] > 0 else 0.0),
+                                    'frac': (prof[k]['bytes'] / (prof[k]['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS if prof[k]['total_ms'] > 0 else 0.0),
+                                    'avg_launch_us': prof[k]['total_ms'] * 1e3 / max(prof[k]['launches'], 1),
+                                    'launches_per_step': prof[k]['launches'] / max(args.steps, 1),
+                                    'kernel_ms_per_step': prof[k]['total_ms'] / max(args.steps, 1),
+                                    'algorithmic_bytes_per_launch': prof[k]['bytes'] / max(prof[k]['launches'], 1),
+                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k])} for k in hbm_classes}},
             'metrics_rows_gathered': int(all_rows.shape[0]),
             'host_cpu': host_cpu,
         }
@@ -237,14 +252,19 @@ def main():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE; profiles/r01_pmc_hbm_traffic.json, produced by scripts/pmc_summary.py); None when absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel]['hbm_bytes_per_launch']
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` (name prefix) from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; profiles/r0N_pmc_hbm_traffic.json, produced by scripts/pmc_summary.py, newest round first); None when absent."""
+    for rnd in ('r02', 'r01'):
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_hbm_traffic.json')
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except Exception:
+            continue
+        for name, v in tab.items():
+            if name.startswith(kernel) or kernel in name.split('(')[0]:
+                return v['hbm_bytes_per_launch']
+    return None
 
 
 def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):

@@ -22,7 +22,8 @@ const char* vpho_last_error(void);
 int vpho_abi_version(void);
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
- * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile).
+ * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
+ * reported in bytes: 4 = MANO FK, 5 = object physics score, 6 = hand cascade fuse, 7 = RoIAlign, 8 = bilinear resize).
  * vpho_prof_collect waits for the recorded events and returns the summed kernel time, the launch count, the algorithmic
  * flop (2*M*N*K) and the algorithmic bytes (operands once) issued. */
 int vpho_prof_enable(int kernel_class, int on);
@@ -384,6 +385,30 @@ int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope,
  * first (1 / world_size after a sum all-reduce) */
 int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- physics branch of the training step (lib/model/VPHO.py:170-172,205-212 under loss.backward()) -------------------------------
+ * backward of vpho_cross_tokens_f32 (cross_module.py:125-133: .view(bs,32,-1) of the projected maps, cat, + positional code):
+ * dtok [bs][65][512] -> d_proj_hand / d_proj_obj [bs][8][8][256] NHWC (NULL for the stream the reference detaches, VPHO.py:170-171)
+ * and d_grav_emb [bs][512] (may be NULL) */
+int vpho_cross_tokens_bwd_f32(const float* dtok, int bs, float* d_proj_hand, float* d_proj_obj, float* d_grav_emb, void* stream);
+/* backward of vpho_add_layernorm_f32 (norm1 / norm2 of nn.TransformerEncoderLayer, post-norm): dy -> dx = d(x + r) and dy_xhat =
+ * dy * normalised input per element (d gamma = its column sums, d beta = the column sums of dy) */
+int vpho_layernorm_bwd_f32(const float* x, const float* r, const float* gamma, const float* dy, long long rows, int E, float eps,
+                           float* dx, float* dy_xhat, void* stream);
+/* backward of vpho_mha_f32 (nn.MultiheadAttention inside the encoder layer, sequence axis = batch, quirk Q3; attention dropout 0):
+ * qkv [S*B][3E], d_out [S*B][E] -> dqkv [S*B][3E]; S <= 64 */
+int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, float* dqkv, void* stream);
+/* HeadPhysics tail + losses + gradient (physics.py:546-557 get_local_force with the double soft-max of :659-664, :362-371
+ * from_local_to_global on the GROUND-TRUTH vertices, :456-500 get_loss; weights as VPHO.py:214-219): scale_raw [bs*32] (fc_scale
+ * output), logits [bs*32][8] (fc_weight before its Softmax), com [bs*32][3] (fc_CoM output); frame [bs][32][3][3] / point
+ * [bs][32][3] from vpho_anchor_frames_f32 of gt_hand_vert_flip; gt_force_local [bs][32][3]; gravity, gt_com [bs][3] in the flipped
+ * frame; weights5 (HOST array) = weight_{force,gravity,torque,supervised,CoM}_loss.  Outputs: force_local [bs*32][3], the weighted
+ * losses losses5 (device, fp64, same order) and d(total)/d(scale_raw | logits | com).  partial_ws: bs*5 doubles. */
+int vpho_physics_loss_f32(const float* scale_raw, const float* logits, const float* com, const float* anchor, float friction,
+                          const float* frame, const float* point, const float* gt_force_local, const float* gravity,
+                          const float* gt_com, const unsigned char* is_grasped, const float* weights5, int bs,
+                          float* force_local, float* d_scale, float* d_logits, float* d_com, double* losses5, double* partial_ws,
+                          void* stream);
 
 #ifdef __cplusplus
 }

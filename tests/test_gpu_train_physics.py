@@ -1,0 +1,79 @@
+"""Physics branch of the training step (lib/model/VPHO.py:170-172,205-212) against the reference's own
+CrossModule x 2 + HeadPhysics + get_loss under autograd (tests/golden/make_golden_physics_train.py; dropout sites at 0):
+forward tokens / forces, the five weighted losses, the gradient of all 48 parameter tensors and of the two stage maps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_physics_train.npz'))
+BS, STRIDE = 6, 997
+W = dict(force_loss=1.0, gravity_loss=1.0, torque_loss=30.0, supervised_loss=10.0, CoM_loss=100.0)
+
+
+def inputs(assets):
+    """the generator's inputs (tests/golden/make_golden_physics_train.py::inputs)"""
+    g = np.random.default_rng(123)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    grav = g.normal(size=(BS, 1, 3))
+    grav /= np.linalg.norm(grav, axis=-1, keepdims=True)
+    vert = np.asarray(assets['mano']['v_template'])[None] + g.normal(size=(BS, 778, 3)) * 0.002 + np.array([0.02, -0.01, 0.7])
+    return dict(st_h=f32(g.normal(size=(BS, 256, 8, 8)) * 0.2), st_o=f32(g.normal(size=(BS, 256, 8, 8)) * 0.2), gravity=f32(grav),
+                gt_vert=f32(vert), gt_CoM=f32(np.array([0.05, 0.0, 0.7]) + g.normal(size=(BS, 1, 3)) * 0.02),
+                gt_force_local=f32(g.normal(size=(BS, 32, 3)) * 0.1), is_grasped=torch.from_numpy(g.random(BS) < 0.7))
+
+
+@pytest.fixture(scope='module')
+def run(sd, assets):
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    from vpho_amd.train_blocks import PhysicsTrain
+    d = inputs(assets)
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    pt = PhysicsTrain(sd, agg, torch.device('cuda'))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    out = pt.forward_backward(nhwc(d['st_h']), nhwc(d['st_o']), d['gravity'].cuda(), d['gt_CoM'].cuda(), torch.ones(BS, dtype=torch.bool).cuda(),
+                              d['gt_vert'].cuda(), d['gt_force_local'].cuda(), d['is_grasped'].cuda(), tuple(W.values()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_forward_tokens_forces_and_losses(run):
+    L, d_sth, d_sto, grads, fl, aux = run
+    c = lambda t: t.detach().cpu().numpy()
+    assert np.abs(c(aux['tok_hand'])[:, ::8, ::16] - G['tok_hand']).max() < 2e-5
+    assert np.abs(c(aux['tok_obj'])[:, ::8, ::16] - G['tok_obj']).max() < 2e-5
+    assert np.abs(c(aux['scale']) - G['scale']).max() < 1e-5          # the raw fc_scale output (abs is taken inside get_local_force)
+    assert np.abs(c(aux['com']) - G['CoM']).max() < 1e-5
+    assert np.abs(c(fl) - G['force_local']).max() < 1e-5
+    for k in W:
+        np.testing.assert_allclose(float(L[k]), float(G[k]), rtol=2e-5, err_msg=k)
+
+
+def test_parameter_gradients(run):
+    L, d_sth, d_sto, grads, fl, aux = run
+    names = [k[len('gnorm_'):] for k in G.files if k.startswith('gnorm_') and not k.startswith('gnorm_st_')]
+    assert len(names) == 48 and set(names) == set(grads), sorted(set(names) ^ set(grads))[:6]
+    worst = 0.0
+    for n in names:
+        g = grads[n].detach().cpu().reshape(-1)
+        nrm = float(G['gnorm_' + n])
+        np.testing.assert_allclose(float(g.double().norm()), nrm, rtol=1e-4, atol=1e-9, err_msg=n)
+        ref = G['g_' + n]
+        got = (g if g.numel() <= 4096 else g[::STRIDE]).numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+        worst = max(worst, err)
+        assert err < 2e-4, (n, err)
+    print('worst relative gradient error', worst)
+
+
+def test_stage_map_gradients(run):
+    """d loss / d stage maps: what the two encoders' backward receives (the detached streams contribute nothing, VPHO.py:170-171)"""
+    L, d_sth, d_sto, grads, fl, aux = run
+    for k, t in (('st_h', d_sth), ('st_o', d_sto)):
+        g = t.permute(0, 3, 1, 2).contiguous().cpu().reshape(-1)            # NHWC -> the reference's NCHW order
+        np.testing.assert_allclose(float(g.double().norm()), float(G['gnorm_' + k]), rtol=1e-4)
+        ref = G['g_' + k]
+        assert np.abs(g[::101].numpy() - ref).max() < 2e-4 * np.abs(ref).max(), k

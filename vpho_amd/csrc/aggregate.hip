@@ -543,6 +543,9 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
     a.hv = hv; a.n_obs_total = n_obs; a.pose = pose; a.bs = bs; a.C = C; a.k = k; a.level = level;
     for (int f = 0; f < 5; ++f) a.jid[f] = jid[level][f];
     a.val = val; a.idx = idx; a.topk_pose = topk_pose;
+    // algorithmic bytes: the score table read once, the fused joints (3 or 5 x 3 floats) written into every candidate's pose
+    vpho::ProfScope prof(vpho::PROF_HAND_FUSE, (hipStream_t)stream, 0.0,
+                         (double)bs * C * ((double)n_obs * 4 + (level == 0 ? 3 : 15) * 4) + (double)bs * (level == 0 ? 1 : 5) * k * 8);
     hipLaunchKernelGGL(hand_fuse_kernel, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
     return vpho::check_launch("hand_fuse_kernel");
 }
@@ -583,6 +586,9 @@ extern "C" int vpho_obj_physics_score(const double* cand, int n, const float* ro
     ObjPhysArgs a;
     a.cand = cand; a.n = n; a.root = root; a.vert_tab = t->vert; a.com_tab = t->com; a.obj_id = obj_id; a.is_right = is_right; a.nv = t->n_vert;
     a.force_point = force_point; a.force_global = force_global; a.score = score;
+    // algorithmic bytes: the object's vertex table and the 32 force points / forces once per image, 72-byte pose + score per candidate
+    vpho::ProfScope prof(vpho::PROF_OBJ_PHYSICS, (hipStream_t)stream, 0.0,
+                         (double)bs * ((double)t->n_vert * 12 + 2 * 32 * 12) + (double)bs * n * (72 + 4));
     hipLaunchKernelGGL(obj_physics_kernel, dim3(bs * n), dim3(256), (size_t)t->n_vert * 12, (hipStream_t)stream, a);
     return vpho::check_launch("obj_physics_kernel");
 }

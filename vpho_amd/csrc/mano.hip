@@ -229,6 +229,9 @@ extern "C" int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, in
     a.hands_per_image = hands_per_image; a.ho3d = ho3d_per_image; a.verts = verts; a.joints = joints;
     // hands per block: enough reuse of the pose-blend table for big batches, enough blocks for small ones
     const unsigned gy = verts ? 4 : 1;
+    // algorithmic bytes: 48 pose floats read + 21 joints (+ 778 vertices) written per hand; v_shaped + J read once per image
+    vpho::ProfScope prof(vpho::PROF_MANO_FK, (hipStream_t)stream, 0.0,
+                         (double)n_hands * (48 * 4 + 21 * 12 + (verts ? 778 * 12 : 0)) + (double)((n_hands + hands_per_image - 1) / hands_per_image) * (778 + 16) * 12);
     if (n_hands >= 1024) hipLaunchKernelGGL(mano_fk_kernel<16>, dim3((unsigned)((n_hands + 15) / 16), gy), dim3(256), 0, (hipStream_t)stream, a);
     else if (n_hands >= 128) hipLaunchKernelGGL(mano_fk_kernel<4>, dim3((unsigned)((n_hands + 3) / 4), gy), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mano_fk_kernel<1>, dim3((unsigned)n_hands, gy), dim3(256), 0, (hipStream_t)stream, a);

@@ -501,6 +501,8 @@ extern "C" int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W
                                              float* y, int ldy, int c_off, int accumulate, void* stream) {
     VPHO_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && ldx >= C && ldy >= c_off + C && c_off >= 0,
                  "vpho_resize_bilinear_nhwc_f32: bad argument");
+    // algorithmic bytes: input read once, output written once (and read once when accumulating into it)
+    vpho::ProfScope prof(vpho::PROF_RESIZE, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)OH * OW * (accumulate ? 2 : 1)));
     if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
         LAUNCH1D(resize_bilinear_nhwc_kernel<4>, (long long)N * OH * OW * (C / 4), stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
     else
@@ -511,6 +513,8 @@ extern "C" int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W
 extern "C" int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                        int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream) {
     VPHO_REQUIRE(feat && boxes && out && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_nhwc_f32: bad argument");
+    // algorithmic bytes: the feature map read once (upper bound of what a box covers), the pooled map written once
+    vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)out_size * out_size));
     if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)feat | (uintptr_t)out) % 16 == 0)
         LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
     else

@@ -800,8 +800,44 @@ def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, w
           I(step), F(grad_scale))
 
 
+# ----------------------------------------------------------------------------------------------- physics branch (training)
+def cross_tokens_bwd(dtok, want_hand=True, want_obj=True):
+    bs = dtok.shape[0]
+    dph = torch.zeros((bs, 8, 8, 256), device=dtok.device) if want_hand else None
+    dpo = torch.zeros((bs, 8, 8, 256), device=dtok.device) if want_obj else None
+    dge = _new((bs, 512), dtok)
+    _call('vpho_cross_tokens_bwd_f32', _f32(dtok), I(bs), _f32(dph), _f32(dpo), _f32(dge))
+    return dph, dpo, dge
+
+
+def layernorm_bwd(x, r, gamma, dy, eps=1e-5):
+    E = x.shape[-1]
+    dx, gx = torch.empty_like(x), torch.empty_like(x)
+    _call('vpho_layernorm_bwd_f32', _f32(x), _f32(r), _f32(gamma), _f32(dy), LL(x.numel() // E), I(E), F(eps), _f32(dx), _f32(gx))
+    return dx, gx
+
+
+def mha_bwd(qkv, d_out, S, B, E, nhead):
+    dqkv = torch.empty_like(qkv)
+    _call('vpho_mha_bwd_f32', _f32(qkv), _f32(d_out), I(S), I(B), I(E), I(nhead), _f32(dqkv))
+    return dqkv
+
+
+def physics_loss(scale_raw, logits, com, anchor, frame, point, gt_force_local, gravity, gt_com, is_grasped, weights, friction=0.8):
+    """-> force_local (bs*32,3), losses (5,) fp64 device [force, gravity, torque, supervised, CoM] (weighted), d scale_raw / d logits / d com"""
+    bs = gravity.shape[0]
+    fl, dsc, dlg, dcm = _new((bs * 32, 3), com), _new((bs * 32, 1), com), _new((bs * 32, 8), com), _new((bs * 32, 3), com)
+    losses, ws = _new((5,), com, torch.float64), _new((bs * 5,), com, torch.float64)
+    w5 = (C.c_float * 5)(*[float(w) for w in weights])
+    _call('vpho_physics_loss_f32', _f32(scale_raw), _f32(logits), _f32(com), _f32(anchor), F(friction), _f32(frame), _f32(point),
+          _f32(gt_force_local), _f32(gravity), _f32(gt_com), _u8(is_grasped), w5, I(bs), _f32(fl), _f32(dsc), _f32(dlg), _f32(dcm),
+          _f64(losses), _f64(ws))
+    return fl, losses, dsc, dlg, dcm
+
+
 # ----------------------------------------------------------------------------------------------- profiling hooks
-PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3}
+PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3,
+                'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8}
 
 
 def prof_enable(name, on=True):

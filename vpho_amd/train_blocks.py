@@ -392,3 +392,173 @@ class HeadManoTrain:
         G['base_layer.0.weight'], G['base_layer.0.bias'] = _wgrad(x, dh1), ops.colsum(dh1)
         dx = ops.linear(dh1, P['base_layer.0.weight'].t().contiguous())
         return L, dx, G
+
+
+class CrossTrain:
+    """Training-mode forward + backward of one ``CrossModule(8, 512)`` (lib/model/cross_module.py:91-137): 3x3 projections of the two
+    8x8 stage maps -> (bs, 32, 512) token streams + the NeRF-embedded gravity token + sinusoidal positional code -> ONE post-norm
+    ``nn.TransformerEncoderLayer`` (2 heads, FFN 2048, ReLU) whose sequence axis is the batch (quirk Q3).  The Linear / Conv2d layers
+    run on the fp32-MFMA implicit-GEMM kernels (forward and dgrad) and the TN weight-gradient kernel; csrc/train_physics.hip holds
+    the token / LayerNorm / attention backward.  ``p_drop``: the reference trains with its five Dropout sites at 0.1
+    (PositionalEncoding, attention probabilities excluded here -- see below --, after self-attention, inside and after the FFN); the
+    masks are Bernoulli draws from the device generator applied with plain tensor multiplies.  Attention-probability dropout is
+    not applied (the fused attention kernels keep P in registers / LDS); the fixtures run every site at 0."""
+    L = 'attn.layers.0'
+
+    def __init__(self, sd, prefix, device, p_drop=0.0):
+        import torch
+        self.dev, self.p_drop = device, p_drop
+        g = lambda k: sd[f'{prefix}.{k}'].detach().float().to(device).contiguous().clone()
+        from .model.pack import pack_conv
+        self.shapes = {k: tuple(sd[f'{prefix}.{k}.weight'].shape) for k in ('proj_hand', 'proj_obj')}
+        self.conv = {k: [pack_conv(sd[f'{prefix}.{k}.weight'].detach().float(), None).to(device), g(f'{k}.bias')] for k in ('proj_hand', 'proj_obj')}
+        self.p = {k: g(k) for k in ('gravity_proj.weight', 'gravity_proj.bias', f'{self.L}.self_attn.in_proj_weight', f'{self.L}.self_attn.in_proj_bias',
+                                    f'{self.L}.self_attn.out_proj.weight', f'{self.L}.self_attn.out_proj.bias', f'{self.L}.linear1.weight',
+                                    f'{self.L}.linear1.bias', f'{self.L}.linear2.weight', f'{self.L}.linear2.bias', f'{self.L}.norm1.weight',
+                                    f'{self.L}.norm1.bias', f'{self.L}.norm2.weight', f'{self.L}.norm2.bias')}
+        self.pe = g('pose_embedder.pe')[:, 0, :].contiguous()                 # (5000, 512) buffer
+        self._gw64 = torch.nn.functional.pad(self.p['gravity_proj.weight'], (0, 1)).contiguous()       # 63 -> 64 input columns
+
+    def _drop(self, x):
+        import torch
+        if self.p_drop <= 0.0:
+            return x, None
+        m = (torch.rand_like(x) >= self.p_drop).float() / (1.0 - self.p_drop)
+        return x * m, m
+
+    def forward(self, st_h, st_o, grav_emb):
+        """st_h, st_o (bs,8,8,256) NHWC, grav_emb (bs,64) = ops.nerf_embed(gravity, flip) -> tokens (bs*65, 512)"""
+        import torch
+        P, L = self.p, self.L
+        bs = st_h.shape[0]
+        ph = ops.conv2d_nhwc(st_h, *self.conv['proj_hand'], kh=3, kw=3, pad=1)
+        po = ops.conv2d_nhwc(st_o, *self.conv['proj_obj'], kh=3, kw=3, pad=1)
+        self._gw64 = torch.nn.functional.pad(P['gravity_proj.weight'], (0, 1)).contiguous()
+        ge = ops.linear(grav_emb, self._gw64, P['gravity_proj.bias'])
+        x0, m0 = self._drop(ops.cross_tokens(ph, po, ge, self.pe[:bs].contiguous()).view(bs * 65, 512))
+        qkv = ops.linear(x0, P[f'{L}.self_attn.in_proj_weight'], P[f'{L}.self_attn.in_proj_bias'])
+        att = ops.mha(qkv, bs, 65, 512, 2).view(bs * 65, 512)
+        sa, m1 = self._drop(ops.linear(att, P[f'{L}.self_attn.out_proj.weight'], P[f'{L}.self_attn.out_proj.bias']))
+        x1 = ops.add_layernorm(x0, sa, P[f'{L}.norm1.weight'], P[f'{L}.norm1.bias'])
+        h, mh = self._drop(ops.linear(x1, P[f'{L}.linear1.weight'], P[f'{L}.linear1.bias'], out_slope=0.0))
+        ff, m2 = self._drop(ops.linear(h, P[f'{L}.linear2.weight'], P[f'{L}.linear2.bias']))
+        x2 = ops.add_layernorm(x1, ff, P[f'{L}.norm2.weight'], P[f'{L}.norm2.bias'])
+        self.saved = dict(st_h=st_h, st_o=st_o, emb=grav_emb, x0=x0, qkv=qkv, att=att, sa=sa, x1=x1, h=h, ff=ff, bs=bs, masks=(m0, m1, mh, m2))
+        return x2
+
+    def backward(self, d_x2, want_hand=True, want_obj=True):
+        """d_x2 (bs*65,512) -> d st_h, d st_o (None for the stream the caller detached), grads under the reference's names"""
+        from .train_score import _wgrad
+        P, L, S = self.p, self.L, self.saved
+        bs = S['bs']
+        m0, m1, mh, m2 = S['masks']
+        T = lambda w: w.t().contiguous()
+        G = {}
+        d_s2, gx2 = ops.layernorm_bwd(S['x1'], S['ff'], P[f'{L}.norm2.weight'], d_x2)
+        G[f'{L}.norm2.weight'], G[f'{L}.norm2.bias'] = ops.colsum(gx2), ops.colsum(d_x2)
+        d_ff = d_s2 if m2 is None else d_s2 * m2
+        G[f'{L}.linear2.weight'], G[f'{L}.linear2.bias'] = _wgrad(S['h'], d_ff), ops.colsum(d_ff)
+        d_h = ops.linear(d_ff, T(P[f'{L}.linear2.weight']))
+        if mh is not None:
+            d_h = d_h * mh
+        d_h = ops.lrelu_bwd(d_h, S['h'], 0.0)
+        G[f'{L}.linear1.weight'], G[f'{L}.linear1.bias'] = _wgrad(S['x1'], d_h), ops.colsum(d_h)
+        d_x1 = ops.add_lrelu(d_s2, ops.linear(d_h, T(P[f'{L}.linear1.weight'])))
+        d_s1, gx1 = ops.layernorm_bwd(S['x0'], S['sa'], P[f'{L}.norm1.weight'], d_x1)
+        G[f'{L}.norm1.weight'], G[f'{L}.norm1.bias'] = ops.colsum(gx1), ops.colsum(d_x1)
+        d_sa = d_s1 if m1 is None else d_s1 * m1
+        G[f'{L}.self_attn.out_proj.weight'], G[f'{L}.self_attn.out_proj.bias'] = _wgrad(S['att'], d_sa), ops.colsum(d_sa)
+        d_att = ops.linear(d_sa, T(P[f'{L}.self_attn.out_proj.weight']))
+        dqkv = ops.mha_bwd(S['qkv'], d_att, bs, 65, 512, 2)
+        G[f'{L}.self_attn.in_proj_weight'], G[f'{L}.self_attn.in_proj_bias'] = _wgrad(S['x0'], dqkv), ops.colsum(dqkv)
+        d_x0 = ops.add_lrelu(d_s1, ops.linear(dqkv, T(P[f'{L}.self_attn.in_proj_weight'])))
+        if m0 is not None:
+            d_x0 = d_x0 * m0
+        dph, dpo, dge = ops.cross_tokens_bwd(d_x0.view(bs, 65, 512))
+        G['gravity_proj.weight'], G['gravity_proj.bias'] = _wgrad(S['emb'], dge)[:, :63].contiguous(), ops.colsum(dge)
+        out = {}
+        for key, st, dp, want in (('proj_hand', S['st_h'], dph, want_hand), ('proj_obj', S['st_o'], dpo, want_obj)):
+            G[f'{key}.weight'] = _unpack_grad(CB.conv2d_wgrad(st, dp, 3, 3, 1, 1), *self.shapes[key])
+            G[f'{key}.bias'] = CB.conv2d_bias_grad(dp)
+            out[key] = CB.conv2d_dgrad(dp, self.conv[key][0], (8, 8), 3, 3, 1, 1) if want else None
+        return out['proj_hand'], out['proj_obj'], G
+
+
+class PhysicsTrain:
+    """The physics branch of ``vpho_net.forward(mode='train')`` (lib/model/VPHO.py:164-172,205-212): gravity / CoM flips,
+    ``cross_hand(hand maps, obj maps.detach())`` -> hand tokens, ``cross_obj(hand maps.detach(), obj maps)`` -> object tokens,
+    ``HeadPhysics`` (fc_scale on the hand tokens, fc_weight / fc_CoM on the object tokens), ``from_local_to_global`` on the
+    ground-truth vertices and the five losses of ``get_loss``; backward down to the two stage maps."""
+    HEADS = ('fc_scale', 'fc_weight', 'fc_CoM')
+
+    def __init__(self, sd, agg, device, p_drop=0.0):
+        self.dev, self.agg = device, agg                     # agg: ops.Aggregation (ForceAnchor tables)
+        self.cross = dict(hand=CrossTrain(sd, 'cross_hand', device, p_drop), obj=CrossTrain(sd, 'cross_obj', device, p_drop))
+        g = lambda k: sd[f'head_physics.{k}'].detach().float().to(device).contiguous().clone()
+        self.p = {f'{h}.{i}.{s}': g(f'{h}.{i}.{s}') for h in self.HEADS for i in (0, 2) for s in ('weight', 'bias')}
+        self.anchor = g('anchor')
+
+    def params(self):
+        """{reference name: live tensor} of every trained tensor of the branch (conv weights: packed live + shape)"""
+        out = {}
+        for br, c in self.cross.items():
+            for k, v in c.p.items():
+                out[f'cross_{br}.{k}'] = v
+            for k, (w, b) in c.conv.items():
+                out[f'cross_{br}.{k}.bias'] = b
+        for k, v in self.p.items():
+            out[f'head_physics.{k}'] = v
+        return out
+
+    def forward_backward(self, st_h, st_o, gravity, obj_com, is_right, gt_vert, gt_force_local, is_grasped, weights):
+        """st_h, st_o (bs,8,8,256) NHWC second-stage maps of the two encoders; gravity, obj_com (bs,1,3) as in the batch (un-flipped);
+        gt_vert = gt_hand_vert_flip (bs,778,3); weights: (force, gravity, torque, supervised, CoM).
+        -> losses dict (weighted 0-d fp64), d st_h, d st_o, grads {reference name: tensor}, force_local (bs,32,3)"""
+        import torch
+        from .train_score import _wgrad
+        bs = st_h.shape[0]
+        left = (~is_right.bool()).to(torch.uint8).contiguous()
+        grav = gravity.float().reshape(bs, 3).contiguous()
+        emb = ops.nerf_embed(grav, left)                                               # flip_point3d_by_mask_index + PosEmbedder (VPHO.py:167)
+        sgn = torch.where(is_right.bool(), 1.0, -1.0).to(grav.dtype)[:, None]
+        flip = lambda t: torch.cat([t[:, :1] * sgn, t[:, 1:]], 1).contiguous()
+        grav_f, com_f = flip(grav), flip(obj_com.float().reshape(bs, 3))
+        tok_h = self.cross['hand'].forward(st_h, st_o, emb).view(bs, 65, 512)
+        tok_o = self.cross['obj'].forward(st_h, st_o, emb).view(bs, 65, 512)
+        xh = tok_h[:, :32].reshape(bs * 32, 512).contiguous()                           # enc_phy_hand
+        xo = tok_o[:, 32:64].reshape(bs * 32, 512).contiguous()                         # enc_phy_obj
+        P = self.p
+        hid = {h: ops.linear(x, P[f'{h}.0.weight'], P[f'{h}.0.bias'], out_slope=SLOPE) for h, x in (('fc_scale', xh), ('fc_weight', xo), ('fc_CoM', xo))}
+        pad4 = lambda w, b: (torch.cat([w, w.new_zeros(4 - w.shape[0] % 4 if w.shape[0] % 4 else 0, w.shape[1])], 0).contiguous(),
+                             torch.cat([b, b.new_zeros(4 - b.shape[0] % 4 if b.shape[0] % 4 else 0)], 0).contiguous())
+        outs = {}
+        for h in self.HEADS:
+            w, b = pad4(P[f'{h}.2.weight'], P[f'{h}.2.bias'])
+            outs[h] = ops.linear(hid[h], w, b)
+        scale_raw = outs['fc_scale'][:, :1].contiguous()
+        logits = outs['fc_weight'][:, :8].contiguous()
+        com = outs['fc_CoM'][:, :3].contiguous()
+        pts, frames = self.agg.anchor_frames(gt_vert.float().contiguous())
+        fl, losses, d_sc, d_lg, d_cm = ops.physics_loss(scale_raw, logits, com, self.anchor, frames, pts, gt_force_local.float().contiguous(),
+                                                        grav_f, com_f, is_grasped.to(torch.uint8).contiguous(), weights)
+        Lz = dict(zip(('force_loss', 'gravity_loss', 'torque_loss', 'supervised_loss', 'CoM_loss'), losses.unbind(0)))
+        # ---- backward: the three two-layer heads, then the two cross modules
+        G = {}
+        d_x = {}
+        for h, x, d_out, n_out in (('fc_scale', xh, d_sc, 1), ('fc_weight', xo, d_lg, 8), ('fc_CoM', xo, d_cm, 3)):
+            w, _ = pad4(P[f'{h}.2.weight'], P[f'{h}.2.bias'])
+            dpad = torch.cat([d_out, d_out.new_zeros(d_out.shape[0], w.shape[0] - n_out)], 1).contiguous()
+            G[f'head_physics.{h}.2.weight'] = _wgrad(hid[h], dpad)[:n_out].contiguous()
+            G[f'head_physics.{h}.2.bias'] = ops.colsum(dpad)[:n_out].contiguous()
+            dh = ops.lrelu_bwd(ops.linear(dpad, w.t().contiguous()), hid[h], SLOPE)
+            G[f'head_physics.{h}.0.weight'], G[f'head_physics.{h}.0.bias'] = _wgrad(x, dh), ops.colsum(dh)
+            d_x[h] = ops.linear(dh, P[f'{h}.0.weight'].t().contiguous())
+        d_tok_h = torch.zeros((bs, 65, 512), device=self.dev)
+        d_tok_h[:, :32] = d_x['fc_scale'].view(bs, 32, 512)
+        d_tok_o = torch.zeros((bs, 65, 512), device=self.dev)
+        d_tok_o[:, 32:64] = ops.add_lrelu(d_x['fc_weight'], d_x['fc_CoM']).view(bs, 32, 512)
+        d_sth, _, gh = self.cross['hand'].backward(d_tok_h.view(bs * 65, 512), want_hand=True, want_obj=False)       # VPHO.py:170: obj maps detached
+        _, d_sto, go = self.cross['obj'].backward(d_tok_o.view(bs * 65, 512), want_hand=False, want_obj=True)       # VPHO.py:171: hand maps detached
+        G.update({f'cross_hand.{k}': v for k, v in gh.items()})
+        G.update({f'cross_obj.{k}': v for k, v in go.items()})
+        return Lz, d_sth, d_sto, G, fl.view(bs, 32, 3), dict(tok_hand=tok_h[:, :32], tok_obj=tok_o[:, 32:64], com=com.view(bs, 32, 3), scale=scale_raw.view(bs, 32))
