@@ -46,6 +46,12 @@ class Config:
         self.weight_joint_loss = 1.0
         self.weight_mano_pose_loss = 1.0
         self.weight_mano_shape_loss = 1.0
+        self.weight_force_loss = 1.0
+        self.weight_gravity_loss = 1.0
+        self.weight_torque_loss = 1.0
+        self.weight_supervised_loss = 1.0
+        self.weight_CoM_loss = 1.0
+        self.cross_dropout = 0.1      # the reference's nn.TransformerEncoderLayer / PositionalEncoding default (cross_module.py:64,104-107)
 
 
 def _parser():
@@ -86,6 +92,12 @@ def _parser():
     p.add_argument('--weight_joint_loss', type=float, default=1e4)
     p.add_argument('--weight_mano_pose_loss', type=float, default=10)
     p.add_argument('--weight_mano_shape_loss', type=float, default=1.0)
+    p.add_argument('--weight_force_loss', type=float, default=1.0)
+    p.add_argument('--weight_gravity_loss', type=float, default=1.0)
+    p.add_argument('--weight_torque_loss', type=float, default=30.0)
+    p.add_argument('--weight_supervised_loss', type=float, default=10)
+    p.add_argument('--weight_CoM_loss', type=float, default=1e2)
+    p.add_argument('--cross_dropout', type=float, default=0.1)
     return p
 
 

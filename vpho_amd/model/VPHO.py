@@ -33,9 +33,98 @@ class vpho_net(nn.Module):
 
     def forward(self, data, mode='predict'):
         assert mode in ['train', 'score', 'sample', 'predict']
+        if mode == 'train':
+            return self._forward_train(data)
         if mode != 'predict':
-            raise NotImplementedError("vpho_amd implements the inference hot path (mode='predict') only")
+            # the reference asserts these two names and implements neither (VPHO.py:113,175,227: only 'train' / 'predict' branches)
+            raise NotImplementedError(f"mode='{mode}' has no implementation in the reference either (lib/model/VPHO.py:113-304)")
         from .engine import Engine
         if self._engine is None or self._engine.stale(self):
             self._engine = Engine(self)
         return self._engine.predict(data)
+
+    # ------------------------------------------------------------------------------------------------------------ training
+    def _forward_train(self, data):
+        """``forward(data, mode='train')`` (lib/model/VPHO.py:175-226): returns ``(loss_dt, pd_dt)`` -- the 13 weighted losses +
+        ``total_loss``, and reg_hand_vert / reg_hand_joint / hand_heatmap / obj_heatmap.  The whole step runs on the HIP kernels of
+        ``train_step.DiffusionTrainStep`` (forward AND analytic backward in one pass; there is no autograd graph over them).
+        ``loss_dt['total_loss']`` carries a one-node graph instead: ``total_loss.backward()`` / ``accel.backward(total_loss)``
+        (train_diff_hand_obj.py:180) deposits the gradients into ``.grad`` of this module's parameters, scaled by the incoming
+        gradient and accumulated like autograd does, so the reference's loop -- backward, clip, ``optimizer.step()`` -- works
+        unchanged with any torch optimiser.  Module parameters are re-packed into the kernels' layouts when they have changed;
+        BatchNorm running statistics are written back to the module's buffers.
+        Batch keys: those of predict + hm_hand, hm_obj, gt_mano (bs,58 axis-angle + betas), gt_obj (bs,9), gt_hand_vert_flip,
+        gt_hand_jt3d_flip, force_local, is_grasped, gravity, obj_CoM (lib/dataset/dexycb6.py:471-509).  ``data['_draws']`` (optional,
+        tests): fixed DSM draws instead of fresh ones from the device generator."""
+        from ..train_step import DiffusionTrainStep
+        from .engine import _signature
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise ops_error("vpho_net.forward(mode='train') runs on the GPU only: move the module with .to('cuda')")
+        ts = getattr(self, '_train_step', None)
+        sig = _signature(self)
+        with torch.no_grad():
+            if ts is None:
+                # cloned: the step's master copies must not alias this module's parameters (an external optimiser owns those)
+                ts = DiffusionTrainStep({k: v.detach().clone() for k, v in self.state_dict().items()}, dev, assets=self.assets)
+                object.__setattr__(self, '_train_step', ts)
+            elif sig != self._train_sig:
+                ts.load_params(self.state_dict())
+            gt_hand = data['gt_hand6d'] if 'gt_hand6d' in data else _aa_to_rot6d(data['gt_mano'][:, :48].float())
+            bs = data['rgb'].shape[0]
+            draws = data.get('_draws')
+            if draws is None:
+                eps, reps = 1e-5, cfg.repeat_num
+                u = lambda: torch.rand(reps, bs, device=dev) * (1. - eps) + eps
+                draws = dict(t_h=u(), z_h=torch.randn(reps, bs, 96, device=dev), t_o=u(), z_o=torch.randn(reps, bs, 9, device=dev))
+            losses, grads, pd_dt = ts.loss_and_grads(data, gt_hand, data['gt_obj'].float(), draws, want_outputs=True)
+            # running statistics live in the step's own buffers: mirror them into the module (nn.BatchNorm2d updates them in forward)
+            own = dict(self.named_buffers())
+            for k, v in ts.state_dict().items():
+                if k.endswith(('running_mean', 'running_var')) and k in own:
+                    own[k].copy_(v)
+        object.__setattr__(self, '_train_sig', _signature(self))
+        params = dict(self.named_parameters())
+        names = [k for k in grads if k in params]
+        total = _DepositGrads.apply(torch.zeros((), device=dev, requires_grad=True), losses['total_loss'].detach().float(),
+                                    [params[k] for k in names], [grads[k] for k in names])
+        loss_dt = {k: v.detach().float() for k, v in losses.items()}
+        loss_dt['total_loss'] = total
+        return loss_dt, pd_dt
+
+
+def _aa_to_rot6d(aa):
+    """mano_aa_to_6D(gt_mano)[..., :96] (lib/model/head_mano.py:10-18): pytorch3d's axis_angle_to_matrix (through the quaternion, with
+    its small-angle branch) and matrix_to_rotation_6d (first two rows) -- ground-truth preprocessing, plain tensor arithmetic"""
+    a = aa.reshape(-1, 3)
+    ang = a.norm(dim=-1, keepdim=True)
+    half = 0.5 * ang
+    small = ang.abs() < 1e-6
+    s = torch.where(small, 0.5 - ang * ang / 48, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    q = torch.cat([torch.cos(half), a * s], -1)
+    r, i, j, k = q.unbind(-1)
+    two_s = 2.0 / (q * q).sum(-1)
+    rows = [1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+            two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r)]
+    return torch.stack(rows, -1).reshape(aa.shape[0], -1).contiguous()
+
+
+def ops_error(msg):
+    from .. import ops
+    return ops.VphoError(msg)
+
+
+class _DepositGrads(torch.autograd.Function):
+    """total_loss with a backward that writes the step's analytic gradients into ``.grad`` of the module's parameters"""
+
+    @staticmethod
+    def forward(ctx, anchor, value, params, grads):
+        ctx.params, ctx.grads = params, grads
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        for p, gr in zip(ctx.params, ctx.grads):
+            gr = gr.reshape(p.shape).to(p.dtype) * g
+            p.grad = gr.clone() if p.grad is None else p.grad + gr
+        return None, None, None, None

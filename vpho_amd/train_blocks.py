@@ -367,6 +367,7 @@ class HeadManoTrain:
         g = lambda k: sd[f'{prefix}.{k}'].detach().float().to(device).contiguous().clone()
         self.p = {f'{n}.{s}': g(f'{n}.{s}') for n in self.NAMES for s in ('weight', 'bias')}
         self._pad = torch.zeros((2, self.p['fc_pose.weight'].shape[1]), device=device)
+        self.last_outputs = None                         # (verts, joints) of the last forward (pd_dt of VPHO.py:221-222)
 
     def forward_backward(self, x, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights):
         """x (bs,1024) encoding.  -> losses dict (weighted, 0-d fp64), d loss / d x (bs,1024), grads"""
@@ -379,7 +380,8 @@ class HeadManoTrain:
         bcat = torch.cat([P['fc_pose.bias'], P['fc_shape.bias'], self._pad[:, 0]], 0).contiguous()
         out = ops.linear(h2, wcat, bcat)
         rot6d, shape = out[:, :96].contiguous(), out[:, 96:106].contiguous()
-        L, d6, ds = self.mano.train(rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights)
+        L, d6, ds, v_, j_ = self.mano.train(rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, want_outputs=True)
+        self.last_outputs = (v_, j_)
         dout = torch.cat([d6, ds, torch.zeros_like(d6[:, :2])], 1).contiguous()                               # (bs, 108)
         G = {}
         dw = _wgrad(h2, dout)

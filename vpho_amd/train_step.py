@@ -1,13 +1,14 @@
-"""End-to-end training step for the diffusion and heat-map losses: ``vpho_net.forward(mode='train')``
-restricted to ``diff_hand_loss + diff_obj_loss + hm_hand_loss + hm_obj_loss`` (lib/model/VPHO.py:115-150,175-195,214-220) with
-every module on the path in training mode, ``loss.backward()`` through score networks -> encoders -> heat-map heads /
-re-alignment -> RoIAlign -> the two-branch backbone, data-parallel gradient averaging and AdamW
+"""End-to-end training step: ``vpho_net.forward(mode='train')`` (lib/model/VPHO.py:115-226) with every module
+in training mode and ``loss.backward()`` through all of it, data-parallel gradient averaging and AdamW
 (lib/engine/train_diff_hand_obj.py:49-52,169-199).
 
-With the MANO tables (``assets``) and the hand ground truth in the batch the step also carries ``head_mano`` and the four MANO
-losses (vert / joint / mano_pose / mano_shape, lib/model/head_mano.py:89-133).  Not part of this step: the physics losses and the
-modules only they reach (cross modules, ``head_physics``).  ``cfg.gradient_clip`` > 0 clips the global gradient norm (off by default,
-as in the reference).
+Losses (all 13 of VPHO.py:190-212, weighted as :214-219): ``diff_hand`` / ``diff_obj`` (DSM draws through the score networks),
+``hm_hand`` / ``hm_obj`` (heat-map heads), ``vert`` / ``joint`` / ``mano_pose`` / ``mano_shape`` (``head_mano`` + MANO layer; need the
+MANO tables in ``assets`` and the hand ground truth in the batch) and ``force`` / ``gravity`` / ``torque`` / ``supervised`` / ``CoM``
+(cross modules + ``head_physics``; need the anchor tables in ``assets`` and gravity / obj_CoM / force_local / is_grasped in the batch).
+Backward: score networks -> encoders (at the encoding AND, from the physics branch, at the second stage map) -> resize /
+re-alignment / heat-map heads -> RoIAlign -> the two-branch backbone.  ``cfg.gradient_clip`` > 0 clips the global gradient norm
+(off by default, as in the reference).
 Composition of ``train_blocks`` / ``train_score``; torch allocates, slices and, under ``torch.distributed``, all-reduces ONE
 flat gradient buffer (RCCL under backend 'nccl').
 """
@@ -17,12 +18,13 @@ import torch.distributed as dist
 from . import ops
 from .configs.args import cfg
 from .model.pack import pack_conv, pack_deconv4x4s2
-from .train_blocks import FPNTrain, EncoderTrain, HeatmapHeadTrain, HeadManoTrain
+from .train_blocks import FPNTrain, EncoderTrain, HeatmapHeadTrain, HeadManoTrain, PhysicsTrain
 from .train_score import ScoreTrainer, SUFFIXES
 
 
 class DiffusionTrainStep:
-    def __init__(self, state_dict, device, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, loss_weights=None, assets=None):
+    def __init__(self, state_dict, device, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, loss_weights=None, assets=None,
+                 cross_dropout=None):
         self.dev = torch.device(device)
         sd = state_dict
         lr = cfg.base_learning_rate if lr is None else lr
@@ -33,7 +35,15 @@ class DiffusionTrainStep:
                           o=ScoreTrainer(sd, 'denoiser_obj', self.dev, lr, betas, eps, weight_decay))
         # MANO losses (head_mano + the MANO layer) need the MANO tables: enabled when `assets` is given
         self.mano_head = HeadManoTrain(sd, 'head_mano', ops.Mano(assets['mano'], self.dev), self.dev) if assets is not None else None
-        self.w = dict(diff_hand=cfg.weight_diff_hand_loss, diff_obj=cfg.weight_diff_obj_loss, hm_hand=cfg.weight_hm_hand_loss,
+        # physics losses (cross modules + head_physics) need the CPF anchor tables
+        self.phys = None
+        if assets is not None and 'anchor' in assets and 'cross_hand.proj_hand.weight' in sd:
+            from .assets import ANCHOR_SKELETON
+            self.phys = PhysicsTrain(sd, ops.Aggregation(assets, ANCHOR_SKELETON, self.dev), self.dev,
+                                     cfg.cross_dropout if cross_dropout is None else cross_dropout)
+        self.w = dict(force=cfg.weight_force_loss, gravity=cfg.weight_gravity_loss, torque=cfg.weight_torque_loss,
+                      supervised=cfg.weight_supervised_loss, CoM=cfg.weight_CoM_loss)
+        self.w.update(diff_hand=cfg.weight_diff_hand_loss, diff_obj=cfg.weight_diff_obj_loss, hm_hand=cfg.weight_hm_hand_loss,
                       hm_obj=cfg.weight_hm_obj_loss, vert=cfg.weight_vert_loss, joint=cfg.weight_joint_loss, mano_pose=cfg.weight_mano_pose_loss,
                       mano_shape=cfg.weight_mano_shape_loss)
         self.w.update(loss_weights or {})
@@ -114,6 +124,15 @@ class DiffusionTrainStep:
         if self.mano_head is not None:
             for k, v in self.mano_head.p.items():
                 vec(f'head_mano.{k}', v)
+        if self.phys is not None:
+            for br, c in self.phys.cross.items():
+                for k, v in c.p.items():
+                    vec(f'cross_{br}.{k}', v)
+                for k, (wp, b) in c.conv.items():
+                    conv(f'cross_{br}.{k}.weight', wp, c.shapes[k])
+                    vec(f'cross_{br}.{k}.bias', b)
+            for k, v in self.phys.p.items():
+                vec(f'head_physics.{k}', v)
         self.names = sorted(self.master)
         sizes = [self.master[k].numel() for k in self.names]
         self.flat_grad = torch.zeros(sum(sizes), device=self.dev)
@@ -126,7 +145,7 @@ class DiffusionTrainStep:
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def loss_and_grads(self, data, gt_hand, gt_obj, draws):
+    def loss_and_grads(self, data, gt_hand, gt_obj, draws, want_outputs=False):
         """data: the batch dict of ``vpho_net`` (device tensors: rgb, bbox_hand, bbox_obj, bbox_hand_rect, bbox_obj_rect, is_right,
         hm_hand (bs,21,64,64), hm_obj (bs,27,64,64)); gt_hand (bs,96) = mano_aa_to_6D(gt_mano), gt_obj (bs,9); draws: dict t_h, z_h,
         t_o, z_o (reps,bs[,D]).  -> losses {name: 0-d fp64 tensor, weighted}, grads {reference parameter name: gradient}."""
@@ -149,8 +168,8 @@ class DiffusionTrainStep:
             hm_o = self.hm['o'].forward(of_or)
             ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_h, bb_h, bb_hr), R, R, out=in_h, c_off=256)
             ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_o, bb_o, bb_or, flip_w=left), R, R, out=in_o, c_off=256)
-            enc_h, _ = eh.forward(in_h)
-            enc_o, _ = eo.forward(in_o)
+            enc_h, st_h = eh.forward(in_h)
+            enc_o, st_o = eo.forward(in_o)
             # ---- losses (VPHO.py:190-195,214-220) and their gradients at the encodings / heat maps
             L = {}
             L['diff_hand_loss'], d_enc_h = self.score['h']._loss_and_grads(enc_h, f32(gt_hand), f32(draws['t_h']), f32(draws['z_h']))
@@ -168,6 +187,15 @@ class DiffusionTrainStep:
                     enc_h, f32(data['gt_hand_vert_flip']), f32(data['gt_hand_jt3d_flip']), f32(gt_hand), f32(data['gt_mano'][:, 48:]),
                     data['is_right'].to(torch.uint8).contiguous(), (self.w['vert'], self.w['joint'], self.w['mano_pose'], self.w['mano_shape']))
                 L.update(Lm)
+            # physics branch (VPHO.py:164-172,205-212): cross modules on the encoders' second stage maps (8x8), head_physics, 5 losses
+            d_stage = dict(h=None, o=None)
+            gp = None
+            if self.phys is not None and 'force_local' in data and 'gt_hand_vert_flip' in data:
+                Lp, d_stage['h'], d_stage['o'], gp, _, _ = self.phys.forward_backward(
+                    st_h[1], st_o[1], f32(data['gravity']), f32(data['obj_CoM']), data['is_right'], f32(data['gt_hand_vert_flip']),
+                    f32(data['force_local']), data['is_grasped'],
+                    (self.w['force'], self.w['gravity'], self.w['torque'], self.w['supervised'], self.w['CoM']))
+                L.update(Lp)
             # ---- backward
             G = {}
             dfeat = {}
@@ -178,7 +206,7 @@ class DiffusionTrainStep:
                     d_enc = d_enc * w_diff
                 if br == 'h' and d_enc_mano is not None:
                     d_enc = ops.add_lrelu(d_enc, d_enc_mano)
-                d_in, g = enc.backward(d_enc)
+                d_in, g = enc.backward(d_enc, d_stage1=d_stage[br])
                 G.update({f'encoder_{long_}.{k}': v for k, v in g.items()})
                 nj = enc.cin - 256
                 # feature channels of the encoder input: RoIAlign of the rectangular box (W-flipped for the object branch)
@@ -194,8 +222,49 @@ class DiffusionTrainStep:
                 G.update({f'{tr.prefix}.{s}': (tr.grads[s] if w_diff == 1.0 else tr.grads[s] * w_diff) for s in SUFFIXES})
             if d_enc_mano is not None:
                 G.update({f'head_mano.{k}': v for k, v in gm.items()})
+            if gp is not None:
+                G.update(gp)
             L['total_loss'] = sum(L.values())
+            if want_outputs:                                   # pd_dt of VPHO.py:221-225
+                pd = dict(hand_heatmap=ops.nhwc_to_nchw(hm_h), obj_heatmap=ops.nhwc_to_nchw(hm_o))
+                if self.mano_head is not None and self.mano_head.last_outputs is not None:
+                    pd['reg_hand_vert'], pd['reg_hand_joint'] = self.mano_head.last_outputs
+                return L, G, pd
         return L, G
+
+    @torch.no_grad()
+    def load_params(self, state_dict):
+        """refresh every trained tensor (masters + the kernels' packed copies) and the BatchNorm running statistics from a state_dict
+        in the reference's layout -- used by vpho_net.forward(mode='train') when an external optimiser has updated the module"""
+        for k in self.names:
+            self.master[k].copy_(state_dict[k].to(self.dev).reshape(self.master[k].shape))
+            if self._repack[k] is not None:
+                self._repack[k](self.master[k])
+        for k, v in self._running_stats().items():
+            v.copy_(state_dict[k].to(self.dev))
+
+    def _running_stats(self):
+        """{reference name: live running_mean / running_var tensor}"""
+        out = {}
+
+        def bn(name, p):
+            out[name + '.running_mean'], out[name + '.running_var'] = p['running_mean'], p['running_var']
+
+        f = self.fpn
+        bn('feature_extractor.layer0_h.1', f.stem['bn'])
+        for blks in f.blocks.values():
+            for k, p, _ in blks:
+                for b, nm in (('bn1', 'bn1'), ('bn2', 'bn2'), ('bn3', 'bn3'), ('bnd', 'downsample.1')):
+                    if b in p:
+                        bn(f'feature_extractor.{k}.{nm}', p[b])
+        for br, mod in (('hand', self.hm['h']), ('obj', self.hm['o'])):
+            bn(f'head_hm_{br}.conv_layers.2', mod.bn1)
+            bn(f'head_hm_{br}.deconv_layers.1', mod.bn2)
+        for br, mod in (('hand', self.enc['h']), ('obj', self.enc['o'])):
+            for k, p in mod.blocks:
+                for b in ('bn', 'bn1', 'bn2'):
+                    bn(f'encoder_{br}.{k}.{b}', p[b])
+        return out
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -93,9 +93,9 @@ class Trainer:
         return gt_hand, gt_obj, g
 
     def run_full(self, n_batches=None):
-        """End-to-end training on the diffusion + heat-map losses over synthetic batches (train_diff_hand_obj.py:169-199 with the
-        loss restricted to diff_hand + diff_obj + hm_hand + hm_obj, see train_step.DiffusionTrainStep): backbone, heat-map heads,
-        encoders and score networks are all updated.  Returns the per-batch loss dicts (floats)."""
+        """End-to-end training over synthetic batches (train_diff_hand_obj.py:169-199) with all 13 losses of VPHO.py:190-212
+        (train_step.DiffusionTrainStep): backbone, heat-map heads, encoders, score networks, head_mano, both cross modules and
+        head_physics are updated.  Returns the per-batch loss dicts (floats)."""
         from .train_step import DiffusionTrainStep
         cfg, bs = self.cfg, self.cfg.batch_size
         n_batches = cfg.num_batches if n_batches is None else n_batches
@@ -108,6 +108,7 @@ class Trainer:
             batch['hm_hand'] = (torch.rand(bs, 21, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
             batch['hm_obj'] = (torch.rand(bs, 27, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
             batch.update(synthetic_mano_targets(step.mano_head.mano, gt_hand, (torch.randn(bs, 10, generator=g) * 0.5).to(self.device), batch['is_right']))
+            batch['force_local'] = (torch.randn(bs, 32, 3, generator=g) * 0.1).to(self.device)      # pseudo-force labels (force_optim.py's output)
             L = step.step(batch, gt_hand, gt_obj)
             hist.append({k: float(v) for k, v in L.items()})
             if self.rank == 0 and i % max(1, getattr(cfg, 'print_freq', 10)) == 0:
