@@ -132,3 +132,77 @@ def test_score_training_gradient_average_world2_gloo():
     for rank, scale, err, mag in got:
         assert scale == 0.5
         assert err <= 2e-6 * mag + 1e-9, (rank, err, mag)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bucketed gradient exchange of the training step (vpho_amd/grad_buckets.py), world 2 on gloo
+_SHAPES = {'denoiser_hand.head.head.0.weight': (4, 7, 5), 'head_mano.fc_pose.bias': (6,), 'cross_obj.gravity_proj.weight': (3, 5),
+           'head_physics.fc_CoM.2.bias': (3,), 'encoder_hand.reg.0.conv1.weight': (4, 4, 1, 1), 'head_hm_hand.final_layer.bias': (5,),
+           'encoder_obj.project.weight': (4, 6, 1, 1), 'head_hm_obj.deconv_layers.0.weight': (3, 2, 4, 4),
+           'feature_extractor.smooth3_h.weight': (2, 2, 3, 3), 'feature_extractor.latlayer1_o.bias': (2,),
+           'feature_extractor.layer4_h.0.0.conv1.weight': (8, 4, 1, 1), 'feature_extractor.layer2_o.0.1.bn2.weight': (4,),
+           'feature_extractor.layer1_h.0.0.conv2.weight': (2, 2, 3, 3), 'feature_extractor.layer0_h.0.weight': (2, 3, 7, 7),
+           'feature_extractor.layer0_h.1.bias': (2,)}
+_NEVER = 'head_hm_obj.deconv_layers.0.weight'            # no loss reaches it on this "batch": keeps a zero gradient
+
+
+def _grad(name, rank, step):
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(f'{name}|{rank}|{step}'.encode()))       # not hash(): str hashes differ per process
+    return torch.randn(_SHAPES[name], generator=g)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vpho_amd.grad_buckets import GradBuckets, BUCKETS, bucket_of
+    B = GradBuckets(_SHAPES, 'cpu')
+    params = {k: torch.zeros(s) for k, s in _SHAPES.items()}
+    trace = []
+    for step in range(3):
+        B.begin()
+        for b in BUCKETS:                                 # the backward's milestone order; the last milestone is left to finish()
+            B.put({k: _grad(k, rank, step) for k in _SHAPES if bucket_of(k) == b and k != _NEVER})
+            if b != 'fpn_end':
+                B.flush(b)
+        scale = B.finish()
+        for k in B.names:
+            params[k] -= 0.1 * scale * B.view[k]
+        trace.append(B.flat.clone())
+    q.put((rank, params, trace, B.names, dict(B.range)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_world2_gloo():
+    """three steps on two ranks with different gradients: every bucket's asynchronous all-reduce delivers the SAME sums to both
+    ranks (replicas bit-identical), equal to the sum of the two ranks' gradients; a tensor no loss reached stays at zero; the flat
+    buffer is laid out in the backward's milestone order"""
+    from vpho_amd.grad_buckets import BUCKETS, bucket_of
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, params, trace, names, rng = q.get(timeout=180)
+        got[r] = (params, trace, names, rng)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (p0, t0, names, rng), (p1, t1, _, _) = got[0], got[1]
+    order = [bucket_of(k) for k in names]
+    assert order == sorted(order, key=BUCKETS.index)                       # buckets are contiguous and in milestone order
+    assert [b for b in BUCKETS if b in rng] == list(BUCKETS) and all(rng[a][1] == rng[b][0] for a, b in zip(BUCKETS[:-1], BUCKETS[1:]))
+    for step in range(3):
+        assert torch.equal(t0[step], t1[step])                              # identical reduced gradients on both ranks
+    for k in _SHAPES:
+        assert torch.equal(p0[k], p1[k]), k                                 # replicas stay bit-identical
+        want = torch.zeros(_SHAPES[k])
+        for step in range(3):
+            if k != _NEVER:
+                want -= 0.1 * 0.5 * (_grad(k, 0, step) + _grad(k, 1, step))
+        assert torch.allclose(p0[k], want, atol=1e-6), k
+    assert float(p0[_NEVER].abs().max()) == 0.0

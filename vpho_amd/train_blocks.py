@@ -160,8 +160,16 @@ class FPNTrain:
                 grads[key] = grads[key] + val if key in grads else val    # layer4 is called twice: its gradients add up
         return dy
 
-    def backward(self, dp2_h, dp2_o):
+    def backward(self, dp2_h, dp2_o, on_ready=None):
+        """on_ready(part, milestone): called with the gradients that have become final at 'fpn_top' (smoothing / lateral / top layers),
+        'fpn_mid' (layers 4-2 of both branches) and 'fpn_end' (layer1 + stem) -- grad_buckets.py"""
         S, grads = self.saved, {}
+        reported = set()
+
+        def report(milestone):
+            if on_ready is not None:
+                on_ready({k: v for k, v in grads.items() if k not in reported}, milestone)
+                reported.update(grads)
         add = lambda a, b_: b_ if a is None else ops.add_lrelu(a, b_)
         dfe = dict(h=[None] * 3, o=[None] * 3)                            # gradients reaching c5, c4, c3 of each branch
         dc2 = None
@@ -186,15 +194,18 @@ class FPNTrain:
             grads[f'toplayer_{br}.weight'] = _unpack_grad(CB.conv2d_wgrad(c5, d, 1, 1), *self.shapes[f'toplayer_{br}.weight'])
             grads[f'toplayer_{br}.bias'] = CB.conv2d_bias_grad(d)
             dfe[br][0] = add(dfe[br][0], CB.conv2d_dgrad(d, wt, c5.shape[1:3], 1, 1))
+        report('fpn_top')
         # bottom-up path in reverse
         for br in 'ho':
             d4 = add(dfe[br][1], self._back_layer('layer4_h', br, dfe[br][0], grads))
             d3 = add(dfe[br][2], self._back_layer(f'layer3_{br}', br, d4, grads))
             dc2 = add(dc2, self._back_layer(f'layer2_{br}', br, d3, grads))
+        report('fpn_mid')                                   # layer4_h's gradients are the sums over both branches: final only now
         dc1 = self._back_layer('layer1_h', 'h', dc2, grads)
         da0 = ops.lrelu_bwd(ops.maxpool_bwd(S['a0'], dc1, 3, 2, 1), S['a0'], SLOPE)
         dc0, grads['layer0_h.1.weight'], grads['layer0_h.1.bias'] = ops.bn_train_backward(S['c0'], da0, self.stem['bn']['gamma'], S['s0'])
         grads['layer0_h.0.weight'] = _unpack_grad(CB.conv2d_wgrad(S['x'], dc0, 7, 7, 2, 3), *self.shapes['layer0_h.0.weight'])
+        report('fpn_end')
         return grads
 
 

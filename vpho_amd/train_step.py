@@ -133,22 +133,23 @@ class DiffusionTrainStep:
                     vec(f'cross_{br}.{k}.bias', b)
             for k, v in self.phys.p.items():
                 vec(f'head_physics.{k}', v)
-        self.names = sorted(self.master)
-        sizes = [self.master[k].numel() for k in self.names]
-        self.flat_grad = torch.zeros(sum(sizes), device=self.dev)
-        self.grad_view, off = {}, 0
-        for k, n in zip(self.names, sizes):
-            self.grad_view[k] = self.flat_grad[off:off + n].view(self.master[k].shape)
-            off += n
+        # ONE flat gradient buffer, laid out in the order in which the backward finishes the modules and cut into buckets whose
+        # all-reduce overlaps the rest of the backward (grad_buckets.py)
+        from .grad_buckets import GradBuckets
+        self.buckets = GradBuckets({k: tuple(v.shape) for k, v in self.master.items()}, self.dev)
+        self.names = self.buckets.names
+        self.flat_grad, self.grad_view = self.buckets.flat, self.buckets.view
         self.m = {k: torch.zeros_like(v) for k, v in self.master.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.master.items()}
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def loss_and_grads(self, data, gt_hand, gt_obj, draws, want_outputs=False):
+    def loss_and_grads(self, data, gt_hand, gt_obj, draws, want_outputs=False, sink=None):
         """data: the batch dict of ``vpho_net`` (device tensors: rgb, bbox_hand, bbox_obj, bbox_hand_rect, bbox_obj_rect, is_right,
         hm_hand (bs,21,64,64), hm_obj (bs,27,64,64)); gt_hand (bs,96) = mano_aa_to_6D(gt_mano), gt_obj (bs,9); draws: dict t_h, z_h,
-        t_o, z_o (reps,bs[,D]).  -> losses {name: 0-d fp64 tensor, weighted}, grads {reference parameter name: gradient}."""
+        t_o, z_o (reps,bs[,D]).  -> losses {name: 0-d fp64 tensor, weighted}, grads {reference parameter name: gradient}.
+        ``sink`` (grad_buckets.GradBuckets): gradients are handed over as soon as they are final and each milestone is flushed, so that
+        the bucket's all-reduce runs under the remaining backward."""
         R, HM = cfg.roi_size, cfg.heatmap_size
         f32 = lambda t: t.float().contiguous()
         bb_h, bb_o, bb_hr, bb_or = (f32(data[k]) for k in ('bbox_hand', 'bbox_obj', 'bbox_hand_rect', 'bbox_obj_rect'))
@@ -199,6 +200,15 @@ class DiffusionTrainStep:
             # ---- backward
             G = {}
             dfeat = {}
+            for tr, w_diff in ((self.score['h'], self.w['diff_hand']), (self.score['o'], self.w['diff_obj'])):
+                G.update({f'{tr.prefix}.{s}': (tr.grads[s] if w_diff == 1.0 else tr.grads[s] * w_diff) for s in SUFFIXES})
+            if d_enc_mano is not None:
+                G.update({f'head_mano.{k}': v for k, v in gm.items()})
+            if gp is not None:
+                G.update(gp)
+            if sink is not None:
+                sink.put(G)
+                sink.flush('heads')
             for br, long_, enc, head, d_enc, d_hm_loss, w_diff, box_rect, box_head, box_tight, flip in (
                     ('h', 'hand', eh, self.hm['h'], d_enc_h, d_hm_h, self.w['diff_hand'], bb_hr, bb_h, bb_h, None),
                     ('o', 'obj', eo, self.hm['o'], d_enc_o, d_hm_o, self.w['diff_obj'], bb_or, bb_or, bb_o, left)):
@@ -217,13 +227,16 @@ class DiffusionTrainStep:
                 d_head_in, gh = head.backward(d_hm)
                 G.update({f'head_hm_{long_}.{k}': v for k, v in gh.items()})
                 dfeat[br] = ops.roi_align_bwd(d_head_in, box_head, (H, W), 256, 0.25, into=df)
-            G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o']).items()})
-            for tr, w_diff in ((self.score['h'], self.w['diff_hand']), (self.score['o'], self.w['diff_obj'])):
-                G.update({f'{tr.prefix}.{s}': (tr.grads[s] if w_diff == 1.0 else tr.grads[s] * w_diff) for s in SUFFIXES})
-            if d_enc_mano is not None:
-                G.update({f'head_mano.{k}': v for k, v in gm.items()})
-            if gp is not None:
-                G.update(gp)
+                if sink is not None:
+                    sink.put({f'encoder_{long_}.{k}': v for k, v in g.items()})
+                    sink.put({f'head_hm_{long_}.{k}': v for k, v in gh.items()})
+                    sink.flush('branch_hand' if br == 'h' else 'branch_obj')
+
+            def fpn_ready(part, milestone):                    # FPNTrain.backward reports its three milestones
+                if sink is not None:
+                    sink.put({f'feature_extractor.{k}': v for k, v in part.items()})
+                    sink.flush(milestone)
+            G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o'], on_ready=fpn_ready).items()})
             L['total_loss'] = sum(L.values())
             if want_outputs:                                   # pd_dt of VPHO.py:221-225
                 pd = dict(hand_heatmap=ops.nhwc_to_nchw(hm_h), obj_heatmap=ops.nhwc_to_nchw(hm_o))
@@ -269,31 +282,20 @@ class DiffusionTrainStep:
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, data, gt_hand, gt_obj, draws=None, repeat_num=None, eps=1e-5, lr=None, gradient_clip=None):
-        """loss_and_grads + gradient average over the ranks (one all-reduce of the flat buffer) + AdamW on every tensor.
+        """loss_and_grads + gradient average over the ranks (bucketed all-reduces issued DURING the backward, grad_buckets.py) + AdamW on
+        every tensor.
         Without `draws` they are made like loss_fn's (torch.rand / torch.randn on the device, score_based_model.py:24,31)."""
         bs = data['rgb'].shape[0]
         reps = cfg.repeat_num if repeat_num is None else repeat_num
         if draws is None:
             u = lambda: torch.rand(reps, bs, device=self.dev) * (1. - eps) + eps
             draws = dict(t_h=u(), z_h=torch.randn(reps, bs, 96, device=self.dev), t_o=u(), z_o=torch.randn(reps, bs, 9, device=self.dev))
-        losses, grads = self.loss_and_grads(data, gt_hand, gt_obj, draws)
+        self.buckets.begin()
+        losses, grads = self.loss_and_grads(data, gt_hand, gt_obj, draws, sink=self.buckets)
         unknown = set(grads) - set(self.names)
         assert not unknown, sorted(unknown)[:5]
         live = [k for k in self.names if k in grads]             # tensors no loss of this batch reached keep their value (grad None)
-        for k in self.names:
-            if k in grads:
-                self.grad_view[k].copy_(grads[k])
-            else:
-                self.grad_view[k].zero_()
-        scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == 'gloo' and self.flat_grad.is_cuda:      # CPU rehearsal backend: stage through host memory
-                host = self.flat_grad.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                self.flat_grad.copy_(host)
-            else:
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            scale = 1.0 / dist.get_world_size()
+        scale = self.buckets.finish()                            # waits for the bucket exchanges still in flight
         clip = cfg.gradient_clip if gradient_clip is None else gradient_clip
         if clip > 0:                                       # accel.clip_grad_norm_ (train_diff_hand_obj.py:182-183): global L2 norm of the averaged gradients
             if scale != 1.0:
