@@ -169,7 +169,8 @@ def _bucket_worker(rank, world, port, q):
         for k in B.names:
             params[k] -= 0.1 * scale * B.view[k]
         trace.append(B.flat.clone())
-    q.put((rank, params, trace, B.names, dict(B.range)))
+    # numpy payloads: torch tensors travel through the queue as shared-memory handles that die with this process
+    q.put((rank, {k: v.numpy().copy() for k, v in params.items()}, [t.numpy().copy() for t in trace], B.names, dict(B.range)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -188,7 +189,7 @@ def test_bucketed_gradient_exchange_world2_gloo():
     got = {}
     for _ in range(2):
         r, params, trace, names, rng = q.get(timeout=180)
-        got[r] = (params, trace, names, rng)
+        got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, [torch.from_numpy(t) for t in trace], names, rng)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
