@@ -4,10 +4,10 @@
     python train.py --steps 10 [--bs 64 --repeat_num 20]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P train.py --gpus N
 
-One step = the reference's ``accel.backward(loss) + optimizer.step()`` (lib/engine/train_diff_hand_obj.py:169-199) with the loss
-restricted to diff_hand + diff_obj + hm_hand + hm_obj + the four MANO losses (lib/model/VPHO.py:190-204): training-mode two-branch
-ResNet-50/FPN, RoIAlign, heat-map heads and re-alignment, the two encoders, repeat_num DSM draws per score network, head_mano +
-MANO layer, the whole backward, one all-reduce of the flat gradient buffer (RCCL) under data parallelism, AdamW on all 521 tensors.  One JSON line on rank 0.
+One step = the reference's ``accel.backward(loss) + optimizer.step()`` (lib/engine/train_diff_hand_obj.py:169-199) with all 13 losses
+of lib/model/VPHO.py:190-212: training-mode two-branch ResNet-50/FPN, RoIAlign, heat-map heads and re-alignment, the two encoders,
+repeat_num DSM draws per score network, head_mano + MANO layer, both cross modules + head_physics, the whole backward, bucketed
+all-reduces of the flat gradient buffer (RCCL) overlapped with it under data parallelism, AdamW on all 569 tensors.  One JSON line on rank 0.
 """
 import argparse
 import json
@@ -67,6 +67,7 @@ def main():
     gt_o = (torch.randn(bs, 9, generator=g) * 0.5).to(dev)
     from vpho_amd.trainer import synthetic_mano_targets
     data.update(synthetic_mano_targets(step.mano_head.mano, gt_h, (torch.randn(bs, 10, generator=g) * 0.5).to(dev), data['is_right']))
+    data['force_local'] = (torch.randn(bs, 32, 3, generator=g) * 0.1).to(dev)          # pseudo-force labels: the physics losses are part of the step
 
     first = None
     for _ in range(args.warmup):
@@ -82,7 +83,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    res = {'metric': 'end-to-end training images/s (diffusion + heat-map + MANO losses, all modules on the path trained)',
+    res = {'metric': 'end-to-end training images/s (all 13 losses of vpho_net.forward(mode=train), every module trained)',
            'value': world * args.steps * bs / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
            'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
            'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),
