@@ -22,7 +22,7 @@ def load(path):
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 out = {}
 print(f"{'kernel':48s} {'launches':>8s} {'FETCH KB/launch':>16s} {'WRITE KB/launch':>16s} {'HBM MB/launch (2*F+W)':>22s}")
-for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]))[:25]:
+for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0])[1]))[:60]:
     n, fv = fetch[k]
     nw, wv = write.get(k, [1, 0.0])
     hbm = (2 * fv / n + wv / max(nw, 1)) * 1024
