@@ -48,3 +48,25 @@ def test_mano_fk_batched_matches_oracle(assets, n_img, per_img):
     np.testing.assert_allclose(verts.cpu()[pick].numpy(), np.asarray(rv), atol=2e-6)
     np.testing.assert_allclose(joints.cpu()[pick].numpy(), np.asarray(rj), atol=2e-6)
     assert torch.equal(joints, joints_only)
+
+
+@pytest.mark.parametrize('n,F,k', [(5, 1, 5), (200, 5, 30), (512, 1, 30), (513, 5, 64), (1024, 1, 30)])
+def test_wavefront_topk_matches_a_stable_descending_sort(assets, n, F, k):
+    """vpho_topk_f32 (wavefront butterfly arg-max; 8 value slots per lane up to 512 candidates, 16 up to 1024): values descending, ties
+    by ascending index (torch.topk leaves that order open; the oracle defines it the same way), NaN first, -inf never picked twice."""
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    g = torch.Generator().manual_seed(n * 7 + F)
+    x = torch.randn(3, n, F, generator=g)
+    x[0, : n // 2] = x[0, 0]                                # a long run of exact ties
+    if n > 40:
+        x[1, 7, 0] = float('nan')
+        x[2, 3:20] = float('-inf')
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    val, idx = agg.topk(x.cuda().contiguous() if F > 1 else x[..., 0].cuda().contiguous(), k, F)
+    val, idx = val.cpu(), idx.cpu().long()
+    xs = torch.where(torch.isnan(x), torch.full_like(x, float('inf')), x)
+    sv, si = torch.sort(xs, dim=1, descending=True, stable=True)
+    assert torch.equal(idx, si[:, :k].permute(0, 2, 1))
+    assert torch.equal(val, sv[:, :k].permute(0, 2, 1))
+    assert idx.min() >= 0 and idx.max() < n

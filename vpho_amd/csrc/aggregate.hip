@@ -97,8 +97,10 @@ __global__ void obj_heat_kernel(const double* __restrict__ pose, const double* _
 }
 
 // ---------------------------------------------------------------------------------------- wavefront top-k
-// One wavefront per row.  Each lane keeps up to 8 (value, index) candidates; k rounds of a 64-lane butterfly arg-max.
-constexpr int TOPK_SLOTS = 8;
+// One wavefront per row.  Each lane keeps SLOTS (value, index) candidates (8: up to 512 candidates -- the README and cfg4 sizes --,
+// 16: up to 1024); k rounds of a 64-lane butterfly arg-max.
+constexpr int TOPK_MAX_SLOTS = 16;
+template <int TOPK_SLOTS>
 __device__ inline void wave_topk(float (&v)[TOPK_SLOTS], int n, int k, int lane, float* val_out, int* idx_out) {
     // v[s] holds element s*64 + lane; `taken` marks elements already emitted (so -inf values are not picked twice)
     unsigned taken = 0;
@@ -120,6 +122,7 @@ __device__ inline void wave_topk(float (&v)[TOPK_SLOTS], int n, int k, int lane,
 }
 
 // scores: element c of row (b, f) at scores[(b*n + c)*F + f]; outputs [b][f][k]
+template <int TOPK_SLOTS>
 __global__ __launch_bounds__(64) void topk_kernel(const float* __restrict__ scores, int n, int F, int k,
                                                   float* __restrict__ val, int* __restrict__ idx) {
     const int row = blockIdx.x, b = row / F, f = row % F, lane = threadIdx.x;
@@ -161,6 +164,7 @@ struct FuseArgs {
     float* val; int* idx;                 // [b][f][k]
     float* topk_pose;                     // [b][k][F][3] gathered axis-angle (aggregation.py:254) or NULL
 };
+template <int TOPK_SLOTS>
 __global__ __launch_bounds__(64) void hand_fuse_kernel(const FuseArgs a) {
     __shared__ float s_val[64];
     __shared__ int s_idx[64];
@@ -536,7 +540,7 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
                                         float* val, int* idx, float* topk_pose, void* stream) {
     VPHO_REQUIRE(hv && pose && val && idx && bs > 0 && C > 0 && level >= 0 && level <= 3, "vpho_hand_fuse_level_f32: bad argument");
     VPHO_REQUIRE(k > 0 && k <= C && k <= 64, "selected index k out of range (topk_hand=%d, candidates=%d, max 64)", k, C);
-    VPHO_REQUIRE(C <= 64 * TOPK_SLOTS, "vpho_hand_fuse_level_f32: at most %d candidates per image", 64 * TOPK_SLOTS);
+    VPHO_REQUIRE(C <= 64 * TOPK_MAX_SLOTS, "vpho_hand_fuse_level_f32: at most %d candidates per image", 64 * TOPK_MAX_SLOTS);
     VPHO_REQUIRE(level == 0 || n_obs % 5 == 0, "vpho_hand_fuse_level_f32: n_obs must be a multiple of 5 for finger levels");
     static const int jid[4][5] = {{0, 0, 0, 0, 0}, {13, 1, 4, 10, 7}, {14, 2, 5, 11, 8}, {15, 3, 6, 12, 9}};   // MANO_PARAMS_LEVEL // 3
     FuseArgs a;
@@ -546,15 +550,17 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
     // algorithmic bytes: the score table read once, the fused joints (3 or 5 x 3 floats) written into every candidate's pose
     vpho::ProfScope prof(vpho::PROF_HAND_FUSE, (hipStream_t)stream, 0.0,
                          (double)bs * C * ((double)n_obs * 4 + (level == 0 ? 3 : 15) * 4) + (double)bs * (level == 0 ? 1 : 5) * k * 8);
-    hipLaunchKernelGGL(hand_fuse_kernel, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
+    if (C <= 512) hipLaunchKernelGGL(hand_fuse_kernel<8>, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(hand_fuse_kernel<16>, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
     return vpho::check_launch("hand_fuse_kernel");
 }
 
 extern "C" int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream) {
     VPHO_REQUIRE(scores && val && idx && rows_outer > 0 && n > 0 && F > 0, "vpho_topk_f32: bad argument");
     VPHO_REQUIRE(k > 0 && k <= n, "selected index k out of range (k=%d, candidates=%d)", k, n);
-    VPHO_REQUIRE(n <= 64 * TOPK_SLOTS, "vpho_topk_f32: at most %d candidates per row", 64 * TOPK_SLOTS);
-    hipLaunchKernelGGL(topk_kernel, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
+    VPHO_REQUIRE(n <= 64 * TOPK_MAX_SLOTS, "vpho_topk_f32: at most %d candidates per row", 64 * TOPK_MAX_SLOTS);
+    if (n <= 512) hipLaunchKernelGGL(topk_kernel<8>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
+    else hipLaunchKernelGGL(topk_kernel<16>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
     return vpho::check_launch("topk_kernel");
 }
 
