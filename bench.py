@@ -62,6 +62,8 @@ def main():
     from vpho_amd import ops, evaluate as E
 
     world, rank, local_rank = world_from_env(args.gpus)
+    from vpho_amd.hostcpu import usable_cpus
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // max(1, world if os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1' else 1))))
     # rehearsal aid for a 1-GPU box: VPHO_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (timings meaningless)
     rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
     dev_index = 0 if rehearse else local_rank
@@ -280,12 +282,16 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     data = synth_batch(n, assets, seed=777)
     torch.manual_seed(99)
     nh, no = torch.randn(n * args.sample_num, 96), torch.randn(n * args.sample_num, 9)
-    cores = torch.get_num_threads()
+    from vpho_amd.hostcpu import usable_cpus
+    threads_before = torch.get_num_threads()
+    cores = min(threads_before, usable_cpus())             # the CPUs this process may really use (affinity AND cgroup quota)
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     ref, info = OV.predict(sd, assets, skeleton, data, sample_num=args.sample_num, sample_T0=args.sample_T0,
                            sampling_steps=args.sampling_steps, topk_hand=args.topk_hand, topk_obj=args.topk_obj,
                            noise_hand=nh, noise_obj=no)
     t_cpu = time.perf_counter() - t0
+    torch.set_num_threads(threads_before)
     gdata = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
     out = model._engine.predict(gdata, noise_hand=nh, noise_obj=no)
     torch.cuda.synchronize()
@@ -310,7 +316,7 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     given_same, _ = parity_summary(out, same_out, eng_info['agg'], same['dbg'], args.sample_num, bound=TIE_REL)
     return {'cpu_baseline': {'value': n / t_cpu, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
                              'sample': f'one batch of {n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
-                                       f'(torch-CPU + host RK45), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
+                                       f'(torch-CPU + host RK45, {cores} threads = this process\'s CPU quota), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
             'parity': {'sample': f'{n} images in one batch, identical inputs and prior draws; bar: 1e-3 on joints / vertices / 6-DoF, selected '
                                  'indices equal.  A top-k chain is discontinuous, so parity = (everything upstream of the aggregation agrees: '
                                  'upstream_max_abs) x (the aggregation kernels select the same indices as the oracle on IDENTICAL candidates, '

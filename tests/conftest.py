@@ -9,6 +9,10 @@ sys.argv = sys.argv[:1]          # vpho_amd.configs.args parses sys.argv at impo
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle: one OpenMP worker per CPU this process may really use (cgroup quota), not per hardware thread of the host
+    import torch
+    from vpho_amd.hostcpu import usable_cpus
+    torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))
 
 
 @pytest.fixture(scope='session')

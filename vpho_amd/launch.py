@@ -25,7 +25,8 @@ def free_port():
 
 def child_env(n, base=None):
     env = dict(os.environ if base is None else base)
-    cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    from .hostcpu import usable_cpus
+    cpus = usable_cpus()                                       # affinity AND cgroup quota (a GPU box grants 16 CPUs per GPU)
     env.setdefault('OMP_NUM_THREADS', str(max(1, min(4, cpus // max(n, 1)))))
     env.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this driver (RCCL needs it)
