@@ -1,0 +1,111 @@
+"""Parity on a TRAINED checkpoint: the two score networks are trained on the box with our own trainer
+(vpho_amd.train_score.ScoreTrainer: DSM loss, backward and AdamW on the HIP kernels) from the round-1 random initialisation, on
+fixed seeded synthetic targets -- no analytic conditioning (vpho_amd.synth.condition_denoisers is NOT used here).  The trained
+networks pull the hypotheses towards the targets, so at the README config (sample_num 100, sampling_steps 50, top-k 30 / 10,
+sample_T0 0.65) the object hypotheses land in the crop and every selection is well defined; the HIP path is then compared with the
+oracle running the SAME trained weights."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+S, STEPS, KH, KO, T0 = 100, 50, 30, 10, 0.65
+TRAIN_STEPS, LR = 1500, 1e-3
+
+
+@pytest.fixture(scope='module')
+def trained(assets):
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.model.engine import Engine
+    from vpho_amd.synth import synth_state_dict, synth_batch, HM_GAIN_CONTRAST
+    from vpho_amd.train_score import ScoreTrainer
+    m = vpho_net(assets)
+    sd = synth_state_dict(m, seed=1, hm_gain=HM_GAIN_CONTRAST)               # random score networks (NOT conditioned)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    eng = Engine(m)
+    bs = 64
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(bs, assets, seed=31).items()}
+    with torch.no_grad():
+        f = eng.features(batch)
+    enc_h, enc_o = f['encoding_hand'].clone(), f['encoding_obj'].clone()
+    g = torch.Generator().manual_seed(17)
+    eye6 = torch.tensor([1., 0, 0, 0, 1, 0])
+    gt_hand = (eye6.repeat(16) + torch.randn(bs, 96, generator=g) * 0.15).cuda()       # per-image target poses near the rest pose
+    gt_obj = torch.cat([eye6 + torch.randn(bs, 6, generator=g) * 0.3, torch.randn(bs, 3, generator=g) * 0.03], 1).cuda()
+    torch.manual_seed(5)
+    hand = ScoreTrainer(sd, 'denoiser_hand', 'cuda', lr=LR)
+    obj = ScoreTrainer(sd, 'denoiser_obj', 'cuda', lr=LR)
+    first = last = None
+    for i in range(TRAIN_STEPS):
+        lh, _ = hand.step(enc_h, gt_hand, repeat_num=20)
+        lo, _ = obj.step(enc_o, gt_obj, repeat_num=20)
+        if i == 0:
+            first = (float(lh), float(lo))
+    last = (float(lh), float(lo))
+    out = dict(sd)
+    out.update({k: v.cpu() for k, v in hand.state_dict().items()})
+    out.update({k: v.cpu() for k, v in obj.state_dict().items()})
+    return out, first, last
+
+
+def test_trained_checkpoint_readme_config_parity(trained, assets):
+    from oracle import vpho as OV
+    from oracle.aggregation import hoi_aggregate
+    from oracle.compare import parity_summary, TIE_REL, E2E_TIE_REL
+    from vpho_amd.assets import ANCHOR_SKELETON
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.model.VPHO import vpho_net
+    from vpho_amd.synth import synth_batch
+    sd, first, last = trained
+    print('DSM loss hand/obj: first step', first, 'last step', last)
+    assert last[0] < 0.6 * first[0] and last[1] < 0.6 * first[1]              # the networks did learn
+    n = 8
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = S, STEPS, KH, KO, T0
+    try:
+        data = synth_batch(n, assets, seed=31)                                 # the first 8 training images
+        torch.manual_seed(77)
+        nh, no = torch.randn(n * S, 96), torch.randn(n * S, 9)
+        ref, info = OV.predict(sd, assets, ANCHOR_SKELETON, data, sample_num=S, sample_T0=T0, sampling_steps=STEPS, topk_hand=KH,
+                               topk_obj=KO, noise_hand=nh, noise_obj=no)
+        m = vpho_net(assets)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        gdata = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        m(gdata, mode='predict')
+        out = m._engine.predict(gdata, noise_hand=nh, noise_obj=no)
+        torch.cuda.synchronize()
+        gi = m._engine.last_info
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+    c = lambda t: t.detach().cpu()
+    od = info['agg']
+    in_crop = (od['transl_score'] != 0).float().mean().item()
+    spread = c(out['diff_final_obj_6d'])[..., 6:].std(1).mean().item()
+    print('object hypotheses scoring inside the crop:', in_crop, ' translation spread (m):', spread, ' nfev', gi['hand_ode']['nfev'], gi['obj_ode']['nfev'])
+    assert in_crop > 0.5                                                       # trained: the hypotheses found the crop
+    assert gi['hand_ode']['nfev'] == info['hand_ode']['nfev'] and gi['obj_ode']['nfev'] == info['obj_ode']['nfev']
+    for k in ('hand_heatmap', 'obj_heatmap', 'force_local', 'reg_hand_joint', 'diff_final_hand_mano', 'diff_final_obj_6d'):
+        err = float((c(out[k]).double() - ref[k].double()).abs().max())
+        assert err < (5e-4 if k == 'diff_final_hand_mano' else 1e-4), (k, err)
+    gf = gi['features']
+    fl = c(out['diff_final_hand_mano']).reshape(-1, 58)
+    same = hoi_aggregate(assets, ANCHOR_SKELETON, cam_intrinsic=data['cam_intr_crop_flip'], root_joint_flip=data['root_joint_flip'],
+                         root_joint=data['root_joint'], is_right=data['is_right'], force_local=c(gf['force_local']),
+                         is_grasped=data['is_grasped'], hand_pose_diff=fl[:, :48].clone(), hand_pose_regression=c(gf['mano_pose']),
+                         hand_shape=fl[:, 48:], hand_heatmap=c(gf['hand_heatmap']), hand_bbox=data['bbox_hand'], hand_topk=KH,
+                         obj_pose6d=c(out['diff_final_obj_6d']), obj_heatmap=c(gf['obj_heatmap']), obj_bbox=data['bbox_obj_rect'],
+                         obj_topk=KO, obj_name=data['obj_name'])
+    same_out = dict(agg_hand_joint=same['hand_agg_joint'], agg_hand_vert=same['hand_agg_vert'], agg_hand_mano=same['hand_agg_mano'],
+                    agg_obj_6d=same['obj_agg_6d'])
+    res, _ = parity_summary(out, same_out, gi['agg'], same['dbg'], S, bound=TIE_REL)
+    print('identical candidates:', {k: v for k, v in res.items() if k != 'per_stage'})
+    # no waiver of any kind on identical candidates: EVERY list of EVERY image equals the oracle's, every output within 1e-4 (bar 1e-3)
+    assert res['images_all_selections_identical'] == n and res['images_with_wrong_selection'] == 0, res
+    for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d'):
+        assert res[f'max_abs_{k}_all'] < 1e-4, (k, res)
+    e2e, _ = parity_summary(out, ref, gi['agg'], od, S, bound=E2E_TIE_REL)
+    print('end to end:', {k: v for k, v in e2e.items() if k != 'per_stage'})
+    assert e2e['images_with_wrong_selection'] == 0, e2e
