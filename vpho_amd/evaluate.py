@@ -78,6 +78,21 @@ def metric_rows(out, data, gt_joint, gt_vert, first_index, assets=None):
     return rows
 
 
+class _Pending:
+    """Future of one pipelined batch: the worker's future + the HIP event behind the batch's last kernel"""
+
+    def __init__(self, fut):
+        self._fut = fut
+
+    def result(self, timeout=None):
+        res, done = self._fut.result(timeout)
+        done.synchronize()
+        return res
+
+    def done(self):
+        return self._fut.done() and self._fut.result()[1].query()
+
+
 class PipelinedPredictor:
     """Evaluation batches are independent, so `depth` of them are kept in flight: each on its own HIP stream, driven by its own
     host thread and execution plan (packed weights are per plan).  One batch alone leaves the GPU idle at the sampler's
@@ -96,10 +111,13 @@ class PipelinedPredictor:
         self.locks = [threading.Lock() for _ in range(depth)]
         self.pool = ThreadPoolExecutor(max_workers=depth, thread_name_prefix='vpho-predict')
         self.n = 0
+        import os
+        self.sync_in_worker = os.environ.get('VPHO_PIPE_SYNC_IN_WORKER', '0') == '1'      # A/B aid: the round-1 behaviour
 
     def submit(self, batch, post=None):
-        """Returns a Future of post(out, batch, engine) (or of the output dict).  The worker synchronises its stream before the
-        future resolves, so the result can be consumed from any stream."""
+        """Returns a future of post(out, batch, engine) (or of the output dict).  The worker thread only ENQUEUES the batch and
+        moves on to its next one; ``.result()`` waits (in the caller's thread, sleeping) for the event recorded behind the batch's
+        last kernel, so the result can be consumed from any stream."""
         from .configs.args import cfg
         bs = batch['rgb'].shape[0]
         noise_h = torch.randn(bs * cfg.sample_num, 96)
@@ -117,10 +135,11 @@ class PipelinedPredictor:
                 res = post(out, batch, eng) if post is not None else out
                 done = torch.cuda.Event(blocking=True)      # sleep, do not spin: the slot threads share the rank's CPU quota
                 done.record(self.streams[slot])
-                done.synchronize()
-                return res
+                if self.sync_in_worker:
+                    done.synchronize()
+                return res, done
 
-        return self.pool.submit(work)
+        return _Pending(self.pool.submit(work))
 
     def close(self):
         self.pool.shutdown(wait=True)
