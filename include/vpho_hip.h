@@ -147,6 +147,9 @@ int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const f
                           int bs, float* out, void* stream);
 /* multi-head attention core over the first axis of qkv (S,B,3E) (nn.MultiheadAttention inside cross_module.py:104-107) */
 int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream);
+/* the same with nn.MultiheadAttention's dropout on the attention probabilities (training): drop_mask [B*nhead][S][S] = keep / (1 - p),
+ * applied after the soft-max and before P V; NULL = no dropout */
+int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int nhead, const float* drop_mask, float* out, void* stream);
 /* out = LayerNorm(x + r) (post-norm TransformerEncoderLayer) */
 int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,
                            float eps, float* out, void* stream);
@@ -395,9 +398,9 @@ int vpho_cross_tokens_bwd_f32(const float* dtok, int bs, float* d_proj_hand, flo
  * dy * normalised input per element (d gamma = its column sums, d beta = the column sums of dy) */
 int vpho_layernorm_bwd_f32(const float* x, const float* r, const float* gamma, const float* dy, long long rows, int E, float eps,
                            float* dx, float* dy_xhat, void* stream);
-/* backward of vpho_mha_f32 (nn.MultiheadAttention inside the encoder layer, sequence axis = batch, quirk Q3; attention dropout 0):
- * qkv [S*B][3E], d_out [S*B][E] -> dqkv [S*B][3E]; S <= 64 */
-int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, float* dqkv, void* stream);
+/* backward of vpho_mha_dropout_f32 (nn.MultiheadAttention inside the encoder layer, sequence axis = batch, quirk Q3):
+ * qkv [S*B][3E], d_out [S*B][E], drop_mask as in the forward (NULL = none) -> dqkv [S*B][3E]; S <= 64 */
+int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv, void* stream);
 /* HeadPhysics tail + losses + gradient (physics.py:546-557 get_local_force with the double soft-max of :659-664, :362-371
  * from_local_to_global on the GROUND-TRUTH vertices, :456-500 get_loss; weights as VPHO.py:214-219): scale_raw [bs*32] (fc_scale
  * output), logits [bs*32][8] (fc_weight before its Softmax), com [bs*32][3] (fc_CoM output); frame [bs][32][3][3] / point

@@ -77,3 +77,56 @@ def test_stage_map_gradients(run):
         np.testing.assert_allclose(float(g.double().norm()), float(G['gnorm_' + k]), rtol=1e-4)
         ref = G['g_' + k]
         assert np.abs(g[::101].numpy() - ref).max() < 2e-4 * np.abs(ref).max(), k
+
+
+@pytest.mark.parametrize('S,p', [(6, 0.0), (32, 0.1), (64, 0.3)])
+def test_attention_forward_backward_with_dropout_mask_matches_autograd(S, p):
+    """vpho_mha_dropout_f32 / vpho_mha_bwd_f32 (sequence axis = batch, 65 token slots x 2 heads) vs fp64 autograd of the same
+    attention written out with an explicit keep-mask / (1 - p) on the probabilities (nn.MultiheadAttention's dropout site)."""
+    from vpho_amd import ops
+    B, E, H = 65, 512, 2
+    hd = E // H
+    g = torch.Generator().manual_seed(S)
+    qkv = torch.randn(S * B, 3 * E, generator=g) * 0.5
+    d_out = torch.randn(S * B, E, generator=g)
+    mask = None if p == 0.0 else ((torch.rand(B * H, S, S, generator=g) >= p).float() / (1.0 - p))
+    x = qkv.double().requires_grad_(True)
+    t = x.view(S, B, 3, H, hd)
+    q, k, v = t[:, :, 0].permute(1, 2, 0, 3), t[:, :, 1].permute(1, 2, 0, 3), t[:, :, 2].permute(1, 2, 0, 3)     # (B,H,S,hd)
+    P = torch.softmax((q / hd ** 0.5) @ k.transpose(-1, -2), dim=-1)
+    if mask is not None:
+        P = P * mask.double().view(B, H, S, S)
+    out = (P @ v).permute(2, 0, 1, 3).reshape(S * B, E)
+    (out * d_out.double()).sum().backward()
+    dev = lambda a: None if a is None else a.cuda().contiguous()
+    got = ops.mha(dev(qkv), S, B, E, H, drop=dev(mask)).view(S * B, E)
+    dq = ops.mha_bwd(dev(qkv), dev(d_out), S, B, E, H, drop=dev(mask))
+    torch.cuda.synchronize()
+    assert float((got.cpu().double() - out.detach()).abs().max()) < 2e-5 * float(out.detach().abs().max())
+    assert float((dq.cpu().double() - x.grad).abs().max()) < 2e-5 * float(x.grad.abs().max())
+
+
+def test_physics_branch_with_dropout_runs_and_differs(sd, assets):
+    """cfg.cross_dropout > 0: all five dropout sites active (fresh Bernoulli masks per call); finite losses / gradients, and two calls
+    differ from each other and from the p = 0 result"""
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    from vpho_amd.train_blocks import PhysicsTrain
+    d = inputs(assets)
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    args = (nhwc(d['st_h']), nhwc(d['st_o']), d['gravity'].cuda(), d['gt_CoM'].cuda(), torch.ones(BS, dtype=torch.bool).cuda(),
+            d['gt_vert'].cuda(), d['gt_force_local'].cuda(), d['is_grasped'].cuda(), tuple(W.values()))
+    torch.manual_seed(3)
+    pt = PhysicsTrain(sd, agg, torch.device('cuda'), p_drop=0.1)
+    a = pt.forward_backward(*args)
+    b = pt.forward_backward(*args)
+    for L, dh, do, G, fl, aux in (a, b):
+        assert all(torch.isfinite(v).all() for v in L.values()) and torch.isfinite(dh).all() and torch.isfinite(do).all()
+        assert all(torch.isfinite(v).all() for v in G.values()) and len(G) == 48
+    assert float(a[0]['CoM_loss']) != float(b[0]['CoM_loss'])
+    assert abs(float(a[0]['CoM_loss']) - float(G_CoM())) > 1e-6
+
+
+def G_CoM():
+    return G['CoM_loss']

@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) void mha_generic_kernel(const float* __restric
 // rows are wave-uniform), lane = feature for P.V (coalesced V rows, probabilities by readlane).  Grid = B * nhead *
 // ceil(S/16) blocks of 4 waves, so the 65-token x 2-head cross module fills the chip instead of 130 CUs.
 // Requires hd % 4 == 0 and hd <= 256.
-__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, float* __restrict__ out) {
+// drop (optional, training): [B*nhead][S][S] keep-mask already scaled by 1 / (1 - p) -- nn.MultiheadAttention's dropout on the
+// attention probabilities (after the soft-max, before P V)
+__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, float* __restrict__ out,
+                                                  const float* __restrict__ drop) {
     const int hd = E / nhead;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nqc = (S + 15) / 16;
@@ -362,6 +365,14 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
         }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         inv[qi] = 1.f / sum;
+        if (drop && q0 + qi < S) {
+            const float* dm = drop + ((long long)bh * S + (q0 + qi)) * S;
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                const int t = slot * 64 + lane;
+                if (t < S) p[slot][qi] *= dm[t];
+            }
+        }
     }
     float acc[4][4];                                 // [query][feature chunk]
 #pragma unroll
@@ -542,13 +553,14 @@ extern "C" int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_o
     return vpho::check_launch("cross_tokens_kernel");
 }
 
-extern "C" int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream) {
+extern "C" int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int nhead, const float* drop_mask, float* out, void* stream) {
     VPHO_REQUIRE(qkv && out && S > 0 && S <= 256 && B > 0 && nhead > 0 && E % nhead == 0, "vpho_mha_f32: bad argument (sequence = batch axis, quirk Q3, must be <= 256; got %d)", S);
     const int hd = E / nhead;
     if (hd % 4 == 0 && hd <= 256 && E % 4 == 0) {
-        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * nhead * ((S + 15) / 16))), dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out);
+        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * nhead * ((S + 15) / 16))), dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out, drop_mask);
         return vpho::check_launch("mha_kernel");
     }
+    VPHO_REQUIRE(drop_mask == nullptr, "vpho_mha_dropout_f32: the dropout mask needs head_dim %% 4 == 0 and head_dim <= 256 (got %d)", hd);
     size_t lds = (size_t)(S * (hd + 1) + S * hd) * sizeof(float);
     const int use_lds = lds <= 150 * 1024;
     if (!use_lds) lds = 0;
@@ -556,6 +568,10 @@ extern "C" int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, fl
     if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
     hipLaunchKernelGGL(mha_generic_kernel, dim3(B * nhead), dim3(256), lds, (hipStream_t)stream, qkv, S, B, E, nhead, use_lds, out);
     return vpho::check_launch("mha_kernel");
+}
+
+extern "C" int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream) {
+    return vpho_mha_dropout_f32(qkv, S, B, E, nhead, nullptr, out, stream);
 }
 
 extern "C" int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // P = softmax(q k^T / sqrt(hd)) and dS = P o (dP - rowsum(dP o P)) live in LDS, then thread c owns feature column c.
 constexpr int MB_S = 64;
 __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, int S, int B, int E,
-                                                      int nhead, float* __restrict__ dqkv) {
+                                                      int nhead, float* __restrict__ dqkv, const float* __restrict__ drop) {
     __shared__ float P[MB_S][MB_S + 1], dS[MB_S][MB_S + 1];
     const int hd = E / nhead, b = blockIdx.x / nhead, h = blockIdx.x % nhead, tid = threadIdx.x;
     const long long rs = (long long)B * 3 * E, ro = (long long)B * E;
@@ -102,11 +102,14 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
         float sum = e;
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         const float p = e / sum;
-        float t = lane < S ? dS[i][lane] * p : 0.f;
+        // attention dropout: O = (P o M) V  ->  dP = (dO V^T) o M; the dV product below uses P o M
+        const float m = (drop && lane < S) ? drop[((long long)blockIdx.x * S + i) * S + lane] : 1.f;
+        const float dp = lane < S ? dS[i][lane] * m : 0.f;
+        float t = dp * p;
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
         if (lane < S) {
-            P[i][lane] = p;
-            dS[i][lane] = p * (dS[i][lane] - t);
+            P[i][lane] = p * m;
+            dS[i][lane] = p * (dp - t);
         }
     }
     __syncthreads();
@@ -259,10 +262,11 @@ extern "C" int vpho_layernorm_bwd_f32(const float* x, const float* r, const floa
     return vpho::check_launch("layernorm_bwd_kernel");
 }
 
-extern "C" int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, float* dqkv, void* stream) {
+extern "C" int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv,
+                                void* stream) {
     VPHO_REQUIRE(qkv && d_out && dqkv && S > 0 && B > 0 && nhead > 0 && E % nhead == 0 && (E / nhead) % 4 == 0, "vpho_mha_bwd_f32: bad argument");
     VPHO_REQUIRE(S <= MB_S, "vpho_mha_bwd_f32: sequence (= batch, quirk Q3) of %d exceeds the %d positions of the training kernel", S, MB_S);
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * nhead), dim3(256), 0, (hipStream_t)stream, qkv, d_out, S, B, E, nhead, dqkv);
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * nhead), dim3(256), 0, (hipStream_t)stream, qkv, d_out, S, B, E, nhead, dqkv, drop_mask);
     return vpho::check_launch("mha_bwd_kernel");
 }
 

@@ -305,9 +305,10 @@ def cross_tokens(proj_hand, proj_obj, grav_emb, pe):
     return out
 
 
-def mha(qkv, S, B, E, nhead):
+def mha(qkv, S, B, E, nhead, drop=None):
+    """drop: optional (B*nhead, S, S) keep-mask / (1 - p) on the attention probabilities (training)"""
     out = _new((S, B, E), qkv)
-    _call('vpho_mha_f32', _f32(qkv), I(S), I(B), I(E), I(nhead), _f32(out))
+    _call('vpho_mha_dropout_f32', _f32(qkv), I(S), I(B), I(E), I(nhead), _f32(drop), _f32(out))
     return out
 
 
@@ -817,9 +818,9 @@ def layernorm_bwd(x, r, gamma, dy, eps=1e-5):
     return dx, gx
 
 
-def mha_bwd(qkv, d_out, S, B, E, nhead):
+def mha_bwd(qkv, d_out, S, B, E, nhead, drop=None):
     dqkv = torch.empty_like(qkv)
-    _call('vpho_mha_bwd_f32', _f32(qkv), _f32(d_out), I(S), I(B), I(E), I(nhead), _f32(dqkv))
+    _call('vpho_mha_bwd_f32', _f32(qkv), _f32(d_out), I(S), I(B), I(E), I(nhead), _f32(drop), _f32(dqkv))
     return dqkv
 
 

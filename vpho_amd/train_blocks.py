@@ -413,9 +413,9 @@ class CrossTrain:
     ``nn.TransformerEncoderLayer`` (2 heads, FFN 2048, ReLU) whose sequence axis is the batch (quirk Q3).  The Linear / Conv2d layers
     run on the fp32-MFMA implicit-GEMM kernels (forward and dgrad) and the TN weight-gradient kernel; csrc/train_physics.hip holds
     the token / LayerNorm / attention backward.  ``p_drop``: the reference trains with its five Dropout sites at 0.1
-    (PositionalEncoding, attention probabilities excluded here -- see below --, after self-attention, inside and after the FFN); the
-    masks are Bernoulli draws from the device generator applied with plain tensor multiplies.  Attention-probability dropout is
-    not applied (the fused attention kernels keep P in registers / LDS); the fixtures run every site at 0."""
+    (PositionalEncoding, the attention probabilities, after self-attention, inside and after the FFN); the masks are Bernoulli
+    draws from the device generator (same distribution as the reference's, not the same stream), applied with plain tensor
+    multiplies except the attention mask, which the attention kernels apply themselves; the fixtures run every site at 0."""
     L = 'attn.layers.0'
 
     def __init__(self, sd, prefix, device, p_drop=0.0):
@@ -450,13 +450,14 @@ class CrossTrain:
         ge = ops.linear(grav_emb, self._gw64, P['gravity_proj.bias'])
         x0, m0 = self._drop(ops.cross_tokens(ph, po, ge, self.pe[:bs].contiguous()).view(bs * 65, 512))
         qkv = ops.linear(x0, P[f'{L}.self_attn.in_proj_weight'], P[f'{L}.self_attn.in_proj_bias'])
-        att = ops.mha(qkv, bs, 65, 512, 2).view(bs * 65, 512)
+        ma = None if self.p_drop <= 0.0 else ((torch.rand((65 * 2, bs, bs), device=self.dev) >= self.p_drop).float() / (1.0 - self.p_drop)).contiguous()
+        att = ops.mha(qkv, bs, 65, 512, 2, drop=ma).view(bs * 65, 512)
         sa, m1 = self._drop(ops.linear(att, P[f'{L}.self_attn.out_proj.weight'], P[f'{L}.self_attn.out_proj.bias']))
         x1 = ops.add_layernorm(x0, sa, P[f'{L}.norm1.weight'], P[f'{L}.norm1.bias'])
         h, mh = self._drop(ops.linear(x1, P[f'{L}.linear1.weight'], P[f'{L}.linear1.bias'], out_slope=0.0))
         ff, m2 = self._drop(ops.linear(h, P[f'{L}.linear2.weight'], P[f'{L}.linear2.bias']))
         x2 = ops.add_layernorm(x1, ff, P[f'{L}.norm2.weight'], P[f'{L}.norm2.bias'])
-        self.saved = dict(st_h=st_h, st_o=st_o, emb=grav_emb, x0=x0, qkv=qkv, att=att, sa=sa, x1=x1, h=h, ff=ff, bs=bs, masks=(m0, m1, mh, m2))
+        self.saved = dict(st_h=st_h, st_o=st_o, emb=grav_emb, x0=x0, qkv=qkv, att=att, sa=sa, x1=x1, h=h, ff=ff, bs=bs, masks=(m0, m1, mh, m2), attn_mask=ma)
         return x2
 
     def backward(self, d_x2, want_hand=True, want_obj=True):
@@ -482,7 +483,7 @@ class CrossTrain:
         d_sa = d_s1 if m1 is None else d_s1 * m1
         G[f'{L}.self_attn.out_proj.weight'], G[f'{L}.self_attn.out_proj.bias'] = _wgrad(S['att'], d_sa), ops.colsum(d_sa)
         d_att = ops.linear(d_sa, T(P[f'{L}.self_attn.out_proj.weight']))
-        dqkv = ops.mha_bwd(S['qkv'], d_att, bs, 65, 512, 2)
+        dqkv = ops.mha_bwd(S['qkv'], d_att, bs, 65, 512, 2, drop=S['attn_mask'])
         G[f'{L}.self_attn.in_proj_weight'], G[f'{L}.self_attn.in_proj_bias'] = _wgrad(S['x0'], dqkv), ops.colsum(dqkv)
         d_x0 = ops.add_lrelu(d_s1, ops.linear(dqkv, T(P[f'{L}.self_attn.in_proj_weight'])))
         if m0 is not None:
