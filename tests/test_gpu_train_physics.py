@@ -125,8 +125,4 @@ def test_physics_branch_with_dropout_runs_and_differs(sd, assets):
         assert all(torch.isfinite(v).all() for v in L.values()) and torch.isfinite(dh).all() and torch.isfinite(do).all()
         assert all(torch.isfinite(v).all() for v in G.values()) and len(G) == 48
     assert float(a[0]['CoM_loss']) != float(b[0]['CoM_loss'])
-    assert abs(float(a[0]['CoM_loss']) - float(G_CoM())) > 1e-6
-
-
-def G_CoM():
-    return G['CoM_loss']
+    assert abs(float(a[0]['CoM_loss']) - float(G['CoM_loss'])) > 1e-6
