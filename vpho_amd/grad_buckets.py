@@ -58,8 +58,12 @@ class GradBuckets:
         self._work, self._flushed = [], set()
 
     def put(self, grads):
-        for k, g in grads.items():
-            self.view[k].copy_(g.reshape(self.view[k].shape))
+        """copy a group of finished gradients into their slots of the flat buffer: one multi-tensor copy, not one launch per tensor"""
+        if not grads:
+            return
+        dst = [self.view[k] for k in grads]
+        src = [g.reshape(self.view[k].shape) for k, g in grads.items()]
+        torch._foreach_copy_(dst, src)
 
     def flush(self, bucket):
         """the gradients of `bucket` are final on this rank: start its all-reduce (sum) without waiting for it"""
