@@ -121,8 +121,8 @@ def test_physics_branch_with_dropout_runs_and_differs(sd, assets):
     pt = PhysicsTrain(sd, agg, torch.device('cuda'), p_drop=0.1)
     a = pt.forward_backward(*args)
     b = pt.forward_backward(*args)
-    for L, dh, do, G, fl, aux in (a, b):
+    for L, dh, do, grads, fl, aux in (a, b):
         assert all(torch.isfinite(v).all() for v in L.values()) and torch.isfinite(dh).all() and torch.isfinite(do).all()
-        assert all(torch.isfinite(v).all() for v in G.values()) and len(G) == 48
+        assert all(torch.isfinite(v).all() for v in grads.values()) and len(grads) == 48
     assert float(a[0]['CoM_loss']) != float(b[0]['CoM_loss'])
     assert abs(float(a[0]['CoM_loss']) - float(G['CoM_loss'])) > 1e-6
