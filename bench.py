@@ -45,6 +45,7 @@ def parse():
     p.add_argument('--cpu_images', type=int, default=64, help='images of the oracle / parity leg (one batch)')
     p.add_argument('--weights', choices=('conditioned', 'random'), default='conditioned', help='synthetic weight set (vpho_amd.synth)')
     p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
+    p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
 
@@ -93,8 +94,17 @@ def main():
         batches.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
     # synthetic ground truth for the metric rows: MANO FK of a seeded small pose (through the HIP FK)
     from vpho_amd.model.engine import Engine
+    if args.no_roi_window:
+        os.environ['VPHO_ROI_WINDOW'] = '0'                # read by every execution plan (this one and the pipeline slots')
     model._engine = Engine(model)
     eng = model._engine
+    # share of the stride-4 FPN pixels the RoIAligns of a batch can read (= what the two smoothing convolutions compute)
+    roi_frac = []
+    for b in batches:
+        fh, fw = b['rgb'].shape[2] // 4, b['rgb'].shape[3] // 4
+        wh = ops.roi_windows(b['bbox_hand'].float().contiguous(), b['bbox_hand_rect'].float().contiguous(), args.bs, fh, fw, 0.25)
+        wo = ops.roi_windows(b['bbox_obj_rect'].float().contiguous(), None, args.bs, fh, fw, 0.25)
+        roi_frac.append((int(wh.count) / (args.bs * fh * fw), int(wo.count) / (args.bs * fh * fw)))
     g = torch.Generator().manual_seed(1234 + rank)
     gt_pose = (torch.randn(args.bs, 48, generator=g) * 0.2).to(dev)
     gt_ctx = eng.mano.shape((torch.randn(args.bs, 10, generator=g) * 0.5).to(dev))
@@ -211,6 +221,10 @@ def main():
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'pipeline_depth': args.pipeline,
+                       'fpn_roi_window': {'enabled': bool(eng.roi_window), 'what': 'the last convolution of each FPN branch is computed only on the pixels its '
+                                          'RoIAligns read (VPHO.py:126-129 are the maps\' only readers); bit-identical results, --no_roi_window computes the full maps',
+                                          'pixel_share_hand_obj_per_batch': roi_frac,
+                                          'boxes': 'synth_batch: hand / object half-extent = focal * 0.11 / depth x U(0.75,1.15) / U(0.6,1.1), unchanged since round 1'},
                        'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,

@@ -61,6 +61,16 @@ typedef struct {
      * input-gradient convolution (torch autograd of nn.LeakyReLU in Bottleneck / Residual, backbone_FPN_HFL.py:326, encoding.py:21-36). */
     const float* gate;
     float gate_slope;
+    /* Optional (NULL = off; ABI version 5): compute only the output pixels listed in row_map[0 .. *row_count) -- each entry the
+     * linear index (n*OH + oy)*OW + ox of an output pixel -- and write them as the rows of a COMPACT (*row_count, Cout) matrix
+     * (y_sx = floats between rows; y_sn / y_sy unused; res, if given, is compact too).  Both live on the device: the grid is
+     * sized for all N*OH*OW pixels and tiles beyond *row_count exit, so the launch needs no host round trip and replays in a
+     * HIP graph with new windows.  Used for the FPN smoothing convolutions, whose maps are read only through RoIAlign
+     * (VPHO.py:126-129): see vpho_roi_windows_i32.  rows_hint (0 = unknown) only feeds the profiling counters. */
+    const int* row_map;
+    const int* row_count;
+    int rows_hint;
+    int rows_scatter;                /* 1: keep y's (n, oy, ox) layout and write only the listed pixels (the rest of y is untouched) */
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
@@ -137,6 +147,24 @@ int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W, int C, in
  * flip_w[n] != 0 mirrors the output along W (flip_tensor_by_mask_index, VPHO.py:138) */
 int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                             int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream);
+/* Demand-driven FPN output.  The stride-4 maps of FPN.forward (backbone_FPN_HFL.py:105-109) are read ONLY by the RoIAligns of
+ * VPHO.py:126-129, so each branch's last convolution is computed on the pixels its image's boxes can sample and nowhere else --
+ * the same values, about half the pixels at the README config's box sizes (dexycb6.py:346-356: boxes = 1.15 / 1.10 x the tight
+ * key-point boxes).  vpho_roi_windows_i32: per image the window = union over boxes_a[n], boxes_b[n] (NULL = one box) of the rows /
+ * columns a bilinear sample of torchvision's roi_align can weigh; wins (N,5) = (first compact row, y0, x0, w, h), row_map = linear
+ * pixel index (n*H + y)*W + x of every window pixel in compact order, *row_count their number; dilate > 0 widens every window by
+ * that many pixels (the 3x3 halo: the lateral 1x1 convolution and the top-down add that feed the last convolution run on the
+ * windows dilated by 1, stored in place -- vpho_conv_desc.rows_scatter).  All device-side: feed row_map /
+ * row_count to vpho_conv_desc and wins to vpho_roi_align_window_nhwc_f32, which reads the compact (rows, C) matrix with the
+ * arithmetic of vpho_roi_align_nhwc_f32 (bit-identical outputs, tests/test_gpu_glue.py). */
+int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, int N, int H, int W, float spatial_scale, int dilate,
+                         int* wins, int* row_map, int* row_count, void* stream);
+/* vpho_resize_bilinear_nhwc_f32 on the listed output pixels only (FPN._upsample_add inside the dilated windows) */
+int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW, float* y, int ldy, int c_off,
+                                       int accumulate, const int* row_map, const int* row_count, int rows_hint, void* stream);
+int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
+                                   float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
+                                   void* stream);
 /* align_hm_to_bbox_rectangle (VPHO.py:333-346, transposing, quirk Q2) (+ optional W flip, VPHO.py:139) */
 int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                 const unsigned char* flip_w, float* out, void* stream);

@@ -70,3 +70,82 @@ def test_wavefront_topk_matches_a_stable_descending_sort(assets, n, F, k):
     assert torch.equal(idx, si[:, :k].permute(0, 2, 1))
     assert torch.equal(val, sv[:, :k].permute(0, 2, 1))
     assert idx.min() >= 0 and idx.max() < n
+
+
+def _window_boxes(g, n, size):
+    """Boxes in image coordinates (the RoIAligns use spatial_scale 1/4): ordinary ones plus the corner cases of the window rule --
+    thinner than one map pixel, beyond the map on either side, covering the whole image, integer and almost-integer edges."""
+    c = torch.rand(n, 2, generator=g) * size
+    h = torch.rand(n, 2, generator=g) * size * 0.45 + 2
+    b = torch.cat([c - h, c + h], 1)
+    special = torch.tensor([[10.0, 10.0, 10.5, 200.0], [-50.0, -30.0, 20.0, 40.0], [200.0, 180.0, 400.0, 300.0], [0.0, 0.0, size, size],
+                            [40.0, 80.0, 160.0, 159.99999], [300.0, 300.0, 320.0, 320.0], [-40.0, -40.0, -10.0, -10.0], [64.0, 64.0, 64.0, 64.0]])
+    b[:special.shape[0]] = special
+    return b
+
+
+@pytest.mark.parametrize('C,k', [(256, 3), (64, 1), (36, 3)])
+def test_roi_windows_give_bit_identical_roi_align(C, k):
+    """Demand-driven FPN output (vpho_roi_windows_i32 + pixel-list convolution + vpho_roi_align_window_nhwc_f32): the convolution
+    computed only on the window pixels and read through the window table gives exactly the RoIAlign outputs of the full map, for both
+    boxes of an image, with and without the W flip -- and every window pixel holds the full map's value."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(C + k)
+    N, H, W, R = 12, 64, 64, 32
+    x = torch.randn(N, H, W, 32, generator=g).cuda()
+    w = (torch.randn(C, k * k * 32, generator=g) * 0.1).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    ba, bb = _window_boxes(g, N, 256.0).cuda(), _window_boxes(torch.Generator().manual_seed(5), N, 256.0).roll(3, 0).cuda()
+    flip = (torch.arange(N) % 2).to(torch.uint8).cuda()
+    full = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, pad=k // 2)
+    for boxes_b in (bb, None):
+        win = ops.roi_windows(ba, boxes_b, N, H, W, 0.25)
+        rows = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, pad=k // 2, rows=win)
+        scat, mask = win.to_map(rows)
+        assert torch.equal(scat[mask], full[mask])
+        n_rows = int(win.count)
+        wins = win.wins.cpu()
+        assert n_rows == int((wins[:, 3] * wins[:, 4]).sum()) and n_rows == int(mask.sum()) and 0 < n_rows < N * H * W
+        assert torch.equal(wins[:, 0], torch.cumsum(wins[:, 3] * wins[:, 4], 0) - wins[:, 3] * wins[:, 4])
+        # the same windows dilated by the 3x3 halo, results stored in place (lateral convolution + top-down add of that level)
+        halo = ops.roi_windows(ba, boxes_b, N, H, W, 0.25, dilate=1)
+        _, hmask = halo.to_map(torch.zeros(N * H * W, 1).cuda())
+        assert bool((torch.nn.functional.max_pool2d(mask.float()[:, None], 3, 1, 1)[:, 0].bool() <= hmask).all())
+        inplace = torch.full((N, H, W, C), -7.0).cuda()
+        ops.conv2d_nhwc(x, w, b, kh=k, kw=k, pad=k // 2, rows=halo, rows_scatter=True, out=inplace)
+        assert torch.equal(inplace[hmask], full[hmask]) and bool((inplace[~hmask] == -7.0).all())
+        small = torch.randn(N, H // 2, W // 2, C, generator=torch.Generator().manual_seed(3)).cuda()
+        up_full = ops.resize_bilinear_nhwc(small, H, W, out=full.clone(), accumulate=True)
+        up_rows = ops.resize_bilinear_nhwc(small, H, W, out=full.clone(), accumulate=True, rows=halo)
+        assert torch.equal(up_rows[hmask], up_full[hmask]) and torch.equal(up_rows[~hmask], full[~hmask])
+        for boxes in ((ba,) if boxes_b is None else (ba, boxes_b)):
+            for fl in (None, flip):
+                ref = ops.roi_align_nhwc(full, boxes, R, 0.25, flip_w=fl)
+                got = ops.roi_align_nhwc(rows, boxes, R, 0.25, flip_w=fl, win=win)
+                assert torch.equal(got, ref)
+    # a box whose window is the whole map: every pixel listed once, in order
+    whole = torch.tensor([[0.0, 0.0, 256.0, 256.0]] * N).cuda()
+    win = ops.roi_windows(whole, None, N, H, W, 0.25)
+    assert int(win.count) == N * H * W and torch.equal(win.row_map.cpu(), torch.arange(N * H * W, dtype=torch.int32))
+
+
+def test_features_with_and_without_roi_windows_are_identical(model_cpu, assets):
+    """Engine.features with the FPN outputs restricted to the RoI windows (default) against VPHO_ROI_WINDOW=0 (full maps): every
+    tensor downstream of the RoIAligns is bit-identical."""
+    import copy
+    from vpho_amd.model.engine import Engine
+    from vpho_amd.synth import synth_batch
+    m = copy.deepcopy(model_cpu).cuda().eval()
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(6, assets, seed=11).items()}
+    eng = Engine(m)
+    assert eng.roi_window
+    with torch.no_grad():
+        a = eng.features(data)
+        eng.roi_window = False
+        b = eng.features(data)
+    assert a['roi_win_hand'] is not None and b['roi_win_hand'] is None and b['hand_feat'].dim() == 4 and a['hand_feat'].dim() == 2
+    frac = int(a['roi_win_hand'].count) / (6 * 64 * 64)
+    assert 0.1 < frac < 1.0
+    for k in ('hf_hr', 'enc_in_hand', 'enc_in_obj', 'hm_hand_nhwc', 'hm_obj_nhwc', 'encoding_hand', 'encoding_obj', 'mano_pose', 'mano_shape',
+              'reg_hand_vert', 'tok_hand', 'tok_obj', 'force_local'):
+        assert torch.equal(a[k], b[k]), k

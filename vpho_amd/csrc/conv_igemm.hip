@@ -45,9 +45,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     vpho_conv_desc d = g.d;
     d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
     // XCD-aware renumbering: hardware block b runs on XCD (b % 8); give each XCD a contiguous run of logical tiles
-    const int per_xcd = gridDim.x >> 3;
+    int per_xcd = gridDim.x >> 3, ntiles = g.ntiles, M_live = g.M;
+    if (d.row_map) {
+        // pixel-list launch: the live row count is device data.  The grid was sized for every pixel; the live tiles are spread
+        // over the 8 XCDs again (contiguous runs of the LIVE tiles), the rest of the grid exits
+        M_live = min(*d.row_count, g.M);
+        ntiles = (M_live + BM - 1) / BM * g.tiles_n;
+        per_xcd = (ntiles + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    }
     const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lb >= g.ntiles) return;
+    if (lb >= ntiles) return;
     const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -63,7 +71,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         int m = m0 + lrow + ROWS * j;
-        if (m < g.M && !(A_PART && lrow >= BM)) {
+        if (m < M_live && !(A_PART && lrow >= BM)) {
+            if (d.row_map) m = d.row_map[m];
             int n = m / ohw, rem = m - n * ohw;
             int oy = rem / d.OW, ox = rem - oy * d.OW;
             a_iy0[j] = oy * d.stride - d.pad_y;
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     auto offsets = [&](int row, long long& yo, long long& ro) {
+        if (d.row_map && d.rows_scatter) row = d.row_map[row];          // pixel list, results stored at the pixels' own positions
         if (g.y_linear && g.r_linear) {
             yo = (long long)row * d.y_sx;
             ro = (long long)row * d.r_sx;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
             const int idx = tid + it * NT;
             const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
             const int row = m0 + r, col = n0 + 4 * c4;
-            ok[it] = row < g.M && col < d.Cout;
+            ok[it] = row < M_live && col < d.Cout;
             v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
             long long ro = 0;
             yo[it] = 0;
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
-                if (row >= g.M) continue;
+                if (row >= M_live) continue;
                 long long yo, ro;
                 offsets(row, yo, ro);
                 float v = acc[i][j][e] + bv;
@@ -312,9 +322,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 
     vpho_conv_desc d = g.d;
     d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
-    const int per_xcd = gridDim.x >> 3;
+    int per_xcd = gridDim.x >> 3, ntiles = g.ntiles, M_live = g.M;
+    if (d.row_map) {
+        // pixel-list launch: the live row count is device data.  The grid was sized for every pixel; the live tiles are spread
+        // over the 8 XCDs again (contiguous runs of the LIVE tiles), the rest of the grid exits
+        M_live = min(*d.row_count, g.M);
+        ntiles = (M_live + BM - 1) / BM * g.tiles_n;
+        per_xcd = (ntiles + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    }
     const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lb >= g.ntiles) return;
+    if (lb >= ntiles) return;
     const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -335,7 +353,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         int m = m0 + lrow + ROWS * j;
-        if (m < g.M) {
+        if (m < M_live) {
+            if (d.row_map) m = d.row_map[m];
             int n = m / ohw, rem = m - n * ohw;
             int oy = rem / d.OW, ox = rem - oy * d.OW;
             a_iy0[j] = oy * d.stride - d.pad_y;
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     }
 
     auto offsets = [&](int row, long long& yo, long long& ro) {
+        if (d.row_map && d.rows_scatter) row = d.row_map[row];          // pixel list, results stored at the pixels' own positions
         if (g.y_linear && g.r_linear) {
             yo = (long long)row * d.y_sx;
             ro = (long long)row * d.r_sx;
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
             const int idx = tid + it * NT;
             const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
             const int row = m0 + r, col = n0 + 4 * c4;
-            ok[it] = row < g.M && col < d.Cout;
+            ok[it] = row < M_live && col < d.Cout;
             v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
             long long ro = 0;
             yo[it] = 0;
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
-                if (row >= g.M) continue;
+                if (row >= M_live) continue;
                 long long yo, ro;
                 offsets(row, yo, ro);
                 float v = acc[i][j][e] + bv;
@@ -570,6 +590,11 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     VPHO_REQUIRE(splits == 1 || (!d.res && !d.bias && !d.in_scale && !d.gate), "vpho_conv2d_nhwc_f32: split launches produce plain partial sums (no bias / residual / prologue / gate)");
     g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
     g.r_linear = (d.res == nullptr) || (d.r_sy == d.r_sx * d.OW && d.r_sn == d.r_sy * d.OH) ? 1 : 0;
+    VPHO_REQUIRE((d.row_map == nullptr) == (d.row_count == nullptr), "vpho_conv2d_nhwc_f32: row_map / row_count must come together");
+    if (d.row_map) {
+        VPHO_REQUIRE(splits == 1 && !d.gate, "vpho_conv2d_nhwc_f32: pixel-list launches take no splits / gate");
+        if (!d.rows_scatter) g.y_linear = g.r_linear = 1;   // compact output: row r of y (and res) is the r-th listed pixel
+    }
     // 16-byte epilogue when every output pixel's channel run (and the residual's) is 16-byte addressable
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     g.vec_epilogue = (d.Cout % 4 == 0 && al16(d.y) && d.y_sx % 4 == 0 && d.y_sy % 4 == 0 && d.y_sn % 4 == 0 &&
@@ -580,9 +605,10 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     g.dbg = dbg;
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * splits;
-    const double flops = 2.0 * (double)M * d.Cout * g.K * splits;
+    const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes
+    const double flops = 2.0 * m_acc * d.Cout * g.K * splits;
     // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
-    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + (double)M * d.Cout * (d.res ? 2 : 1) + d.Cout);
+    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout);
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)

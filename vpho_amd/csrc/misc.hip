@@ -83,13 +83,18 @@ __device__ inline void stv(float* __restrict__ p, const float (&v)[V]) {
 // y[n,oy,ox,c_off+c] (=|+=) bilinear(x)[n,oy,ox,c]
 template <int V>
 __global__ void resize_bilinear_nhwc_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int OH, int OW,
-                                            float* __restrict__ y, int ldy, int c_off, int accumulate) {
+                                            float* __restrict__ y, int ldy, int c_off, int accumulate,
+                                            const int* __restrict__ row_map, const int* __restrict__ row_count) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int CV = C / V;
     const long long total = (long long)N * OH * OW * CV;
     if (i >= total) return;
     const int c = (int)(i % CV) * V;
     long long p = i / CV;
+    if (row_map) {                                   // pixel list (vpho_roi_windows_i32): the p-th listed output pixel only
+        if (p >= *row_count) return;
+        p = row_map[p];
+    }
     const int ox = (int)(p % OW); p /= OW;
     const int oy = (int)(p % OH);
     const long long n = p / OH;
@@ -113,8 +118,12 @@ __global__ void resize_bilinear_nhwc_kernel(const float* __restrict__ x, int N, 
 
 // ------------------------------------------------------------------------------------------------ RoIAlign
 // torchvision roi_align, aligned=False, sampling_ratio=-1 (adaptive), one RoI per image (batch index = roi index)
+// RoI window of an image: the pixels [y0, y0+h) x [x0, x0+w) of its map, stored as rows base .. base + w*h of a compact matrix
+struct RoiWin { int base, y0, x0, w, h; };
+
 template <int V>
-__device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, int ld, float y, float x, float (&acc)[V]) {
+__device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, int ld, float y, float x, float (&acc)[V],
+                                    const RoiWin* win = nullptr) {
     if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
 #pragma unroll
         for (int u = 0; u < V; ++u) acc[u] += 0.f;
@@ -127,8 +136,17 @@ __device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, i
     if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
     const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
     float a[V], b[V], c[V], d[V];
-    ldv<V>(f + ((long long)yl * W + xl) * ld, a); ldv<V>(f + ((long long)yl * W + xh) * ld, b);
-    ldv<V>(f + ((long long)yh * W + xl) * ld, c); ldv<V>(f + ((long long)yh * W + xh) * ld, d);
+    if (win) {
+        // compact map: the window holds every pixel a sample of this image's boxes can weigh (roi_window_kernel); the clamp only
+        // guards the address of a zero-weight neighbour
+        const int wy0 = min(max(yl - win->y0, 0), win->h - 1), wy1 = min(max(yh - win->y0, 0), win->h - 1);
+        const int wx0 = min(max(xl - win->x0, 0), win->w - 1), wx1 = min(max(xh - win->x0, 0), win->w - 1);
+        ldv<V>(f + ((long long)wy0 * win->w + wx0) * ld, a); ldv<V>(f + ((long long)wy0 * win->w + wx1) * ld, b);
+        ldv<V>(f + ((long long)wy1 * win->w + wx0) * ld, c); ldv<V>(f + ((long long)wy1 * win->w + wx1) * ld, d);
+    } else {
+        ldv<V>(f + ((long long)yl * W + xl) * ld, a); ldv<V>(f + ((long long)yl * W + xh) * ld, b);
+        ldv<V>(f + ((long long)yh * W + xl) * ld, c); ldv<V>(f + ((long long)yh * W + xh) * ld, d);
+    }
 #pragma unroll
     for (int u = 0; u < V; ++u) acc[u] += hy * hx * a[u] + hy * lx * b[u] + ly * hx * c[u] + ly * lx * d[u];
 }
@@ -136,7 +154,7 @@ __device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, i
 template <int V>
 __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int H, int W, int C, const float* __restrict__ boxes,
                                       float scale, int P, const unsigned char* __restrict__ flip_w,
-                                      float* __restrict__ out, int ldo, int c_off) {
+                                      float* __restrict__ out, int ldo, int c_off, const RoiWin* __restrict__ wins) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int CV = C / V;
     const long long total = (long long)N * P * P * CV;
@@ -152,7 +170,9 @@ __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int
     const float bh = rh / (float)P, bw = rw / (float)P;
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float cnt = fmaxf((float)(gh * gw), 1.f);
-    const float* f = feat + (long long)n * H * W * C + c;
+    RoiWin win;
+    if (wins) win = wins[n];
+    const float* f = feat + (wins ? (long long)win.base : (long long)n * H * W) * C + c;
     float acc[V];
 #pragma unroll
     for (int u = 0; u < V; ++u) acc[u] = 0.f;
@@ -160,13 +180,57 @@ __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int
         const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
         for (int ix = 0; ix < gw; ++ix) {
             const float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
-            roi_bilinear<V>(f, H, W, C, y, x, acc);
+            roi_bilinear<V>(f, H, W, C, y, x, acc, wins ? &win : nullptr);
         }
     }
     const int ow = (flip_w && flip_w[n]) ? P - 1 - pw : pw;
 #pragma unroll
     for (int u = 0; u < V; ++u) acc[u] = acc[u] / cnt;
     stv<V>(out + (((long long)n * P + ph) * P + ow) * ldo + c_off + c, acc);
+}
+
+// RoI windows (demand-driven FPN output): RoIAlign is the only reader of the stride-4 FPN maps (VPHO.py:115,126-129), so the last
+// convolution of each branch needs only the pixels the image's boxes can sample.  A sample lies in (start, start + max(len, 1))
+// and weighs rows floor(y), floor(y)+1 clipped to the map (roi_bilinear): the window of an image is the union over its boxes of
+// [floor(max(start, 0)), floor(start + max(len, 1)) + 1], clipped; `dilate` widens it by that many pixels on every side (the input
+// halo of a 3x3 convolution that produces the window).  Thread n sizes image n; thread 0 lays the windows end to end.
+__global__ __launch_bounds__(256) void roi_window_kernel(const float* __restrict__ boxes_a, const float* __restrict__ boxes_b, int N, int H, int W,
+                                                         float scale, int dilate, RoiWin* __restrict__ wins, int* __restrict__ count) {
+    for (int n0 = 0; n0 < N; n0 += 256) {          // N <= 256 in every configuration; the loop keeps larger batches correct
+        const int n = n0 + threadIdx.x;
+        if (n < N) {
+            float lo_x = 3.0e38f, lo_y = 3.0e38f, hi_x = -3.0e38f, hi_y = -3.0e38f;
+            for (int k = 0; k < 2; ++k) {
+                const float* b = k == 0 ? boxes_a : boxes_b;
+                if (!b) continue;
+                const float x1 = b[n * 4 + 0] * scale, y1 = b[n * 4 + 1] * scale, x2 = b[n * 4 + 2] * scale, y2 = b[n * 4 + 3] * scale;
+                const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+                lo_x = fminf(lo_x, x1); lo_y = fminf(lo_y, y1);
+                hi_x = fmaxf(hi_x, x1 + rw); hi_y = fmaxf(hi_y, y1 + rh);
+            }
+            auto clampi = [](float v, int hi) { return v <= 0.f ? 0 : (v >= (float)hi ? hi : (int)v); };   // floor for v >= 0, NaN -> 0
+            RoiWin w;
+            w.y0 = max(clampi(lo_y, H - 1) - dilate, 0); w.x0 = max(clampi(lo_x, W - 1) - dilate, 0);
+            const int y1i = min(clampi(hi_y, H - 1) + 1 + dilate, H - 1), x1i = min(clampi(hi_x, W - 1) + 1 + dilate, W - 1);
+            w.h = max(y1i - w.y0 + 1, 1); w.w = max(x1i - w.x0 + 1, 1);
+            w.base = 0;
+            wins[n] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int base = 0;
+        for (int n = 0; n < N; ++n) { wins[n].base = base; base += wins[n].w * wins[n].h; }
+        *count = base;
+    }
+}
+// row_map[base + p] = linear index of the p-th window pixel of image n (row-major inside the window)
+__global__ void roi_rows_kernel(const RoiWin* __restrict__ wins, int H, int W, int* __restrict__ row_map) {
+    const RoiWin w = wins[blockIdx.y];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w.w * w.h) return;
+    const int yy = p / w.w, xx = p - yy * w.w;
+    row_map[w.base + p] = ((int)blockIdx.y * H + w.y0 + yy) * W + w.x0 + xx;
 }
 
 // ------------------------------------------------------------------------------------------------ heat-map re-alignment
@@ -515,10 +579,23 @@ extern "C" int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W
     // algorithmic bytes: input read once, output written once (and read once when accumulating into it)
     vpho::ProfScope prof(vpho::PROF_RESIZE, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)OH * OW * (accumulate ? 2 : 1)));
     if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
-        LAUNCH1D(resize_bilinear_nhwc_kernel<4>, (long long)N * OH * OW * (C / 4), stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
+        LAUNCH1D(resize_bilinear_nhwc_kernel<4>, (long long)N * OH * OW * (C / 4), stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate, (const int*)nullptr, (const int*)nullptr);
     else
-        LAUNCH1D(resize_bilinear_nhwc_kernel<1>, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate);
+        LAUNCH1D(resize_bilinear_nhwc_kernel<1>, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate, (const int*)nullptr, (const int*)nullptr);
     return vpho::check_launch("resize_bilinear_nhwc_kernel");
+}
+
+extern "C" int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW, float* y, int ldy, int c_off,
+                                                  int accumulate, const int* row_map, const int* row_count, int rows_hint, void* stream) {
+    VPHO_REQUIRE(x && y && row_map && row_count && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && ldx >= C && ldy >= c_off + C && c_off >= 0,
+                 "vpho_resize_bilinear_rows_nhwc_f32: bad argument");
+    const double px = rows_hint > 0 ? (double)rows_hint : (double)N * OH * OW;
+    vpho::ProfScope prof(vpho::PROF_RESIZE, (hipStream_t)stream, 0.0, 4.0 * C * ((double)N * H * W + px * (accumulate ? 2 : 1)));
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
+        LAUNCH1D(resize_bilinear_nhwc_kernel<4>, (long long)N * OH * OW * (C / 4), stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate, row_map, row_count);
+    else
+        LAUNCH1D(resize_bilinear_nhwc_kernel<1>, (long long)N * OH * OW * C, stream, x, N, H, W, C, ldx, OH, OW, y, ldy, c_off, accumulate, row_map, row_count);
+    return vpho::check_launch("resize_bilinear_nhwc_kernel(rows)");
 }
 
 extern "C" int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
@@ -527,10 +604,34 @@ extern "C" int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, i
     // algorithmic bytes: the feature map read once (upper bound of what a box covers), the pooled map written once
     vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)out_size * out_size));
     if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)feat | (uintptr_t)out) % 16 == 0)
-        LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
+        LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)nullptr);
     else
-        LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off);
+        LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)nullptr);
     return vpho::check_launch("roi_align_nhwc_kernel");
+}
+
+extern "C" int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, int N, int H, int W, float spatial_scale, int dilate,
+                                    int* wins, int* row_map, int* row_count, void* stream) {
+    VPHO_REQUIRE(boxes_a && wins && row_map && row_count && N > 0 && H > 0 && W > 0 && dilate >= 0, "vpho_roi_windows_i32: bad argument");
+    VPHO_REQUIRE((long long)N * H * W < (1ll << 31), "vpho_roi_windows_i32: map too large");
+    static_assert(sizeof(RoiWin) == 5 * sizeof(int), "window record = 5 ints");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(roi_window_kernel, dim3(1), dim3(256), 0, s, boxes_a, boxes_b, N, H, W, spatial_scale, dilate, (RoiWin*)wins, row_count);
+    hipLaunchKernelGGL(roi_rows_kernel, dim3((H * W + 255) / 256, N), dim3(256), 0, s, (const RoiWin*)wins, H, W, row_map);
+    return vpho::check_launch("roi_window_kernel");
+}
+
+extern "C" int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
+                                              float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
+                                              void* stream) {
+    VPHO_REQUIRE(feat_rows && wins && boxes && out && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_window_nhwc_f32: bad argument");
+    // algorithmic bytes: upper bound as for the full map (the window sizes are device data)
+    vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)out_size * out_size));
+    if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)feat_rows | (uintptr_t)out) % 16 == 0)
+        LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins);
+    else
+        LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins);
+    return vpho::check_launch("roi_align_nhwc_kernel(window)");
 }
 
 extern "C" int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,

@@ -115,6 +115,8 @@ class Engine:
         self._obj_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vpho-obj-sampler')
         # launch-bound, sync-free phases are replayed as HIP graphs (VPHO_GRAPHS=0: plain launches, same kernels)
         self.use_graphs = os.environ.get('VPHO_GRAPHS', '1') != '0'
+        # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
+        self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         from .graphs import GraphedCall
         self._features_graph = GraphedCall(self.features, dev)
         self._aggregate_graph = GraphedCall(self._aggregate_from_tensors, dev)
@@ -134,7 +136,10 @@ class Engine:
             x = self._bottleneck(x, b)
         return x
 
-    def _fpn(self, rgb):
+    def _fpn(self, rgb, windows=None):
+        """FPN.forward.  ``windows`` = {'h': (RoiWindows, the same dilated by 1), 'o': ...}: the two stride-4 outputs are produced
+        only on the pixels the RoIAligns read, as compact (rows, 256) matrices (vpho_roi_windows_i32); the lateral convolution and
+        the top-down add of that level run on the dilated windows."""
         x = ops.nchw_to_nhwc(rgb, 4)
         c1 = ops.maxpool_nhwc(ops.conv2d_nhwc(x, *self.stem, kh=7, kw=7, stride=2, pad=3, out_slope=0.01), 3, 2, 1)
         c2 = self._layer(c1, 'layer1_h')
@@ -149,9 +154,11 @@ class Engine:
         for br, c5, c4, c3 in (('h', c5h, c4h, c3h), ('o', c5o, c4o, c3o)):
             p = ops.conv2d_nhwc(c5, *self.fpn[f'toplayer_{br}'])
             for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2)):
-                q = ops.conv2d_nhwc(c, *self.fpn[lat])
-                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
-            out.append(ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1))
+                # the stride-4 level: lateral convolution and top-down add only inside the windows dilated by the 3x3 halo
+                halo = windows[br][1] if (windows is not None and c is c2) else None
+                q = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None)
+                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
+            out.append(ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1, rows=None if windows is None else windows[br][0]))
         return out
 
     def _hm_head(self, x, h):
@@ -198,15 +205,22 @@ class Engine:
         is_right = data['is_right'].bool()
         left_u8 = (~is_right).to(torch.uint8).contiguous()
         R, HM = cfg.roi_size, cfg.heatmap_size
-        hand_feat, obj_feat = self._fpn(rgb)
         bb_h, bb_o, bb_hr, bb_or = f32('bbox_hand'), f32('bbox_obj'), f32('bbox_hand_rect'), f32('bbox_obj_rect')
+        win_h = win_o = None
+        if self.roi_window:
+            # the FPN outputs are read only through these RoIAligns (the reference's `of_or` on bbox_obj is never used, VPHO.py:127)
+            fh, fw = rgb.shape[2] // 4, rgb.shape[3] // 4
+            win_h = ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25)
+            win_o = ops.roi_windows(bb_or, None, bs, fh, fw, 0.25)
+            halo = {'h': ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25, dilate=1), 'o': ops.roi_windows(bb_or, None, bs, fh, fw, 0.25, dilate=1)}
+        hand_feat, obj_feat = self._fpn(rgb, None if win_h is None else {'h': (win_h, halo['h']), 'o': (win_o, halo['o'])})
         eh, eo = self.enc['hand'], self.enc['obj']
         in_h = torch.zeros((bs, R, R, eh['cin_pad']), device=self.dev)
         in_o = torch.zeros((bs, R, R, eo['cin_pad']), device=self.dev)
-        hf_hr = ops.roi_align_nhwc(hand_feat, bb_h, R, 0.25)
-        ops.roi_align_nhwc(hand_feat, bb_hr, R, 0.25, out=in_h)
-        of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25)
-        ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o)          # VPHO.py:138
+        hf_hr = ops.roi_align_nhwc(hand_feat, bb_h, R, 0.25, win=win_h)
+        ops.roi_align_nhwc(hand_feat, bb_hr, R, 0.25, out=in_h, win=win_h)
+        of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, win=win_o)
+        ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o, win=win_o)   # VPHO.py:138
         hm_hand = self._hm_head(hf_hr, self.hm['hand'])                                  # (bs,64,64,21)
         hm_obj = self._hm_head(of_or_rect, self.hm['obj'])                               # (bs,64,64,27)
         ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_hand, bb_h, bb_hr), R, R, out=in_h, c_off=256)
@@ -227,7 +241,7 @@ class Engine:
         scale = ops.linear(ops.linear(tok_h, *ph['s0'], out_slope=0.01), *ph['s2'])      # (bs*65,1)
         logits = ops.linear(ops.linear(tok_o, *ph['w0'], out_slope=0.01), *ph['w2'])     # (bs*65,8)
         force_local = ops.force_local(scale, logits, ph['anchor'], bs * 32, 32, 65, 0, 32).view(bs, 32, 3)
-        return dict(hand_feat=hand_feat, obj_feat=obj_feat, hf_hr=hf_hr, enc_in_hand=in_h, enc_in_obj=in_o,
+        return dict(hand_feat=hand_feat, obj_feat=obj_feat, roi_win_hand=win_h, roi_win_obj=win_o, hf_hr=hf_hr, enc_in_hand=in_h, enc_in_obj=in_o,
                     hm_hand_nhwc=hm_hand, hm_obj_nhwc=hm_obj, hand_heatmap=ops.nhwc_to_nchw(hm_hand), obj_heatmap=ops.nhwc_to_nchw(hm_obj),
                     encoding_hand=enc_h, encoding_obj=enc_o, stage_hand=st_h[1], stage_obj=st_o[1], mano_pose=pose, mano_shape=shape,
                     mano_ctx=ctx, reg_hand_vert=reg_vert, reg_hand_joint=reg_joint, tok_hand=tok_h, tok_obj=tok_o, force_local=force_local)

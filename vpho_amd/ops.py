@@ -58,7 +58,8 @@ class ConvDesc(C.Structure):
                 ('r_sn', C.c_longlong), ('r_sy', C.c_longlong), ('r_sx', C.c_longlong),
                 ('in_slope', C.c_float), ('out_slope', C.c_float),
                 ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong),
-                ('gate', C.c_void_p), ('gate_slope', C.c_float)]
+                ('gate', C.c_void_p), ('gate_slope', C.c_float),
+                ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -69,12 +70,16 @@ def _addr(t):
 
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
-                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None):
+                out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None,
+                rows=None, rows_scatter=False):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
 
     ``out_view`` = (tensor, y_sn, y_sy, y_sx, element_offset) writes into a strided destination (concat buffers,
     transposed-convolution phases).  ``res`` is a contiguous (N,OH,OW,Cout) tensor.  ``gate`` = (tensor shaped like the
-    destination, slope): y = gate > 0 ? y : slope * y (LeakyReLU backward fused into an input-gradient convolution)."""
+    destination, slope): y = gate > 0 ? y : slope * y (LeakyReLU backward fused into an input-gradient convolution).
+    ``rows`` = a ``RoiWindows``: only the listed output pixels are computed and the result is the COMPACT (N*OH*OW, Cout)
+    matrix whose first ``rows.count`` rows are live (``roi_align_nhwc(..., win=rows)`` reads it); with ``rows_scatter`` the listed
+    pixels are written at their own positions of the ordinary (N,OH,OW,Cout) output and the other pixels are left untouched."""
     N, H, W, x_ld = x.shape
     cin = x_ld if cin is None else cin
     cout = w.shape[0]
@@ -90,7 +95,18 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     d.in_scale, d.in_shift, d.res = _addr(in_scale), _addr(in_shift), _addr(res)
     for t in (x, w, bias, in_scale, in_shift, res):
         _ptr(t, torch.float32)
-    if out_view is not None:
+    if rows is not None:
+        assert out_view is None and res is None and gate is None and rows.shape == (N, OH, OW)
+        if out is None:
+            out = torch.empty((N, OH, OW, cout) if rows_scatter else (N * OH * OW, cout), device=x.device, dtype=torch.float32)
+        _ptr(out, torch.float32)
+        ld = out.shape[-1]
+        d.y, d.y_sx, d.y_sy, d.y_sn = out.data_ptr(), ld, (ld * OW if rows_scatter else 0), (ld * OW * OH if rows_scatter else 0)
+        d.rows_scatter = 1 if rows_scatter else 0
+        d.row_map, d.row_count = rows.row_map.data_ptr(), rows.count.data_ptr()
+        d.rows_hint = int(rows.count.item()) if _prof_on else 0      # the instrumented pass may synchronise; the product path never does
+        ret = out
+    elif out_view is not None:
         yt, d.y_sn, d.y_sy, d.y_sx, off = out_view
         _ptr(yt, torch.float32)
         d.y = yt.data_ptr() + 4 * off
@@ -264,18 +280,61 @@ def maxpool_nhwc(x, k, stride, pad):
     return y
 
 
-def resize_bilinear_nhwc(x, OH, OW, out=None, c_off=0, accumulate=False, channels=None):
+def resize_bilinear_nhwc(x, OH, OW, out=None, c_off=0, accumulate=False, channels=None, rows=None):
     N, H, W, ldx = x.shape
     Cc = ldx if channels is None else channels
     if out is None:
         out = _new((N, OH, OW, Cc), x)
     assert out.shape[:3] == (N, OH, OW)
+    if rows is not None:                                     # only the listed output pixels (RoiWindows), in place
+        assert rows.shape == (N, OH, OW)
+        _call('vpho_resize_bilinear_rows_nhwc_f32', _f32(x), I(N), I(H), I(W), I(Cc), I(ldx), I(OH), I(OW), _f32(out), I(out.shape[-1]),
+              I(c_off), I(1 if accumulate else 0), _ptr(rows.row_map, torch.int32), _ptr(rows.count, torch.int32),
+              I(int(rows.count.item()) if _prof_on else 0))
+        return out
     _call('vpho_resize_bilinear_nhwc_f32', _f32(x), I(N), I(H), I(W), I(Cc), I(ldx), I(OH), I(OW), _f32(out), I(out.shape[-1]),
           I(c_off), I(1 if accumulate else 0))
     return out
 
 
-def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, c_off=0):
+class RoiWindows:
+    """Per-image pixel windows of a feature map (device data): ``wins`` (N,5) int32 = (first row, y0, x0, w, h), ``row_map``
+    the linear pixel index of every window pixel, ``count`` (1,) their number.  See vpho_roi_windows_i32."""
+    def __init__(self, wins, row_map, count, shape):
+        self.wins, self.row_map, self.count, self.shape = wins, row_map, count, shape
+
+    def to_map(self, rows):
+        """Inspection helper (synchronises): the compact matrix scattered back to (N,H,W,C), zeros outside the windows, and the
+        (N,H,W) mask of the window pixels."""
+        n = int(self.count.item())
+        N, H, W = self.shape
+        idx = self.row_map[:n].long()
+        full = torch.zeros((N * H * W, rows.shape[-1]), device=rows.device, dtype=rows.dtype)
+        full[idx] = rows[:n]
+        mask = torch.zeros((N * H * W,), device=rows.device, dtype=torch.bool)
+        mask[idx] = True
+        return full.view(N, H, W, -1), mask.view(N, H, W)
+
+
+def roi_windows(boxes_a, boxes_b, N, H, W, spatial_scale, dilate=0):
+    dev = boxes_a.device
+    wins = torch.empty((N, 5), device=dev, dtype=torch.int32)
+    row_map = torch.empty((N * H * W,), device=dev, dtype=torch.int32)
+    count = torch.empty((1,), device=dev, dtype=torch.int32)
+    _call('vpho_roi_windows_i32', _f32(boxes_a), _f32(boxes_b), I(N), I(H), I(W), F(spatial_scale), I(dilate), _ptr(wins, torch.int32),
+          _ptr(row_map, torch.int32), _ptr(count, torch.int32))
+    return RoiWindows(wins, row_map, count, (N, H, W))
+
+
+def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, c_off=0, win=None):
+    if win is not None:                                      # feat = compact (rows, C) matrix of the windows' pixels
+        N, H, W = win.shape
+        Cc = feat.shape[-1]
+        if out is None:
+            out = _new((N, out_size, out_size, Cc), feat)
+        _call('vpho_roi_align_window_nhwc_f32', _f32(feat), _ptr(win.wins, torch.int32), I(N), I(H), I(W), I(Cc), _f32(boxes),
+              F(spatial_scale), I(out_size), _u8(flip_w), _f32(out), I(out.shape[-1]), I(c_off))
+        return out
     N, H, W, Cc = feat.shape
     if out is None:
         out = _new((N, out_size, out_size, Cc), feat)
@@ -841,7 +900,12 @@ PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2,
                 'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8}
 
 
+_prof_on = False
+
+
 def prof_enable(name, on=True):
+    global _prof_on
+    _prof_on = bool(on)
     _check(lib.vpho_prof_enable(I(PROF_CLASSES[name]), I(1 if on else 0)))
 
 
