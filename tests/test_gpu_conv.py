@@ -58,6 +58,21 @@ def test_conv_epilogue_residual_lrelu_and_prologue_affine():
     _close(y.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize('N,H,Cin,Cout', [(16, 32, 256, 256), (9, 31, 128, 64), (3, 17, 512, 128), (2, 8, 544, 64)])
+def test_prologue_affine_on_the_direct_to_lds_kernel(N, H, Cin, Cout):
+    """Pre-activation BN + LeakyReLU applied to the fragments as they are read from LDS (1x1, Cin % 32 == 0, Cin <= 512) in all
+    three tile classes incl. ragged pixel counts; Cin = 544 exceeds the table and takes the register-staged kernel."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    x, w, b = _rand((N, Cin, H, H), 40), _rand((Cout, Cin, 1, 1), 41, (2.0 / Cin) ** 0.5), _rand((Cout,), 42)
+    sc, sh = _rand((Cin,), 43).abs() + 0.5, _rand((Cin,), 44)
+    pre = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.01)
+    ref = F.leaky_relu(F.conv2d(pre, w, b), 0.01)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                        in_slope=0.01, out_slope=0.01)
+    _close(y.permute(0, 3, 1, 2), ref)
+
+
 def test_prologue_affine_pads_with_zero_after_activation():
     from vpho_amd import ops
     from vpho_amd.model.pack import pack_conv

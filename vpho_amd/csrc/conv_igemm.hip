@@ -18,6 +18,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
+constexpr int GLDS_PRE_MAX = 512;     // most input channels of a pre-activation 1x1 convolution on the direct-to-LDS kernel
 
 struct Geo {
     vpho_conv_desc d;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 // Geo::uni (Cin % 32 == 0): the 32 k of a stage lie in ONE tap: the tap is wave-uniform, the k / tap advance rides in the buffer
 // instruction's scalar offset and the per-lane offsets are loop constants (only the padding test of a 3x3 stays per stage; for 1x1
 // unpadded convolutions the loop has no per-lane address work at all).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && ROWS % 16 == 0, "tile/wave layout");
     constexpr int TILE = (BM + BN) * BK;              // floats per stage (unpadded)
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * GLDS_PRE_MAX : 4];   // pre-activation scale | shift (PRE instantiations: 1x1 convolutions only)
 
     vpho_conv_desc d = g.d;
     d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
@@ -450,6 +452,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
 
     const int nk = (g.K + BK - 1) / BK;
     const int sw = (li >> 1) & 7;                                   // (row >> 1) & 7 of every fragment row of this lane
+    // Pre-activation BN + LeakyReLU of the INPUT (encoding.Residual): the tiles travel global -> LDS untouched, the affine and
+    // the activation are applied to the A fragments as they are read (1x1 convolutions: k is the channel, no padding to keep
+    // zero).  The table is staged before the first fill: an ordinary load consumed in the loop would drain the fill queue.
+    if constexpr (PRE) {
+        for (int c = tid; c < d.Cin; c += NT) { pre_tab[c] = d.in_scale[c]; pre_tab[GLDS_PRE_MAX + c] = d.in_shift[c]; }
+        __syncthreads();
+    }
     if (UNI) fill_uni(0, 0); else fill(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -465,6 +474,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + ch);
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + ch);
+            if constexpr (PRE) {
+                const int c = kt * BK + (2 * kk + lh) * 4;          // channel of this lane's 4 consecutive k
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(pre_tab + c), sh = *reinterpret_cast<const f32x4*>(pre_tab + GLDS_PRE_MAX + c);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = a[i][e] * sc[e] + sh[e];
+                        a[i][e] = t > 0.f ? t : t * d.in_slope;
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -630,21 +650,27 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(splits - 1) * (double)g.w_zs);
     VPHO_REQUIRE(x_extent < 3.9e9 && w_extent < 3.9e9 && g.x_zs >= 0 && g.w_zs >= 0,
                  "vpho_conv2d_nhwc_f32: input (%.2f GB) and weights (%.2f GB) must each stay below 3.9 GB", x_extent * 1e-9, w_extent * 1e-9);
-    const bool glds = d.in_scale == nullptr && !no_glds;
     static const int no_uni = getenv("VPHO_CONV_NO_UNI") ? atoi(getenv("VPHO_CONV_NO_UNI")) : 0;          // tuning aid
     g.uni = (d.Cin % BK == 0 && d.pad_y >= 0 && d.pad_x >= 0 && !no_uni) ? 1 : 0;
+    // a pre-activation prologue rides on the direct-to-LDS kernel when the fragment's k is a plain channel index (1x1, unpadded,
+    // Cin a multiple of 32 and within the LDS table); everything else with a prologue takes the register-staged kernel
+    const bool pre_on_read = d.in_scale != nullptr && g.uni && d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin <= GLDS_PRE_MAX;
+    const bool glds = (d.in_scale == nullptr || pre_on_read) && !no_glds;
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288:
-            if (glds) launch(conv_igemm_glds_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128);
+            if (glds && pre_on_read) launch(conv_igemm_glds_kernel<128, 128, 4, 2, true>, 128, 128, 512, vpho::PROF_CONV128);
+            else if (glds) launch(conv_igemm_glds_kernel<128, 128, 4, 2>, 128, 128, 512, vpho::PROF_CONV128);
             else      launch(conv_igemm_kernel<128, 128, 4, 2, 1>, 128, 128, 512, vpho::PROF_CONV128);
             break;
         case 12864:
-            if (glds) launch(conv_igemm_glds_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128x64);
+            if (glds && pre_on_read) launch(conv_igemm_glds_kernel<128, 64, 4, 2, true>, 128, 64, 512, vpho::PROF_CONV128x64);
+            else if (glds) launch(conv_igemm_glds_kernel<128, 64, 4, 2>, 128, 64, 512, vpho::PROF_CONV128x64);
             else      launch(conv_igemm_kernel<128, 64, 4, 2, 1>, 128, 64, 512, vpho::PROF_CONV128x64);
             break;
         default:
-            if (glds) launch(conv_igemm_glds_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64);
+            if (glds && pre_on_read) launch(conv_igemm_glds_kernel<64, 64, 2, 2, true>, 64, 64, 256, vpho::PROF_CONV64);
+            else if (glds) launch(conv_igemm_glds_kernel<64, 64, 2, 2>, 64, 64, 256, vpho::PROF_CONV64);
             else      launch(conv_igemm_kernel<64, 64, 2, 2, 1>, 64, 64, 256, vpho::PROF_CONV64);
             break;
     }
