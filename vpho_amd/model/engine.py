@@ -117,6 +117,8 @@ class Engine:
         self.use_graphs = os.environ.get('VPHO_GRAPHS', '1') != '0'
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
+        self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
+        self._feat_side = None
         from .graphs import GraphedCall
         self._features_graph = GraphedCall(self.features, dev)
         self._aggregate_graph = GraphedCall(self._aggregate_from_tensors, dev)
@@ -140,26 +142,56 @@ class Engine:
         """FPN.forward.  ``windows`` = {'h': (RoiWindows, the same dilated by 1), 'o': ...}: the two stride-4 outputs are produced
         only on the pixels the RoIAligns read, as compact (rows, 256) matrices (vpho_roi_windows_i32); the lateral convolution and
         the top-down add of that level run on the dilated windows."""
+        tr = self._fpn_trunk(rgb)
+        with self._side():
+            obj = self._fpn_branch('o', tr, windows)
+        hand = self._fpn_branch('h', tr, windows)
+        self._join()
+        return [hand, obj]
+
+    # The hand and the object branch are independent between the shared stem / layer1 and the shared layer4, and again from the
+    # top-down path to the cross modules.  With VPHO_FEATURE_STREAMS=2 the object branch is issued on a second stream (a parallel
+    # branch of the captured HIP graph), so the many sub-chip launches of the two branches (16 x 16 and 8 x 8 maps, 32 x 32 RoI
+    # crops) overlap instead of queueing; same kernels, same results.
+    def _side(self):
+        import contextlib
+        if self.feature_streams < 2:
+            return contextlib.nullcontext()
+        if self._feat_side is None:
+            self._feat_side = torch.cuda.Stream(self.dev)
+        self._feat_side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._feat_side)
+
+    def _join(self):
+        if self.feature_streams >= 2 and self._feat_side is not None:
+            torch.cuda.current_stream().wait_stream(self._feat_side)
+
+    def _fpn_trunk(self, rgb):
         x = ops.nchw_to_nhwc(rgb, 4)
         c1 = ops.maxpool_nhwc(ops.conv2d_nhwc(x, *self.stem, kh=7, kw=7, stride=2, pad=3, out_slope=0.01), 3, 2, 1)
         c2 = self._layer(c1, 'layer1_h')
-        c3h, c3o = self._layer(c2, 'layer2_h'), self._layer(c2, 'layer2_o')
-        c4h, c4o = self._layer(c3h, 'layer3_h'), self._layer(c3o, 'layer3_o')
+        with self._side():
+            c3o = self._layer(c2, 'layer2_o')
+            c4o = self._layer(c3o, 'layer3_o')
+        c3h = self._layer(c2, 'layer2_h')
+        c4h = self._layer(c3h, 'layer3_h')
+        self._join()
         # shared layer4 (quirk Q6): both branches go through the same weights, so they run as ONE batch of 2N images
         # (twice the tiles per launch at 8x8 resolution, half the launches); convolutions are per-image, results unchanged
         n = c4h.shape[0]
         c5 = self._layer(torch.cat([c4h, c4o], 0), 'layer4_h')
-        c5h, c5o = c5[:n], c5[n:]
-        out = []
-        for br, c5, c4, c3 in (('h', c5h, c4h, c3h), ('o', c5o, c4o, c3o)):
-            p = ops.conv2d_nhwc(c5, *self.fpn[f'toplayer_{br}'])
-            for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2)):
-                # the stride-4 level: lateral convolution and top-down add only inside the windows dilated by the 3x3 halo
-                halo = windows[br][1] if (windows is not None and c is c2) else None
-                q = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None)
-                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
-            out.append(ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1, rows=None if windows is None else windows[br][0]))
-        return out
+        return dict(c2=c2, h=(c5[:n], c4h, c3h), o=(c5[n:], c4o, c3o))
+
+    def _fpn_branch(self, br, tr, windows):
+        c5, c4, c3 = tr[br]
+        c2 = tr['c2']
+        p = ops.conv2d_nhwc(c5, *self.fpn[f'toplayer_{br}'])
+        for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2)):
+            # the stride-4 level: lateral convolution and top-down add only inside the windows dilated by the 3x3 halo
+            halo = windows[br][1] if (windows is not None and c is c2) else None
+            q = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None)
+            p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
+        return ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1, rows=None if windows is None else windows[br][0])
 
     def _hm_head(self, x, h):
         y = ops.conv2d_nhwc(x, *h['c0'], kh=3, kw=3, pad=1)
@@ -213,20 +245,30 @@ class Engine:
             win_h = ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25)
             win_o = ops.roi_windows(bb_or, None, bs, fh, fw, 0.25)
             halo = {'h': ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25, dilate=1), 'o': ops.roi_windows(bb_or, None, bs, fh, fw, 0.25, dilate=1)}
-        hand_feat, obj_feat = self._fpn(rgb, None if win_h is None else {'h': (win_h, halo['h']), 'o': (win_o, halo['o'])})
+        windows = None if win_h is None else {'h': (win_h, halo['h']), 'o': (win_o, halo['o'])}
         eh, eo = self.enc['hand'], self.enc['obj']
         in_h = torch.zeros((bs, R, R, eh['cin_pad']), device=self.dev)
         in_o = torch.zeros((bs, R, R, eo['cin_pad']), device=self.dev)
+        grav = f32('gravity').view(bs, 3)
+        tr = self._fpn_trunk(rgb)
+        with self._side():                                                               # object branch
+            obj_feat = self._fpn_branch('o', tr, windows)
+            of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, win=win_o)
+            ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o, win=win_o)   # VPHO.py:138
+            hm_obj = self._hm_head(of_or_rect, self.hm['obj'])                           # (bs,64,64,27)
+            ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_obj, bb_o, bb_or, flip_w=left_u8), R, R, out=in_o, c_off=256)
+            enc_o, st_o = self._encoder(in_o, eo)
+            obj_heatmap = ops.nhwc_to_nchw(hm_obj)
+        hand_feat = self._fpn_branch('h', tr, windows)
         hf_hr = ops.roi_align_nhwc(hand_feat, bb_h, R, 0.25, win=win_h)
         ops.roi_align_nhwc(hand_feat, bb_hr, R, 0.25, out=in_h, win=win_h)
-        of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, win=win_o)
-        ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o, win=win_o)   # VPHO.py:138
         hm_hand = self._hm_head(hf_hr, self.hm['hand'])                                  # (bs,64,64,21)
-        hm_obj = self._hm_head(of_or_rect, self.hm['obj'])                               # (bs,64,64,27)
         ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_hand, bb_h, bb_hr), R, R, out=in_h, c_off=256)
-        ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_obj, bb_o, bb_or, flip_w=left_u8), R, R, out=in_o, c_off=256)
         enc_h, st_h = self._encoder(in_h, eh)
-        enc_o, st_o = self._encoder(in_o, eo)
+        hand_heatmap = ops.nhwc_to_nchw(hm_hand)
+        self._join()
+        with self._side():
+            tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
         hmn = self.head_mano
         h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01), *hmn['l2'], out_slope=0.01)
         pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose']), 16)                  # (bs,48)
@@ -234,15 +276,14 @@ class Engine:
         ctx = self.mano.shape(shape)
         ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
         reg_vert, reg_joint = self.mano.fk(pose, ctx, 1, True, ho3d)
-        grav = f32('gravity').view(bs, 3)
         tok_h = self._cross(self.cross['hand'], st_h[1], st_o[1], grav, left_u8)
-        tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
+        self._join()
         ph = self.phys
         scale = ops.linear(ops.linear(tok_h, *ph['s0'], out_slope=0.01), *ph['s2'])      # (bs*65,1)
         logits = ops.linear(ops.linear(tok_o, *ph['w0'], out_slope=0.01), *ph['w2'])     # (bs*65,8)
         force_local = ops.force_local(scale, logits, ph['anchor'], bs * 32, 32, 65, 0, 32).view(bs, 32, 3)
         return dict(hand_feat=hand_feat, obj_feat=obj_feat, roi_win_hand=win_h, roi_win_obj=win_o, hf_hr=hf_hr, enc_in_hand=in_h, enc_in_obj=in_o,
-                    hm_hand_nhwc=hm_hand, hm_obj_nhwc=hm_obj, hand_heatmap=ops.nhwc_to_nchw(hm_hand), obj_heatmap=ops.nhwc_to_nchw(hm_obj),
+                    hm_hand_nhwc=hm_hand, hm_obj_nhwc=hm_obj, hand_heatmap=hand_heatmap, obj_heatmap=obj_heatmap,
                     encoding_hand=enc_h, encoding_obj=enc_o, stage_hand=st_h[1], stage_obj=st_o[1], mano_pose=pose, mano_shape=shape,
                     mano_ctx=ctx, reg_hand_vert=reg_vert, reg_hand_joint=reg_joint, tok_hand=tok_h, tok_obj=tok_o, force_local=force_local)
 
