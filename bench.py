@@ -227,9 +227,9 @@ def main():
                                           'boxes': 'synth_batch: hand / object half-extent = focal * 0.11 / depth x U(0.75,1.15) / U(0.6,1.1), unchanged since round 1'},
                        'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2,false> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
+                         'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>') or pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
                          'timing': 'HIP events around every launch, in a separate instrumented repeat of the K steps',
                          'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
                          'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),
