@@ -288,19 +288,23 @@ struct HeadArgs {
     float coef;          // rhs = 0 - coef*score when rhs_mode, else score
     int rhs_mode;
     const RkCtl* ctl; int ctl_mode, stage, out_slot; float* kbase; long long n_el;
+    int nheads, full_tiles, tail_tiles;   // per head: 128-row tiles, then 32-row tail tiles (launch order: all full tiles first)
 };
 
-__global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) float smem[];
-    // [2] stages x ([256][32] weights | [128][32] activations), unpadded rows filled by global_load_lds with the 16-B chunk
-    // index XOR-swizzled by (row >> 1) & 7 (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2} and
-    // [2][128][4] partial outputs
+// One tile of the score head: ROWS = 32*RG hypotheses of head n.  TI = MFMA row tiles (32 hidden units each) per wave:
+//   TI = 4: 128 hypotheses, wave = (row group rg = wave & 3) x (hidden half hh = wave >> 2)         -- the ordinary tile
+//   TI = 1:  32 hypotheses, wave = hidden units 32*wave .. 32*wave+31 of the same 32 hypotheses      -- the tail tile
+// A launch whose tile count is not a multiple of the chip's workgroup slots ends in a round that keeps a few CUs busy for a whole
+// tile time (6 400 rows x 32 heads = 1 600 tiles on 512 slots: 3.125 rounds cost 4).  The launch therefore cuts the rows beyond the
+// last full round into quarter tiles that all CUs share: 1 536 ordinary tiles = 3 rounds exactly, then 256 tail tiles, one per CU.
+template <int TI>
+__device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
+    constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = TI == 4 ? 2 : 8;
     constexpr int STAGE = (256 + 128) * HB_K;
     float* Eb = smem + 2 * STAGE;
     float* Ob = Eb + 256 * 4;
-    const int n = blockIdx.y, r0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
-    const int rg = wave & 3, hh = wave >> 2;            // wave = 32 hypotheses (rg) x 128 hidden units (hh)
+    const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;   // hidden base of the wave = 32*TI*hh
     // one wave instruction fills 64 x 16 B = RPW whole tile rows; chunk swizzle f(row) = (row >> SW_SHIFT) & (CPR-1) keeps
     // the 16 lanes of every ds_read_b128 group on distinct 16-B slots of a 256-B bank row (rows of 128 B: 2 per bank row,
     // rows of 64 B: 4 per bank row)
@@ -309,7 +313,6 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     const int lrow = wave * RPW + lane / CPR;           // tile row this lane fills (per pass: + RPP*j)
     const int kq = (lane % CPR) ^ ((lrow >> SW_SHIFT) & (CPR - 1));      // logical 16-B chunk this lane fetches
     const float* Wg = a.w1p + (long long)n * 256 * 256;
-    if (ctl_skip(a.ctl, a.ctl_mode)) return;
 
     if (tid < 256) {   // epilogue table
         f32x4 e;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     }
 
     // tiles through buffer resources: per-lane byte offsets are loop constants, the k advance is the instruction's scalar offset;
-    // hypothesis rows beyond R carry an out-of-range offset (the hardware writes zeros)
+    // hypothesis rows beyond R (or beyond the tile) carry an out-of-range offset (the hardware writes zeros)
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wg), 0, 256 * 256 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p2), 0, 0xFFFFFFF0u, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -329,8 +332,8 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     for (int j = 0; j < 256 / RPP; ++j) woff[j] = ((lrow + RPP * j) * 256 + 4 * kq) * 4;
 #pragma unroll
     for (int j = 0; j < 128 / RPP; ++j) {
-        const int r = r0 + lrow + RPP * j;
-        poff[j] = r < a.R ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
+        const int lr = lrow + RPP * j, r = r0 + lr;
+        poff[j] = (r < a.R && lr < ROWS) ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
     }
     auto fill = [&](int buf, int kt) {
         float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
@@ -342,9 +345,9 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
         for (int j = 0; j < 128 / RPP; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)(Ps + RPP * j * HB_K), 16, poff[j], koff, 0, 0);
     };
 
-    f32x16 acc[4];
+    f32x16 acc[TI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -358,20 +361,20 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     fill(1, 1);
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        const float* As = smem + buf * STAGE + (hh * 128 + li) * HB_K;
+        const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
         const float* Bs = smem + buf * STAGE + 256 * HB_K + (rg * 32 + li) * HB_K;
-        f32x4 b, av[4];
+        f32x4 b, av[TI];
         auto frags = [&](int kk) {
             const int ch = ((2 * kk + lh) ^ sw) * 4;
             b = *reinterpret_cast<const f32x4*>(Bs + ch);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_K + ch);
+            for (int i = 0; i < TI; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_K + ch);
         };
         auto mfmas = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TI; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b[q], acc[i], 0, 0, 0);
         };
 #pragma unroll
@@ -383,17 +386,17 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     }
     __syncthreads();
 
-    // epilogue: hidden unit j = 128*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
+    // epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
     const int lrow_out = rg * 32 + li;
     const int row = r0 + lrow_out;
     const bool live = row < a.R;
     const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int j = 128 * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int j = 32 * TI * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
             const f32x4 t = *reinterpret_cast<const f32x4*>(Eb + j * 4);
             float h = acc[i][e] + cim[j] + t[0];
             h = h > 0.f ? h : 0.f;
@@ -404,11 +407,11 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (lh == 0) {
-        float* ob = Ob + (hh * 128 + lrow_out) * 4;
+        float* ob = Ob + (hh * ROWS + lrow_out) * 4;
         ob[0] = o0; ob[1] = o1; ob[2] = o2;
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < ROWS) {
         const int orow = r0 + tid;
         float inv_std = a.inv_std_den, coef = a.coef;
         float* outp = a.out;
@@ -417,18 +420,35 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
             outp = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
         }
         if (orow < a.R) {
-            const float* p0 = Ob + tid * 4;
-            const float* p1 = Ob + (128 + tid) * 4;
             int nans = 0;
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) {
-                float sv = ((p0[dd] + p1[dd]) + a.b2[n * 3 + dd]) / inv_std;
+                float acc2 = Ob[tid * 4 + dd];                            // partial sums of the hidden slices, ascending
+#pragma unroll
+                for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + tid) * 4 + dd];
+                float sv = (acc2 + a.b2[n * 3 + dd]) / inv_std;
                 if (sv != sv) { sv = 0.f; ++nans; }
                 if (a.rhs_mode) sv = 0.f - coef * sv;
                 outp[(long long)orow * a.D + n * 3 + dd] = sv;
             }
             if (nans) atomicAdd(a.nan_count, nans);
         }
+    }
+}
+
+__global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    // [2] stages x ([256][HB_K] weights | [128][HB_K] activations), unpadded rows filled by global_load_lds with the 16-B chunk
+    // index XOR-swizzled (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2} and 1024 floats of partial outputs
+    if (ctl_skip(a.ctl, a.ctl_mode)) return;
+    // (measured no better: dispatching the tail tiles first, next to ordinary tiles, 233 vs 230 us; giving each XCD whole heads of
+    // tail tiles, 231 us -- a tail tile is bound by its chain of 16 barrier-separated weight stages, not by where the weights are)
+    const int b = blockIdx.x, n_full = a.nheads * a.full_tiles;
+    if (b < n_full) {
+        head_tile<4>(a, smem, b / a.full_tiles, (b % a.full_tiles) * 128);
+    } else {
+        const int q = b - n_full;
+        head_tile<1>(a, smem, q / a.tail_tiles, a.full_tiles * 128 + (q % a.tail_tiles) * 32);
     }
 }
 
@@ -823,9 +843,26 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_opt_in = true;
     }
+    // Tile plan: 128-row tiles; when the last round of the launch would be less than half full, the rows beyond the last full round
+    // become 32-row tail tiles (see head_tile).  VPHO_HEAD_TAIL=0: ordinary tiles only.
+    static const int tail_on = getenv("VPHO_HEAD_TAIL") ? atoi(getenv("VPHO_HEAD_TAIL")) : 1;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0; hipDeviceProp_t prop;
+        VPHO_HIP(hipGetDevice(&dev));
+        VPHO_HIP(hipGetDeviceProperties(&prop, dev));
+        slots = 2 * prop.multiProcessorCount;               // two 57 KB workgroups per CU
+    }
+    const int tiles = (int)((c.R + 127) / 128), nheads = c.w->nheads;
+    a.nheads = nheads; a.full_tiles = tiles; a.tail_tiles = 0;
+    const long long total = (long long)tiles * nheads;
+    if (tail_on && total > slots && total % slots != 0 && (total % slots) * 2 < slots) {
+        const int fp = (int)(total / slots * slots / nheads);
+        if (fp >= 1 && fp < tiles) { a.full_tiles = fp; a.tail_tiles = (int)((c.R - 128ll * fp + 31) / 32); }
+    }
     {
         vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
-        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)((c.R + 127) / 128), c.w->nheads), dim3(512), lds, c.s, a);
+        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)(nheads * (a.full_tiles + a.tail_tiles))), dim3(512), lds, c.s, a);
     }
     return vpho::check_launch("score_head_kernel");
 }
