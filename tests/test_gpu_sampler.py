@@ -31,6 +31,27 @@ def test_score_matches_oracle(sd, nets, name, D):
         assert (got - ref).abs().max().item() <= 2e-5 * scale, (t, (got - ref).abs().max().item(), scale)
 
 
+def test_score_tail_tiles_match_oracle(sd, nets):
+    """6 387 rows x 32 heads = 1 600 tiles on 512 workgroup slots: the launch runs 48 ordinary tiles per head and the remaining 243
+    rows as 32-row tail tiles (the last one ragged).  Rows of every kind of tile against the oracle, and against a launch of
+    the same rows that is small enough to take ordinary tiles only."""
+    from oracle import nets as N
+    bs, S = 3, 2129
+    R = bs * S
+    feat, x = seeded((bs, 1024), 50, 0.3), seeded((R, 96), 51, 1.5)
+    got = nets['hand'].score(feat.cuda(), x.cuda(), 0.3, S).cpu()
+    assert torch.isfinite(got).all()
+    pick = torch.cat([torch.arange(0, 64), torch.arange(6100, 6150), torch.arange(6144 - 8, R)])      # first tiles, last full tile, all tail rows
+    ref = N.denoiser(sd, 'denoiser_hand', feat[pick // S], x[pick], torch.full((len(pick), 1), 0.3))
+    scale = ref.abs().max().item()
+    assert (got[pick] - ref).abs().max().item() <= 2e-5 * scale
+    # the tail rows again as the head of a 2-image launch of 250 rows each (500 rows: ordinary tiles only)
+    rows = torch.arange(R - 250, R)
+    assert int(rows[0]) // S == int(rows[-1]) // S == 2
+    small = nets['hand'].score(feat[[2, 2]].cuda(), torch.cat([x[rows], x[rows]]).cuda(), 0.3, 250).cpu()[:250]
+    assert (small - got[rows]).abs().max().item() <= 2e-6 * scale
+
+
 @pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
 def test_ode_sampler_matches_oracle_and_reference_fixture(sd, nets, name, D):
     """Same run as the reference fixture (tests/golden/make_golden.py: 8 rows, 5 stamps, T0=0.65, seed 5)."""
