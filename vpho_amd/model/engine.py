@@ -118,6 +118,7 @@ class Engine:
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
+        self.serial_samplers = False            # True: object sampler after the hand sampler on one stream (exclusive kernel timings)
         self._feat_side = None
         from .graphs import GraphedCall
         self._features_graph = GraphedCall(self.features, dev)
@@ -402,7 +403,7 @@ class Engine:
                 with torch.cuda.device(self.dev), torch.cuda.stream(obj_stream):
                     return self.score_obj.sample(f['encoding_obj'], init_o, S, T0, steps, xs_f64=True, x_f64=True)
 
-            concurrent = os.environ.get('VPHO_SERIAL_SAMPLERS', '0') != '1'
+            concurrent = os.environ.get('VPHO_SERIAL_SAMPLERS', '0') != '1' and not self.serial_samplers
             fut = self._obj_worker.submit(run_obj) if concurrent else None
             # hand hypotheses
             xs_h, x_h, st_h = self.score_hand.sample(f['encoding_hand'], init_h, S, T0, steps, xs_f64=False, x_f64=False)
