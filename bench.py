@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 FEATURE_GFLOP_PER_IMAGE = 37.09
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk_kernel', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
@@ -45,6 +46,8 @@ def parse():
     p.add_argument('--cpu_images', type=int, default=64, help='images of the oracle / parity leg (one batch)')
     p.add_argument('--weights', choices=('conditioned', 'random'), default='conditioned', help='synthetic weight set (vpho_amd.synth)')
     p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
+    p.add_argument('--score_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32',
+                   help='score head products: f32 = fp32 MFMA (default, the path parity is stated on); bf16x6 / bf16x9 = opt-in split-bf16 products with fp32 accumulation')
     p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
@@ -96,6 +99,8 @@ def main():
     from vpho_amd.model.engine import Engine
     if args.no_roi_window:
         os.environ['VPHO_ROI_WINDOW'] = '0'                # read by every execution plan (this one and the pipeline slots')
+    score_mfma = os.environ.get('VPHO_SCORE_MFMA', 'f32') if args.score_mfma == 'f32' else args.score_mfma
+    os.environ['VPHO_SCORE_MFMA'] = score_mfma             # read when an execution plan packs its score networks
     model._engine = Engine(model)
     eng = model._engine
     # share of the stride-4 FPN pixels the RoIAligns of a batch can read (= what the two smoothing convolutions compute)
@@ -222,17 +227,20 @@ def main():
         conv_tf = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
         head_tf = head['flops'] / (head['total_ms'] * 1e-3) / 1e12 if head['total_ms'] > 0 else 0.0
         head_excl_tf = head_excl['flops'] / (head_excl['total_ms'] * 1e-3) / 1e12 if head_excl['total_ms'] > 0 else 0.0
+        # fp32-equivalent peak of the score head: the fp32 MFMA peak, or the dense bf16 peak over the 6 / 9 products per fp32 product
+        head_peak = FP32_MFMA_PEAK_TFLOPS if score_mfma == 'f32' else BF16_MFMA_PEAK_TFLOPS / int(score_mfma[-1])
         result = {
             'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if score_mfma == 'f32' else f'f32 storage and accumulation; score-head products as {score_mfma} split-bf16 (opt-in, NOT the default)',
+            'data': 'synthetic',
             'config': {'workload': 'vpho_net.forward(mode=predict), ' + ('README eval config (BASELINE.json configs[1])' if
                                     (args.bs, args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj) == (64, 100, 50, 30, 10)
                                     else 'non-default config (see the keys below)'),
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
-                       'pipeline_depth': args.pipeline,
+                       'pipeline_depth': args.pipeline, 'score_mfma': score_mfma,
                        'fpn_roi_window': {'enabled': bool(eng.roi_window), 'what': 'the last convolution of each FPN branch is computed only on the pixels its '
                                           'RoIAligns read (VPHO.py:126-129 are the maps\' only readers); bit-identical results, --no_roi_window computes the full maps',
                                           'pixel_share_hand_obj_per_batch': roi_frac,
@@ -252,11 +260,11 @@ def main():
                          'avg_launch_us': conv['total_ms'] * 1e3 / max(conv['launches'], 1),
                          'flop_per_launch_avg': conv['flops'] / max(conv['launches'], 1),
                          'kernel_ms_per_step': conv['total_ms'] / max(args.steps, 1),
-                         'score_head': {'achieved': head_tf, 'frac': head_tf / FP32_MFMA_PEAK_TFLOPS,
+                         'score_head': {'achieved': head_tf, 'frac': head_tf / head_peak, 'peak': head_peak,
                                         'kernel_ms_per_step': head['total_ms'] / max(args.steps, 1),
                                         'launches_per_step': head['launches'] / max(args.steps, 1),
                                         'note': 'hand and object solves run concurrently: these durations span the other solve\'s kernels',
-                                        'samplers_serialised': {'achieved': head_excl_tf, 'frac': head_excl_tf / FP32_MFMA_PEAK_TFLOPS,
+                                        'samplers_serialised': {'achieved': head_excl_tf, 'frac': head_excl_tf / head_peak,
                                                                 'avg_launch_us': head_excl['total_ms'] * 1e3 / max(head_excl['launches'], 1),
                                                                 'what': 'same kernels, object solve after the hand solve: exclusive durations (hand 32 heads + object 3 heads, averaged over launches by time)'}},
                          'feature_path_gflop_per_image_ref': FEATURE_GFLOP_PER_IMAGE},

@@ -96,6 +96,11 @@ int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
 typedef struct {
     int D, Dp, nheads;
     const float *t_W, *t_w, *t_b, *pe0_w, *pe0_b, *pe2_w, *pe2_b, *w1_t, *w1_p, *w1_f, *b1, *w2, *b2;
+    /* Optional, opt-in (NULL / 0 = the fp32-MFMA score head, the default and the path parity is stated on): w1_p as three bf16
+     * planes [nheads][3][256][256] with w1_p = plane0 + plane1 + plane2 exactly (plane0 = bf16(w), plane1 = bf16(w - plane0), ...),
+     * split_terms = 6 or 9 cross products per fp32 product on the bf16 matrix cores, fp32 accumulation (csrc/score_ode.hip). */
+    const void* w1_p_split;
+    int split_terms;
 } vpho_score_weights;
 
 /* bytes of scratch `vpho_score_eval` / `vpho_ode_sample` need for R = bs*S rows */

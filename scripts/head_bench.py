@@ -8,8 +8,9 @@ from vpho_amd import ops
 a = synthetic_assets(0); m = vpho_net(a); sd = synth_state_dict(m, 1)
 dev = 'cuda'
 key = [k for k in ops.PROF_CLASSES if 'head' in k][0]
+import os
 for name, D in (('hand', 96), ('obj', 9)):
-    net = ops.ScoreNet(sd, f'denoiser_{name}', dev)
+    net = ops.ScoreNet(sd, f'denoiser_{name}', dev)       # VPHO_SCORE_MFMA=bf16x6|bf16x9 selects the split-bf16 head
     bs, S = 64, 100
     feat = torch.randn(bs, 1024, device=dev) * 0.3
     x = torch.randn(bs * S, D, device=dev)

@@ -289,6 +289,7 @@ struct HeadArgs {
     int rhs_mode;
     const RkCtl* ctl; int ctl_mode, stage, out_slot; float* kbase; long long n_el;
     int nheads, full_tiles, tail_tiles;   // per head: 128-row tiles, then 32-row tail tiles (launch order: all full tiles first)
+    const unsigned short* w1p_split;      // [nheads][3][256][256] bf16 planes of w1p (split-bf16 kernel only)
 };
 
 // One tile of the score head: ROWS = 32*RG hypotheses of head n.  TI = MFMA row tiles (32 hidden units each) per wave:
@@ -449,6 +450,196 @@ __global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
     } else {
         const int q = b - n_full;
         head_tile<1>(a, smem, q / a.tail_tiles, a.full_tiles * 128 + (q % a.tail_tiles) * 32);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- score head, split-bf16 products (opt-in)
+// VPHO_SCORE_MFMA=bf16x6 | bf16x9 (not the default; the fp32-MFMA kernel above is the product path and the one every parity claim is
+// made on).  gfx950 multiplies bf16 on the matrix cores 16 x faster than fp32, and a product of two fp32 numbers can be assembled
+// from bf16 products without giving up fp32 accuracy: every fp32 x is EXACTLY x = h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m) (3 x 8 significant bits), each bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32 like the
+// fp32 instruction does.  bf16x9 adds all nine cross products (nothing dropped: same operands, same accumulator type, 9/16 of the
+// matrix-core time); bf16x6 drops m*l, l*m, l*l, each below 2^-24 |x||y| -- the size of one fp32 rounding.  The weights are split
+// once on the host ([n][3][256][256] bf16), the activations (P2, fp32 in LDS) as the fragments are read: 8 values -> 3 x 8 bf16 with
+// v_cvt_pk_bf16_f32 + two subtractions per level, issued in the shadow of the MFMAs.  Error study: scripts/split_error_study.py.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int SP_K = 16;                                    // k per LDS stage = one 32x32x16 MFMA step
+
+__device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        const __bf16 hb = (__bf16)x;
+        const float r1 = x - (float)hb;                     // exact: |r1| <= ulp_bf16(x) / 2 needs <= 16 bits
+        const __bf16 mb = (__bf16)r1;
+        const float r2 = r1 - (float)mb;                    // exact, <= 8 significant bits left
+        h[e] = hb; m[e] = mb; l[e] = (__bf16)r2;
+    }
+}
+
+template <int TI, int TERMS>
+__device__ __forceinline__ void head_tile_split(const HeadArgs& a, float* smem, const int n, const int r0) {
+    constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = TI == 4 ? 2 : 8;
+    constexpr int W_PLANE = 256 * SP_K / 2;                 // floats per plane and stage ([256][16] bf16)
+    constexpr int STAGE = 3 * W_PLANE + 128 * SP_K;         // floats per stage: three weight planes | [128][16] fp32 activations
+    float* Eb = smem + 2 * STAGE;
+    float* Ob = Eb + 256 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+    const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;
+    if (tid < 256) {   // epilogue table
+        f32x4 e;
+        e[0] = a.ct[n * 256 + tid];
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(a.w2 + (long long)(n * 256 + tid) * 4);
+        e[1] = w2[0]; e[2] = w2[1]; e[3] = w2[2];
+        *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
+    }
+    // weight planes: one wave instruction = 64 x 16 B = 32 rows of 32 B (16 bf16): 8 waves fill the 256 rows of a plane in one
+    // pass; the two 16-B chunks of row r are exchanged when (r >> 3) & 1, so that 16 consecutive rows read at one logical chunk hit
+    // 16 distinct 16-B slots of the two 256-B bank rows they span
+    const int wrow = wave * 32 + (lane >> 1);
+    const int wchunk = (lane & 1) ^ ((wrow >> 3) & 1);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(a.w1p_split) + (long long)n * 3 * 256 * 256, 0, 3 * 256 * 256 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p2), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int woff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) woff[p] = ((p * 256 + wrow) * 256 + wchunk * 8) * 2;
+    // activations: [128][16] fp32, rows of 64 B (4 chunks), chunk index XOR (row >> 2) & 3 (as in head_tile with HB_K = 16)
+    const int prow = wave * 16 + (lane >> 2);
+    const int pkq = (lane & 3) ^ ((prow >> 2) & 3);
+    const int pr_row = r0 + prow;
+    const int poff = (pr_row < a.R && prow < ROWS) ? (int)(((unsigned)pr_row * 256u + 4u * (unsigned)pkq) * 4u) : -1;
+    auto fill = [&](int buf, int kt) {
+        float* Ws = smem + buf * STAGE + wave * 32 * (SP_K / 2);
+        float* Ps = smem + buf * STAGE + 3 * W_PLANE + wave * 16 * SP_K;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Ws + p * W_PLANE), 16, woff[p], kt * SP_K * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)Ps, 16, poff, kt * SP_K * 4, 0, 0);
+    };
+
+    f32x16 acc[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    constexpr int NK = 256 / SP_K;
+    const int a_sw = (li >> 3) & 1, b_sw = (li >> 2) & 3;
+    // Register double buffer: the fragments of stage kt+1 are read from LDS and split while the MFMAs of stage kt issue (its fill
+    // landed before barrier kt), one tile's three weight planes per group of products; the barrier of stage kt only orders "every
+    // wave has read stage kt" (done one iteration earlier) before the refill of that buffer.
+    struct Frag { bf16x8 a[TI][3]; bf16x8 bh, bm, bl; };
+    auto read_b = [&](int buf, Frag& f) {
+        const float* Bs = smem + buf * STAGE + 3 * W_PLANE + (rg * 32 + li) * SP_K;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(Bs + ((2 * lh) ^ b_sw) * 4);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(Bs + ((2 * lh + 1) ^ b_sw) * 4);
+        split3(x0, x1, f.bh, f.bm, f.bl);
+    };
+    auto read_a = [&](int buf, int i, Frag& f) {
+        const float* Wst = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            f.a[i][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(Wst + p * W_PLANE) + (hh * 32 * TI + 32 * i + li) * SP_K + ((lh ^ a_sw) * 8));
+    };
+    auto products = [&](int i, const Frag& f) {
+        // small terms first
+        if (TERMS == 9) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.bl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.bm, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.bl, acc[i], 0, 0, 0);
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.bm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.bm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.bh, acc[i], 0, 0, 0);
+    };
+    Frag fr[2];
+    fill(0, 0);
+    fill(1, 1);
+    __syncthreads();
+    read_b(0, fr[0]);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) read_a(0, i, fr[0]);
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();                                    // all waves hold stage kt in registers; fill(kt+1) has landed
+        if (kt + 2 < NK) fill(buf, kt + 2);
+        Frag& cur = fr[kt & 1];
+        Frag& nxt = fr[(kt + 1) & 1];
+        if (kt + 1 < NK) read_b(buf ^ 1, nxt);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (kt + 1 < NK) read_a(buf ^ 1, i, nxt);
+            products(i, cur);
+        }
+    }
+    __syncthreads();
+
+    // epilogue: identical to head_tile (same accumulator layout)
+    const int lrow_out = rg * 32 + li;
+    const int row = r0 + lrow_out;
+    const bool live = row < a.R;
+    const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * TI * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Eb + j * 4);
+            float h = acc[i][e] + cim[j] + t[0];
+            h = h > 0.f ? h : 0.f;
+            o0 += h * t[1]; o1 += h * t[2]; o2 += h * t[3];
+        }
+    }
+    o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 32);
+    if (lh == 0) {
+        float* ob = Ob + (hh * ROWS + lrow_out) * 4;
+        ob[0] = o0; ob[1] = o1; ob[2] = o2;
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        const int orow = r0 + tid;
+        float inv_std = a.inv_std_den, coef = a.coef;
+        float* outp = a.out;
+        if (a.ctl && a.ctl_mode == 1) {
+            inv_std = a.ctl->inv_std[a.stage]; coef = a.ctl->coef[a.stage];
+            outp = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
+        }
+        if (orow < a.R) {
+            int nans = 0;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                float acc2 = Ob[tid * 4 + dd];
+#pragma unroll
+                for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + tid) * 4 + dd];
+                float sv = (acc2 + a.b2[n * 3 + dd]) / inv_std;
+                if (sv != sv) { sv = 0.f; ++nans; }
+                if (a.rhs_mode) sv = 0.f - coef * sv;
+                outp[(long long)orow * a.D + n * 3 + dd] = sv;
+            }
+            if (nans) atomicAdd(a.nan_count, nans);
+        }
+    }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void score_head_split_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    if (ctl_skip(a.ctl, a.ctl_mode)) return;
+    const int b = blockIdx.x, n_full = a.nheads * a.full_tiles;
+    if (b < n_full) {
+        head_tile_split<4, TERMS>(a, smem, b / a.full_tiles, (b % a.full_tiles) * 128);
+    } else {
+        const int q = b - n_full;
+        head_tile_split<1, TERMS>(a, smem, q / a.tail_tiles, a.full_tiles * 128 + (q % a.tail_tiles) * 32);
     }
 }
 
@@ -859,6 +1050,21 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     if (tail_on && total > slots && total % slots != 0 && (total % slots) * 2 < slots) {
         const int fp = (int)(total / slots * slots / nheads);
         if (fp >= 1 && fp < tiles) { a.full_tiles = fp; a.tail_tiles = (int)((c.R - 128ll * fp + 31) / 32); }
+    }
+    a.w1p_split = (const unsigned short*)c.w->w1_p_split;
+    if (c.w->w1_p_split && (c.w->split_terms == 6 || c.w->split_terms == 9)) {
+        const size_t slds = (size_t)(2 * (3 * 256 * SP_K / 2 + 128 * SP_K) + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+        static bool split_opt_in = false;
+        if (!split_opt_in) {
+            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_split_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_split_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            split_opt_in = true;
+        }
+        vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
+        const dim3 grid((unsigned)(nheads * (a.full_tiles + a.tail_tiles)));
+        if (c.w->split_terms == 6) hipLaunchKernelGGL(score_head_split_kernel<6>, grid, dim3(512), slds, c.s, a);
+        else                       hipLaunchKernelGGL(score_head_split_kernel<9>, grid, dim3(512), slds, c.s, a);
+        return vpho::check_launch("score_head_split_kernel");
     }
     {
         vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));

@@ -148,7 +148,7 @@ def linear(x, w, bias=None, out_slope=1.0, out=None):
 class ScoreWeights(C.Structure):
     _fields_ = [('D', C.c_int), ('Dp', C.c_int), ('nheads', C.c_int)] + \
                [(k, C.c_void_p) for k in ('t_W', 't_w', 't_b', 'pe0_w', 'pe0_b', 'pe2_w', 'pe2_b', 'w1_t', 'w1_p',
-                                          'w1_f', 'b1', 'w2', 'b2')]
+                                          'w1_f', 'b1', 'w2', 'b2')] + [('w1_p_split', C.c_void_p), ('split_terms', C.c_int)]
 
 
 class OdeStats(C.Structure):
@@ -192,6 +192,21 @@ class ScoreNet:
             setattr(self.c, k, v.data_ptr())
         self.device = device
         self._ws = None
+        self.set_split(os.environ.get('VPHO_SCORE_MFMA', 'f32'))
+
+    def set_split(self, mode):
+        """'f32' (default: fp32 MFMA) | 'bf16x6' | 'bf16x9': the score head's 256 x 256 layer as split-bf16 products (opt-in)"""
+        terms = {'f32': 0, 'bf16x6': 6, 'bf16x9': 9}[mode]
+        if terms and 'w1_p_split' not in self.tensors:
+            w = self.tensors['w1_p'].view(self.nheads, 256, 256)
+            h = w.to(torch.bfloat16)
+            m = (w - h.float()).to(torch.bfloat16)
+            l = (w - h.float() - m.float()).to(torch.bfloat16)
+            assert torch.equal(h.float() + m.float() + l.float(), w)       # three 8-bit pieces hold an fp32 exactly
+            self.tensors['w1_p_split'] = torch.stack([h, m, l], 1).contiguous()      # (n, 3, 256, 256)
+        self.c.w1_p_split = self.tensors['w1_p_split'].data_ptr() if terms else None
+        self.c.split_terms = terms
+        self.split_mode = mode
 
     def workspace(self, bs, S):
         need = lib.vpho_score_workspace_bytes(C.byref(self.c), bs, S)
