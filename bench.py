@@ -48,6 +48,7 @@ def parse():
     p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
     p.add_argument('--score_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32',
                    help='score head products: f32 = fp32 MFMA (default, the path parity is stated on); bf16x6 / bf16x9 = opt-in split-bf16 products with fp32 accumulation')
+    p.add_argument('--conv_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32', help='the same switch for the convolutions of the feature path (opt-in)')
     p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
@@ -101,6 +102,8 @@ def main():
         os.environ['VPHO_ROI_WINDOW'] = '0'                # read by every execution plan (this one and the pipeline slots')
     score_mfma = os.environ.get('VPHO_SCORE_MFMA', 'f32') if args.score_mfma == 'f32' else args.score_mfma
     os.environ['VPHO_SCORE_MFMA'] = score_mfma             # read when an execution plan packs its score networks
+    conv_mfma = os.environ.get('VPHO_CONV_MFMA', 'f32') if args.conv_mfma == 'f32' else args.conv_mfma
+    os.environ['VPHO_CONV_MFMA'] = conv_mfma
     model._engine = Engine(model)
     eng = model._engine
     # share of the stride-4 FPN pixels the RoIAligns of a batch can read (= what the two smoothing convolutions compute)
@@ -229,26 +232,28 @@ def main():
         head_excl_tf = head_excl['flops'] / (head_excl['total_ms'] * 1e-3) / 1e12 if head_excl['total_ms'] > 0 else 0.0
         # fp32-equivalent peak of the score head: the fp32 MFMA peak, or the dense bf16 peak over the 6 / 9 products per fp32 product
         head_peak = FP32_MFMA_PEAK_TFLOPS if score_mfma == 'f32' else BF16_MFMA_PEAK_TFLOPS / int(score_mfma[-1])
+        conv_peak = FP32_MFMA_PEAK_TFLOPS if conv_mfma == 'f32' else BF16_MFMA_PEAK_TFLOPS / int(conv_mfma[-1])
         result = {
             'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if score_mfma == 'f32' else f'f32 storage and accumulation; score-head products as {score_mfma} split-bf16 (opt-in, NOT the default)',
+            'dtype': 'f32' if (score_mfma, conv_mfma) == ('f32', 'f32') else f'f32 storage and accumulation; products as split-bf16 (score head {score_mfma}, convolutions {conv_mfma}; opt-in, NOT the default)',
             'data': 'synthetic',
             'config': {'workload': 'vpho_net.forward(mode=predict), ' + ('README eval config (BASELINE.json configs[1])' if
                                     (args.bs, args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj) == (64, 100, 50, 30, 10)
                                     else 'non-default config (see the keys below)'),
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
-                       'pipeline_depth': args.pipeline, 'score_mfma': score_mfma,
+                       'pipeline_depth': args.pipeline, 'score_mfma': score_mfma, 'conv_mfma': conv_mfma,
                        'fpn_roi_window': {'enabled': bool(eng.roi_window), 'what': 'the last convolution of each FPN branch is computed only on the pixels its '
                                           'RoIAligns read (VPHO.py:126-129 are the maps\' only readers); bit-identical results, --no_roi_window computes the full maps',
                                           'pixel_share_hand_obj_per_batch': roi_frac,
                                           'boxes': 'synth_batch: hand / object half-extent = focal * 0.11 / depth x U(0.75,1.15) / U(0.6,1.1), unchanged since round 1'},
                        'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2,false> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)', 'achieved': conv_tf,
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tf / FP32_MFMA_PEAK_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2,false> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)' if conv_mfma == 'f32'
+                         else f'conv_igemm_split_kernel<128,128,4,2,{conv_mfma[-1]}> (split-bf16 products, opt-in)', 'achieved': conv_tf,
+                         'peak': conv_peak, 'unit': 'TFLOP/s', 'frac': conv_tf / conv_peak,
                          'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>') or pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
                          'timing': 'HIP events around every launch, in a separate instrumented repeat of the K steps',
                          'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),

@@ -71,6 +71,11 @@ typedef struct {
     const int* row_count;
     int rows_hint;
     int rows_scatter;                /* 1: keep y's (n, oy, ox) layout and write only the listed pixels (the rest of y is untouched) */
+    /* Optional, opt-in (NULL / 0 = fp32 MFMA, the default and the path parity is stated on): w as three bf16 planes [3][Cout][K]
+     * with w = plane0 + plane1 + plane2 exactly, plane_terms = 6 or 9 bf16 products per fp32 product, fp32 accumulation.  Taken for
+     * Cin % 16 == 0, no prologue affine, no splits / gate, 16-byte addressable output rows; other shapes run the fp32 kernels. */
+    const void* w_planes;
+    int plane_terms;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);

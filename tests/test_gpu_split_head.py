@@ -44,8 +44,8 @@ def test_split_bf16_head_is_as_accurate_as_the_fp32_mfma_head(sd, name, D, capsy
                   f'; max deviation from the fp32 kernel: x9 {dev["bf16x9"]:.2e}, x6 {dev["bf16x6"]:.2e}', end='')
 
 
-def test_predict_with_split_head_agrees_with_the_default(model_cpu, assets):
-    """vpho_net.forward(mode='predict') with the split-bf16 score heads against the default engine on the same inputs and prior draws:
+def test_predict_with_split_products_agrees_with_the_default(model_cpu, assets):
+    """vpho_net.forward(mode='predict') with split-bf16 score heads AND convolutions against the default engine on the same inputs and prior draws:
     same step sequence of both solves, outputs within the north-star 1e-3 (observed ~1e-5)."""
     import copy
     from vpho_amd.configs.args import cfg
@@ -64,10 +64,64 @@ def test_predict_with_split_head_agrees_with_the_default(model_cpu, assets):
         for mode in ('bf16x6', 'bf16x9'):
             eng.score_hand.set_split(mode)
             eng.score_obj.set_split(mode)
+            eng.conv_terms = int(mode[-1])                    # the convolutions of the feature path too
             out = eng.predict(data, nh, no)
+            for k in ('hand_heatmap', 'obj_heatmap', 'reg_hand_joint', 'force_local'):
+                d = (out[k].double() - ref[k].double()).abs().max().item()
+                assert 0 < d < 1e-4 * max(1.0, ref[k].abs().max().item()), (mode, k, d)      # the split kernels did run, and agree
             for k in ('hand_ode', 'obj_ode'):
                 assert (eng.last_info[k]['nfev'], [s[3] for s in eng.last_info[k]['steps']]) == info[k]
             for k in ('diff_final_hand_mano', 'diff_final_obj_6d', 'diff_final_hand_joint'):
                 assert (out[k].double() - ref[k].double()).abs().max().item() < 1e-3, (mode, k)
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+
+
+CONV_CASES = [  # N, H, W, Cin, Cout, k, stride, pad  -> all three tile classes, padding, stride 2, ragged pixel counts, K = 16
+    (16, 32, 32, 128, 128, 3, 1, 1), (8, 64, 64, 64, 256, 1, 1, 0), (64, 16, 16, 256, 256, 3, 1, 1), (4, 31, 29, 32, 64, 3, 2, 1),
+    (2, 8, 8, 512, 128, 1, 1, 0), (3, 17, 17, 16, 48, 3, 1, 1), (64, 8, 8, 2048, 256, 1, 1, 0), (5, 9, 9, 48, 32, 1, 1, 0)]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_split_bf16_conv_is_as_accurate_as_the_fp32_mfma_conv(case, capsys):
+    """ops.conv_split(6 | 9): the convolution with split-bf16 products against the fp32-MFMA kernel and an fp64 torch convolution, with
+    bias, residual and LeakyReLU epilogue.  Bar: error against fp64 at most 1.25x (x9) / 1.5x (x6) the fp32 kernel's."""
+    import torch.nn.functional as F
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    N, H, W, Cin, Cout, k, st, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, Cout, OH, OW, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), st, pad) + res.double(), 0.01)
+    xg, wg, bg, rg = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda(), res.permute(0, 2, 3, 1).contiguous().cuda()
+    out = {}
+    for name, terms in (('f32', 0), ('bf16x9', 9), ('bf16x6', 6)):
+        with ops.conv_split(terms):
+            out[name] = ops.conv2d_nhwc(xg, wg, bg, kh=k, kw=k, stride=st, pad=pad, res=rg, out_slope=0.01).permute(0, 3, 1, 2).cpu().double()
+    scale = ref.abs().max().item()
+    err = {m: ((o - ref).abs().max().item() / scale, (o - ref).pow(2).mean().sqrt().item() / scale) for m, o in out.items()}
+    assert err['bf16x9'][0] <= 1.25 * err['f32'][0] + 1e-9 and err['bf16x9'][1] <= 1.25 * err['f32'][1] + 1e-10, err
+    assert err['bf16x6'][0] <= 1.5 * err['f32'][0] + 1e-9 and err['bf16x6'][1] <= 1.5 * err['f32'][1] + 1e-10, err
+    with capsys.disabled():
+        print(f'\n[split study] conv {case}: max/rms error vs fp64: ' + ', '.join(f'{m} {e[0]:.2e}/{e[1]:.2e}' for m, e in err.items()), end='')
+
+
+def test_split_bf16_conv_on_a_pixel_list():
+    """the RoI-window launch (row_map / row_count) through the split kernel: the listed pixels equal the full split convolution's"""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(4)
+    N, H, W = 6, 64, 64
+    x = torch.randn(N, H, W, 64, generator=g).cuda()
+    w = (torch.randn(128, 9 * 64, generator=g) * 0.05).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    boxes = torch.tensor([[20.0, 30.0, 200.0, 180.0]] * N).cuda()
+    win = ops.roi_windows(boxes, None, N, H, W, 0.25)
+    with ops.conv_split(6):
+        full = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1)
+        rows = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, rows=win)
+    scat, mask = win.to_map(rows)
+    assert 0 < int(mask.sum()) < N * H * W and torch.equal(scat[mask], full[mask])

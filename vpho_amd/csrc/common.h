@@ -31,6 +31,11 @@ struct ProfScope {
 #define VPHO_REQUIRE(cond, ...) do { if (!(cond)) return vpho::fail(__VA_ARGS__); } while (0)
 #define VPHO_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return vpho::fail("%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// Barrier that publishes `buffer_load ... lds` (LDS-DMA) tiles to the other waves of the workgroup: every wave first waits for ITS
+// OWN outstanding fills.  __syncthreads() alone is not enough: the compiler places the vmcnt wait of an LDS-DMA by what the issuing
+// wave itself reads afterwards and may leave a barrier with the fill still in flight -- other waves then read the tile too early.
+#define VPHO_SYNC_LDS_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
         __syncthreads();
     }
     if (UNI) fill_uni(0, 0); else fill(0);
-    __syncthreads();
+    VPHO_SYNC_LDS_DMA();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { if (UNI) fill_uni(buf ^ 1, kt + 1); else fill(buf ^ 1); }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        VPHO_SYNC_LDS_DMA();
     }
 
     auto offsets = [&](int row, long long& yo, long long& ro) {
@@ -582,6 +582,241 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Opt-in split-bf16 variant of the direct-to-LDS kernel (vpho_conv_desc.w_planes / plane_terms; VPHO_CONV_MFMA=bf16x6|bf16x9 in the
+// Python plan; NOT the default -- see csrc/score_ode.hip::head_tile_split for the arithmetic and tests/test_gpu_split_head.py /
+// test_gpu_conv.py for the error study).  Weights arrive as three bf16 planes [3][Cout][K] that sum to the fp32 weights exactly;
+// activations stay fp32 in HBM and LDS and are split into their three bf16 pieces as the fragments are read.  Stage = 16 k
+// (one v_mfma_f32_32x32x16_bf16 step): A rows of 64 B, B rows of 32 B per plane; register double buffer: the fragments of stage
+// kt+1 are read and split in the shadow of the MFMAs of stage kt.  Shapes: Cin % 16 == 0 (every stage inside one filter tap), no
+// prologue affine; everything else takes the fp32 kernels.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SBK = 16;
+
+__device__ __forceinline__ void conv_split3(const f32x4& x0, const f32x4& x1, cbf16x8& h, cbf16x8& m, cbf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        const __bf16 hb = (__bf16)x;
+        const float r1 = x - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        const float r2 = r1 - (float)mb;
+        h[e] = hb; m[e] = mb; l[e] = (__bf16)r2;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int TERMS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(const Geo g) {
+    constexpr int NT = 64 * WM * WN, NW = WM * WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int A_ROWS = NW * 16;                   // A tile rows per pass (a wave instruction = 16 rows of 64 B)
+    constexpr int A_LD = BM / A_ROWS;
+    constexpr int B_ROWS = NW * 32;                   // plane rows per pass (a wave instruction = 32 rows of 32 B)
+    constexpr int B_PASSES = (3 * BN + B_ROWS - 1) / B_ROWS;
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && BM % A_ROWS == 0, "tile/wave layout");
+    constexpr int A_FLOATS = BM * SBK, PLANE_FLOATS = BN * SBK / 2;
+    constexpr int TILE = A_FLOATS + 3 * PLANE_FLOATS;                 // floats per stage
+    constexpr int EPI_FLOATS = BM * BN;                               // the epilogue stages the accumulator tile through LDS
+    __shared__ __attribute__((aligned(1024))) float smem[(2 * TILE > EPI_FLOATS) ? 2 * TILE : EPI_FLOATS];
+
+    vpho_conv_desc d = g.d;
+    int per_xcd = gridDim.x >> 3, ntiles = g.ntiles, M_live = g.M;
+    if (d.row_map) {
+        M_live = min(*d.row_count, g.M);
+        ntiles = (M_live + BM - 1) / BM * g.tiles_n;
+        per_xcd = (ntiles + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    }
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= ntiles) return;
+    const int tile_n = lb % g.tiles_n, tile_m = lb / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ohw = d.OH * d.OW;
+
+    // ---- A fill: lane -> (row = wave*16 + lane/4 [+ A_ROWS*j], physical 16-B chunk lane%4), fetching logical chunk ^ (row>>2)&3
+    const long long pad_shift = ((long long)d.pad_y * d.W + d.pad_x) * d.x_ld;
+    const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(d.x) - (uintptr_t)(pad_shift * 4)), 0, 0xFFFFFFF0u, 0x00020000);
+    const int arow = wave * 16 + (lane >> 2);
+    int a_iy0[A_LD], a_ix0[A_LD], u_voff[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int lr = arow + A_ROWS * j;
+        int m = m0 + lr;
+        const int kq = (lane & 3) ^ ((lr >> 2) & 3);
+        if (m < M_live) {
+            if (d.row_map) m = d.row_map[m];
+            const int n = m / ohw, rem = m - n * ohw;
+            const int oy = rem / d.OW, ox = rem - oy * d.OW;
+            a_iy0[j] = oy * d.stride - d.pad_y;
+            a_ix0[j] = ox * d.stride - d.pad_x;
+            const unsigned off = (unsigned)(((long long)(n * d.H + a_iy0[j]) * d.W + a_ix0[j]) * d.x_ld * 4);
+            u_voff[j] = (int)(off + (unsigned)(pad_shift * 4) + 16u * (unsigned)kq);
+        } else {
+            a_iy0[j] = -(1 << 28); a_ix0[j] = 0; u_voff[j] = -1;
+        }
+    }
+    // ---- B fill: flat row index over the three planes: fr = wave*32 + lane/2 + B_ROWS*pass -> (plane fr / BN, row fr % BN)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_planes), 0, 0xFFFFFFF0u, 0x00020000);
+    int b_voff[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int fr = wave * 32 + (lane >> 1) + B_ROWS * ps;
+        const int plane = fr / BN, r = fr - plane * BN, n = n0 + r;
+        const int ch = (lane & 1) ^ ((r >> 3) & 1);
+        b_voff[ps] = (plane < 3 && n < d.Cout) ? (int)((((long long)plane * d.Cout + n) * g.w_ld + ch * 8) * 2) : -1;
+    }
+    const bool simple = d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0;
+    int u_r = 0, u_s = 0, u_c = 0;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto fill = [&](int buf, int kt) {
+        float* As = smem + buf * TILE + wave * 16 * SBK;
+        float* Bs = smem + buf * TILE + A_FLOATS + wave * 32 * (SBK / 2);
+        const int tap_s = ((u_r * d.W + u_s) * d.x_ld + u_c) * 4;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            int off = u_voff[j];
+            if (!simple) {
+                const unsigned iy = (unsigned)(a_iy0[j] + u_r), ix = (unsigned)(a_ix0[j] + u_s);
+                off = (iy < (unsigned)d.H && ix < (unsigned)d.W) ? off : -1;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xu, (lds_ptr)(As + A_ROWS * j * SBK), 16, off, tap_s, 0, 0);
+        }
+        const int koff = kt * SBK * 2;
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            if (wave * 32 + B_ROWS * ps < 3 * BN) {          // wave-uniform: this wave's 32 rows of the pass exist
+                const int bo = b_voff[ps];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Bs + B_ROWS * ps * (SBK / 2)), 16, bo, koff, 0, 0);
+            }
+        }
+        u_c += SBK;
+        if (u_c >= d.Cin) { u_c = 0; if (++u_s == d.KW) { u_s = 0; ++u_r; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Frag { cbf16x8 ah[TM], am[TM], al[TM]; cbf16x8 b[TN][3]; };
+    const int a_sw = (li >> 2) & 3, b_sw = (li >> 3) & 1;
+    auto read_frags = [&](int buf, Frag& f) {
+        const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * SBK;
+        const __bf16* Bp = reinterpret_cast<const __bf16*>(smem + buf * TILE + A_FLOATS) + (wn * (BN / WN) + li) * SBK + ((lh ^ b_sw) * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.b[j][p] = *reinterpret_cast<const cbf16x8*>(Bp + (p * BN + j * 32) * SBK);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + i * 32 * SBK + ((2 * lh) ^ a_sw) * 4);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + i * 32 * SBK + ((2 * lh + 1) ^ a_sw) * 4);
+            conv_split3(x0, x1, f.ah[i], f.am[i], f.al[i]);
+        }
+    };
+    auto products = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (TERMS == 9) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[i], f.b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.b[j][1], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.b[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[i], f.b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[i], f.b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.b[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int nk = g.K / SBK;                                          // the host guarantees K % 16 == 0
+    Frag fr[2];
+    fill(0, 0);
+    if (nk > 1) fill(1, 1);
+    VPHO_SYNC_LDS_DMA();
+    read_frags(0, fr[0]);
+    for (int kt = 0; kt < nk; kt += 2) {
+        VPHO_SYNC_LDS_DMA();                                           // stage kt is in registers everywhere; fill(kt+1) has landed
+        if (kt + 2 < nk) fill(0, kt + 2);
+        if (kt + 1 < nk) read_frags(1, fr[1]);
+        products(fr[0]);
+        if (kt + 1 < nk) {
+            VPHO_SYNC_LDS_DMA();
+            if (kt + 3 < nk) fill(1, kt + 3);
+            if (kt + 2 < nk) read_frags(0, fr[0]);
+            products(fr[1]);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (same as conv_igemm_glds_kernel): accumulator tile through LDS, 16-byte rows out
+    auto offsets = [&](int row, long long& yo, long long& ro) {
+        if (d.row_map && d.rows_scatter) row = d.row_map[row];
+        if (g.y_linear && g.r_linear) {
+            yo = (long long)row * d.y_sx;
+            ro = (long long)row * d.r_sx;
+        } else {
+            int n = row / ohw, rem = row - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
+            ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+        }
+    };
+    constexpr int C_LD = BN;
+    float* Cs = smem;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                Cs[r * C_LD + wn * (BN / WN) + j * 32 + li] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int V_PER_ROW = BN / 4, ITERS = BM * V_PER_ROW / NT;
+    f32x4 v[ITERS], rv[ITERS];
+    long long yo[ITERS];
+    bool ok[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
+        const int row = m0 + r, col = n0 + 4 * c4;
+        ok[it] = row < M_live && col < d.Cout;
+        v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
+        long long ro = 0;
+        yo[it] = 0;
+        if (ok[it]) { offsets(row, yo[it], ro); yo[it] += col; ro += col; }
+        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.res && ok[it]) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        if (!ok[it]) continue;
+        const int idx = tid + it * NT;
+        const int c4 = idx % V_PER_ROW;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n0 + 4 * c4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+        *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
@@ -656,6 +891,28 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // Cin a multiple of 32 and within the LDS table); everything else with a prologue takes the register-staged kernel
     const bool pre_on_read = d.in_scale != nullptr && g.uni && d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin <= GLDS_PRE_MAX;
     const bool glds = (d.in_scale == nullptr || pre_on_read) && !no_glds;
+    // opt-in split-bf16 products (never the default): shapes the split kernel takes, everything else stays on the fp32 kernels
+    const bool split_ok = d.w_planes != nullptr && (d.plane_terms == 6 || d.plane_terms == 9) && d.in_scale == nullptr && splits == 1 && !d.gate &&
+                          d.Cin % SBK == 0 && g.vec_epilogue && d.pad_y >= 0 && d.pad_x >= 0 && g.w_ld == g.K &&
+                          ((uintptr_t)d.w_planes & 15) == 0 && 6.0 * d.Cout * g.K < 3.9e9;
+    if (split_ok) {
+        const bool x9 = d.plane_terms == 9;
+        switch (variant) {
+            case 128: case 1288:
+                if (x9) launch(conv_igemm_split_kernel<128, 128, 4, 2, 9>, 128, 128, 512, vpho::PROF_CONV128);
+                else    launch(conv_igemm_split_kernel<128, 128, 4, 2, 6>, 128, 128, 512, vpho::PROF_CONV128);
+                break;
+            case 12864:
+                if (x9) launch(conv_igemm_split_kernel<128, 64, 4, 2, 9>, 128, 64, 512, vpho::PROF_CONV128x64);
+                else    launch(conv_igemm_split_kernel<128, 64, 4, 2, 6>, 128, 64, 512, vpho::PROF_CONV128x64);
+                break;
+            default:
+                if (x9) launch(conv_igemm_split_kernel<64, 64, 2, 2, 9>, 64, 64, 256, vpho::PROF_CONV64);
+                else    launch(conv_igemm_split_kernel<64, 64, 2, 2, 6>, 64, 64, 256, vpho::PROF_CONV64);
+                break;
+        }
+        return vpho::check_launch("conv_igemm_split_kernel");
+    }
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
         case 1288:

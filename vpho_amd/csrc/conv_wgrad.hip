@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     const int nk = (m_end - m_begin + BK - 1) / BK;
     if (nk > 0) {
         fill(0, 0);
-        __syncthreads();
+        VPHO_SYNC_LDS_DMA();
     }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][kk][i], bv[h][kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        VPHO_SYNC_LDS_DMA();
     }
 
     float* out = a.out + (long long)blockIdx.y * a.Cout * a.K;

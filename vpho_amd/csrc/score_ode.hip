@@ -358,7 +358,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
     // load has a whole k-tile of MFMA time to land before the next barrier needs it.
     fill(0, 0);
-    __syncthreads();
+    VPHO_SYNC_LDS_DMA();
     fill(1, 1);
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
 #pragma unroll
         for (int kk = 0; kk < NKK - 1; ++kk) { frags(kk); mfmas(); }
         frags(NKK - 1);
-        __syncthreads();
+        VPHO_SYNC_LDS_DMA();
         if (kt + 2 < NK) fill(buf, kt + 2);
         mfmas();
     }
@@ -560,14 +560,14 @@ __device__ __forceinline__ void head_tile_split(const HeadArgs& a, float* smem, 
     Frag fr[2];
     fill(0, 0);
     fill(1, 1);
-    __syncthreads();
+    VPHO_SYNC_LDS_DMA();
     read_b(0, fr[0]);
 #pragma unroll
     for (int i = 0; i < TI; ++i) read_a(0, i, fr[0]);
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        __syncthreads();                                    // all waves hold stage kt in registers; fill(kt+1) has landed
+        VPHO_SYNC_LDS_DMA();                                // all waves hold stage kt in registers; fill(kt+1) has landed
         if (kt + 2 < NK) fill(buf, kt + 2);
         Frag& cur = fr[kt & 1];
         Frag& nxt = fr[(kt + 1) & 1];

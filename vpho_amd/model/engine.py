@@ -118,6 +118,8 @@ class Engine:
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
+        # opt-in split-bf16 convolution products (default: fp32 MFMA); see ops.conv_split
+        self.conv_terms = {'f32': 0, 'bf16x6': 6, 'bf16x9': 9}[os.environ.get('VPHO_CONV_MFMA', 'f32')]
         self.serial_samplers = False            # True: object sampler after the hand sampler on one stream (exclusive kernel timings)
         self._feat_side = None
         from .graphs import GraphedCall
@@ -232,6 +234,10 @@ class Engine:
 
     def features(self, data):
         """VPHO.py:112-172.  Returns a dict of device tensors (NHWC unless noted)."""
+        with ops.conv_split(self.conv_terms):
+            return self._features(data)
+
+    def _features(self, data):
         rgb = data['rgb'].float().contiguous()
         bs = rgb.shape[0]
         f32 = lambda k: data[k].float().contiguous()
@@ -378,7 +384,7 @@ class Engine:
         S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
         with torch.cuda.device(self.dev):
             if self.use_graphs:
-                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size))
+                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams))
                 keep = lambda t: t.clone()                 # graph-owned buffers are overwritten by the next replay
             else:
                 f = self.features(data)

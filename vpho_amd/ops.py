@@ -59,7 +59,8 @@ class ConvDesc(C.Structure):
                 ('in_slope', C.c_float), ('out_slope', C.c_float),
                 ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong),
                 ('gate', C.c_void_p), ('gate_slope', C.c_float),
-                ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int)]
+                ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int),
+                ('w_planes', C.c_void_p), ('plane_terms', C.c_int)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -67,6 +68,43 @@ lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
 
 def _addr(t):
     return None if t is None else t.data_ptr()
+
+
+# Opt-in split-bf16 convolutions (VPHO_CONV_MFMA=bf16x6|bf16x9, inference plan only; default: fp32 MFMA).  The three bf16 planes of
+# a packed weight matrix are made on first use and kept on the tensor object.
+import threading
+_conv_split = threading.local()
+
+
+class conv_split:
+    """context: convolutions launched inside use split-bf16 products (terms = 6 or 9) where the kernel takes the shape"""
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __enter__(self):
+        self.prev = getattr(_conv_split, 'terms', 0)
+        _conv_split.terms = self.terms
+
+    def __exit__(self, *exc):
+        _conv_split.terms = self.prev
+
+
+def bf16_planes(w):
+    """(3, *w.shape) bf16 with planes[0] + planes[1] + planes[2] == w exactly (each piece the bf16 rounding of what is left)"""
+    h = w.to(torch.bfloat16)
+    m = (w - h.float()).to(torch.bfloat16)
+    l = (w - h.float() - m.float()).to(torch.bfloat16)
+    return torch.stack([h, m, l], 0).contiguous()
+
+
+def _planes_of(w):
+    """the planes live ON the weight tensor object (an address-keyed cache would hand a new tensor at a recycled address the old
+    tensor's planes); an in-place update of the weights (``_version``) re-splits them"""
+    c = getattr(w, '_vpho_planes', None)
+    if c is None or c[0] != w._version:
+        c = (w._version, bf16_planes(w))
+        w._vpho_planes = c
+    return c[1]
 
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
@@ -132,6 +170,10 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     d.in_slope, d.out_slope = in_slope, out_slope
     if split is not None:                                   # (splits, w_ld, x_split, w_split, y_split): see vpho_conv_desc
         d.splits, d.w_ld, d.x_split, d.w_split, d.y_split = split
+    terms = getattr(_conv_split, 'terms', 0)
+    if terms and split is None and in_scale is None and gate is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
+        planes = _planes_of(w)                              # kept alive by the cache
+        d.w_planes, d.plane_terms = planes.data_ptr(), terms
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
     return ret
 
