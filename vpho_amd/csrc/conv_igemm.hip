@@ -319,8 +319,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
     constexpr int A_LD = BM / ROWS, B_LD = BN / ROWS;
     static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && ROWS % 16 == 0, "tile/wave layout");
     constexpr int TILE = (BM + BN) * BK;              // floats per stage (unpadded)
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
-    __shared__ __attribute__((aligned(16))) float pre_tab[PRE ? 2 * GLDS_PRE_MAX : 4];   // pre-activation scale | shift (PRE instantiations: 1x1 convolutions only)
+    // PRE instantiations keep the pre-activation scale | shift table behind the two stages, in the SAME LDS object: with a second
+    // __shared__ array the compiler no longer separates the fills from the fragment reads and waits for the next stage's fill
+    // before it reads the current one
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE + (PRE ? 2 * GLDS_PRE_MAX : 0)];
+    float* const pre_tab = smem + 2 * TILE;
 
     vpho_conv_desc d = g.d;
     d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
