@@ -426,6 +426,11 @@ int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope,
  * first (1 / world_size after a sum all-reduce) */
 int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* the same step for a list of tensors in one launch.  segments: device array of n_segments records
+ * { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; long long first_block; } with
+ * first_block = running sum of ceil(n / 1024) over the preceding records, total_blocks = that sum over all records. */
+int vpho_adamw_multi_f32(const void* segments, int n_segments, long long total_blocks, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float grad_scale, void* stream);
 
 /* ---- physics branch of the training step (lib/model/VPHO.py:170-172,205-212 under loss.backward()) -------------------------------
  * backward of vpho_cross_tokens_f32 (cross_module.py:125-133: .view(bs,32,-1) of the projected maps, cat, + positional code):

@@ -26,6 +26,8 @@ USE_TN_WGRAD = os.environ.get('VPHO_WGRAD_IM2COL', '0') == '0'      # tuning aid
 
 def _flip_transpose(w_packed, cout, cin, kh, kw):
     """(Cout, KH*KW*Cin) -> (Cin, KH*KW*Cout) with both spatial axes reversed"""
+    if kh == 1 and kw == 1:
+        return w_packed.t().contiguous()                        # nothing to flip: one transposing copy
     return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
 
 

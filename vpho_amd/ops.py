@@ -917,6 +917,25 @@ def adamw_(param, grad, m, v, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, w
           I(step), F(grad_scale))
 
 
+class AdamWList:
+    """torch.optim.AdamW on a fixed list of (param, grad, exp_avg, exp_avg_sq) tensors as ONE launch (vpho_adamw_multi_f32)"""
+    def __init__(self, quads):
+        self.keep = quads
+        rows, blk = [], 0
+        for p, g, m, v in quads:
+            for t in (p, g, m, v):
+                _ptr(t, torch.float32)
+            assert p.numel() == g.numel() == m.numel() == v.numel()
+            rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), blk])
+            blk += (p.numel() + 1023) // 1024
+        self.blocks, self.n = blk, len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(quads[0][0].device)
+
+    def step(self, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+        _call('vpho_adamw_multi_f32', _ptr(self.table, torch.int64), I(self.n), LL(self.blocks), F(lr), F(beta1), F(beta2), F(eps), F(weight_decay),
+              I(step), F(grad_scale))
+
+
 # ----------------------------------------------------------------------------------------------- physics branch (training)
 def cross_tokens_bwd(dtok, want_hand=True, want_obj=True):
     bs = dtok.shape[0]

@@ -63,7 +63,8 @@ class DiffusionTrainStep:
         def conv(name, live, shape, cin_pad=None):
             cout, cin, kh, kw = shape
             master = live.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2).contiguous()
-            add(name, master, lambda w, live=live, cin_pad=cin_pad: live.copy_(pack_conv(w, cin_pad)))
+            # re-pack = ONE strided copy into the packed layout (the padded channels of the stem / encoder inputs stay zero)
+            add(name, master, lambda w, view=live.view(cout, kh, kw, -1)[..., :cin]: view.copy_(w.permute(0, 2, 3, 1)))
 
         def vec(name, live):
             add(name, live, None)
@@ -306,8 +307,12 @@ class DiffusionTrainStep:
         self.steps += 1
         hyper = dict(self.hyper, lr=self.hyper['lr'] if lr is None else lr)
         with torch.cuda.device(self.dev):
+            key = tuple(live)
+            if getattr(self, '_adam_key', None) != key:                  # the list is the same every step unless a loss is switched off
+                self._adam = ops.AdamWList([(self.master[k], self.grad_view[k], self.m[k], self.v[k]) for k in live])
+                self._adam_key = key
+            self._adam.step(self.steps, grad_scale=scale, **hyper)
             for k in live:
-                ops.adamw_(self.master[k], self.grad_view[k], self.m[k], self.v[k], self.steps, grad_scale=scale, **hyper)
                 if self._repack[k] is not None:
                     self._repack[k](self.master[k])
         return losses
