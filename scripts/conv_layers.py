@@ -21,7 +21,9 @@ def timed(x, w, bias=None, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); y = orig(x, w, bias, **kw); e1.record()
     N, H, W, ld = x.shape
-    rec.append((e0, e1, (N, H, W, kw.get('cin', ld), w.shape[0], kw.get('kh', 1), kw.get('stride', 1)), y.shape))
+    rows = kw.get('rows')                                     # RoI-window launches: the pixels really computed (synchronises; timing aid only)
+    ys = y.shape if rows is None else (int(rows.count), 1, 1, y.shape[-1])
+    rec.append((e0, e1, (N, H, W, kw.get('cin', ld), w.shape[0], kw.get('kh', 1), kw.get('stride', 1), 'win' if rows is not None else ''), ys))
     return y
 ops.conv2d_nhwc = timed
 import vpho_amd.model.engine as EM
@@ -36,4 +38,4 @@ for e0, e1, key, ys in rec:
 tot = sum(v[1] for v in agg.values())
 print(f'total conv time {tot:.2f} ms in {len(rec)} launches')
 for key, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f'N{key[0]} H{key[1]} Cin{key[3]} Cout{key[4]} k{key[5]} s{key[6]}: calls {n} time {t:.3f} ms ({100*t/tot:.1f}%)  {fl/t/1e9:.1f} TF/s')
+    print(f'N{key[0]} H{key[1]} Cin{key[3]} Cout{key[4]} k{key[5]} s{key[6]} {key[7]}: calls {n} time {t:.3f} ms ({100*t/tot:.1f}%)  {fl/t/1e9:.1f} TF/s')
