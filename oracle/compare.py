@@ -27,6 +27,11 @@ import torch
 
 TIE_REL = 1e-6
 E2E_TIE_REL = 1e-3
+# Identical-candidate comparison on batches other than the pinned one (tests/test_gpu_seed_probe.py).  The hand cascade re-runs MANO
+# FK on every candidate at every level and feeds each level's fused rotation to the next, so the level scores of the two sides see
+# joints that differ by fp32 rounding (~2e-7 m -> ~1e-4 px after projection) on heat-maps with O(0.1)/px slopes: score differences of
+# 1e-6 ... 1e-4 relative by level 3.  1e-6 holds on the pinned batch; over further batches the first differences reach 7.6e-5.
+CASCADE_TIE_REL = 2e-4
 
 
 def _c(t):
