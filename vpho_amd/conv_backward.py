@@ -24,11 +24,19 @@ import os
 USE_TN_WGRAD = os.environ.get('VPHO_WGRAD_IM2COL', '0') == '0'      # tuning aid: 1 = the explicit im2col + transpose path for every shape
 
 
+_REV = {}
+
+
 def _flip_transpose(w_packed, cout, cin, kh, kw):
     """(Cout, KH*KW*Cin) -> (Cin, KH*KW*Cout) with both spatial axes reversed"""
     if kh == 1 and kw == 1:
         return w_packed.t().contiguous()                        # nothing to flip: one transposing copy
-    return w_packed.view(cout, kh, kw, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, kh * kw * cout).contiguous()
+    # reversing both spatial axes = reversing the flat tap index; one gather does the reversal and the transposition
+    key = (kh * kw, w_packed.device)
+    rev = _REV.get(key)
+    if rev is None:
+        rev = _REV[key] = torch.arange(kh * kw - 1, -1, -1, device=w_packed.device)
+    return w_packed.view(cout, kh * kw, cin).permute(2, 1, 0).index_select(1, rev).reshape(cin, kh * kw * cout)
 
 
 def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None):

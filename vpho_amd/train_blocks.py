@@ -66,8 +66,9 @@ def _bn_params(sd, key, dev):
 
 
 def _unpack_grad(gp, cout, cin, kh, kw):
-    """packed (Cout, kh*kw*cin_pad) gradient -> the reference's (Cout, Cin, kh, kw)"""
-    return gp.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2).contiguous()
+    """packed (Cout, kh*kw*cin_pad) gradient -> the reference's (Cout, Cin, kh, kw), as a VIEW: the one copy it needs is the one
+    into the flat gradient buffer (grad_buckets.GradBuckets.put)"""
+    return gp.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2)
 
 
 class FPNTrain:
