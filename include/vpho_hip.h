@@ -407,6 +407,11 @@ int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope
 /* nn.MaxPool2d backward (backbone_FPN_HFL.py:209): dx[n,iy,ix,c] = sum of dy over the windows whose first maximum (row-major)
  * is (iy,ix); x is the pooling input.  Deterministic gather, no atomics. */
 int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream);
+/* the same with a byte workspace (vpho_maxpool_bwd_workspace_bytes; 0 = not needed) for overlapping windows: arg-max position of
+ * every window first, then the gather compares position codes instead of re-scanning windows (bit-identical results) */
+long long vpho_maxpool_bwd_workspace_bytes(int N, int H, int W, int C, int k, int stride, int pad);
+int vpho_maxpool_bwd_ws_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx,
+                                 void* workspace, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) backward (FPN._upsample_add, backbone_FPN_HFL.py:66-68):
  * dy [N][OH][OW][C] -> dx [N][H][W][C] */
 int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);

@@ -122,6 +122,13 @@ def test_maxpool_backward_matches_autograd(N, H, W, C, k, stride, pad):
     nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
     dx = ops.maxpool_bwd(nhwc(x), nhwc(dy), k, stride, pad).permute(0, 3, 1, 2).cpu()
     np.testing.assert_allclose(dx.numpy(), x.grad.numpy(), atol=1e-6)
+    # overlapping windows take the two-pass form (arg-max bytes, then position codes); the one-pass gather must give the same bits,
+    # also with ties inside a window (first maximum in row-major order)
+    xt = torch.randint(0, 3, (N, H, W, C), generator=g).float().cuda()
+    dyt = nhwc(dy)
+    one = torch.empty_like(xt)
+    ops._call('vpho_maxpool_bwd_nhwc_f32', ops._f32(xt), ops._f32(dyt), ops.I(N), ops.I(H), ops.I(W), ops.I(C), ops.I(k), ops.I(stride), ops.I(pad), ops._f32(one))
+    assert torch.equal(ops.maxpool_bwd(xt, dyt, k, stride, pad), one)
 
 
 @pytest.mark.parametrize('N,H,W,C,OH,OW', [(2, 8, 8, 16, 16, 16), (1, 4, 6, 8, 8, 12), (2, 16, 16, 4, 8, 8), (1, 5, 7, 4, 13, 9)])

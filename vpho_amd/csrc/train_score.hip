@@ -900,6 +900,88 @@ extern "C" int vpho_add_lrelu_f32(const float* a, const float* b, long long n, f
     return vpho::check_launch("add_lrelu_kernel");
 }
 
+// Overlapping windows (k > stride: the 3x3 / stride-2 pool behind the stem) make the gather above scan k*k inputs for each of up to
+// four windows per input pixel.  Two passes instead: the arg-max position of every window once (one byte per output element), then an
+// input pixel compares its own position code with at most four of those bytes.  Same selection rule, same summation order.
+__global__ void maxpool_argmax_kernel(const float* __restrict__ x, int N, int H, int W, int C, int k, int stride, int pad, int OH, int OW,
+                                      unsigned char* __restrict__ arg) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // 4 consecutive channels of one OUTPUT pixel
+    const int CV = C / 4;
+    if (i >= (long long)N * OH * OW * CV) return;
+    const int c = (int)(i % CV) * 4;
+    long long p = i / CV;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const long long n = p / OH;
+    const float* xb = x + n * H * W * (long long)C + c;
+    float m[4];
+    unsigned char code[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { m[v] = -INFINITY; code[v] = 255; }
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+        const int yy = oy * stride - pad + r;
+        if (yy < 0 || yy >= H) continue;
+        for (int q = 0; q < k; ++q) {
+            const int xx = ox * stride - pad + q;
+            if (xx < 0 || xx >= W) continue;
+            float xv[4];
+            ldv<4>(xb + ((long long)yy * W + xx) * C, xv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (xv[v] > m[v] || first) { m[v] = xv[v]; code[v] = (unsigned char)(r * k + q); }
+            first = false;
+        }
+    }
+    uchar4 o; o.x = code[0]; o.y = code[1]; o.z = code[2]; o.w = code[3];
+    *reinterpret_cast<uchar4*>(arg + ((n * OH + oy) * OW + ox) * (long long)C + c) = o;
+}
+__global__ void maxpool_bwd_arg_kernel(const unsigned char* __restrict__ arg, const float* __restrict__ dy, int N, int H, int W, int C, int k, int stride,
+                                       int pad, int OH, int OW, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CV = C / 4;
+    if (i >= (long long)N * H * W * CV) return;
+    const int c = (int)(i % CV) * 4;
+    long long p = i / CV;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const long long n = p / H;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
+    const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int mine = (iy - (oy * stride - pad)) * k + (ix - (ox * stride - pad));
+            const long long o = ((n * OH + oy) * OW + ox) * (long long)C + c;
+            const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + o);
+            float dv[4];
+            ldv<4>(dy + o, dv);
+            g[0] += a4.x == mine ? dv[0] : 0.f; g[1] += a4.y == mine ? dv[1] : 0.f;
+            g[2] += a4.z == mine ? dv[2] : 0.f; g[3] += a4.w == mine ? dv[3] : 0.f;
+        }
+    stv<4>(dx + ((n * H + iy) * W + ix) * (long long)C + c, g);
+}
+
+extern "C" long long vpho_maxpool_bwd_workspace_bytes(int N, int H, int W, int C, int k, int stride, int pad) {
+    if (k <= stride || C % 4 != 0 || k * k > 255) return 0;            // non-overlapping windows: the one-pass gather reads each input once
+    const long long OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    return (long long)N * OH * OW * C;
+}
+
+extern "C" int vpho_maxpool_bwd_ws_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx,
+                                            void* workspace, void* stream) {
+    VPHO_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, "vpho_maxpool_bwd_ws_nhwc_f32: bad argument");
+    if (!workspace || vpho_maxpool_bwd_workspace_bytes(N, H, W, C, k, stride, pad) == 0 || !aligned16(x) || !aligned16(dy) || !aligned16(dx) ||
+        ((uintptr_t)workspace & 3))
+        return vpho_maxpool_bwd_nhwc_f32(x, dy, N, H, W, C, k, stride, pad, dx, stream);
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(nblk((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, k, stride, pad,
+                       OH, OW, (unsigned char*)workspace);
+    hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(nblk((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)workspace,
+                       dy, N, H, W, C, k, stride, pad, OH, OW, dx);
+    return vpho::check_launch("maxpool_bwd_arg_kernel");
+}
+
 extern "C" int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream) {
     VPHO_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, "vpho_maxpool_bwd_nhwc_f32: bad argument");
     const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;

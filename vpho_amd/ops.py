@@ -198,6 +198,8 @@ class OdeStats(C.Structure):
 
 
 lib.vpho_score_workspace_bytes.restype = C.c_longlong
+lib.vpho_maxpool_bwd_workspace_bytes.restype = C.c_longlong
+lib.vpho_maxpool_bwd_workspace_bytes.argtypes = [C.c_int] * 7
 lib.vpho_score_workspace_bytes.argtypes = [C.POINTER(ScoreWeights), C.c_int, C.c_int]
 lib.vpho_score_eval.argtypes = [C.POINTER(ScoreWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p, C.c_longlong, C.c_void_p]
@@ -878,7 +880,9 @@ def lrelu_bwd(dy, y, slope):
 def maxpool_bwd(x, dy, k, stride, pad):
     N, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    _call('vpho_maxpool_bwd_nhwc_f32', _f32(x), _f32(dy), I(N), I(H), I(W), I(Cc), I(k), I(stride), I(pad), _f32(dx))
+    need = lib.vpho_maxpool_bwd_workspace_bytes(N, H, W, Cc, k, stride, pad)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need > 0 else None
+    _call('vpho_maxpool_bwd_ws_nhwc_f32', _f32(x), _f32(dy), I(N), I(H), I(W), I(Cc), I(k), I(stride), I(pad), _f32(dx), _u8(ws))
     return dx
 
 
