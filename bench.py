@@ -49,6 +49,7 @@ def parse():
     p.add_argument('--score_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32',
                    help='score head products: f32 = fp32 MFMA (default, the path parity is stated on); bf16x6 / bf16x9 = opt-in split-bf16 products with fp32 accumulation')
     p.add_argument('--conv_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32', help='the same switch for the convolutions of the feature path (opt-in)')
+    p.add_argument('--winograd', action='store_true', help='opt-in: 3x3 / stride-1 convolutions of the feature path as Winograd F(2x2,3x3) on the fp32 matrix cores')
     p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
@@ -102,6 +103,8 @@ def main():
         os.environ['VPHO_ROI_WINDOW'] = '0'                # read by every execution plan (this one and the pipeline slots')
     score_mfma = os.environ.get('VPHO_SCORE_MFMA', 'f32') if args.score_mfma == 'f32' else args.score_mfma
     os.environ['VPHO_SCORE_MFMA'] = score_mfma             # read when an execution plan packs its score networks
+    if args.winograd:
+        os.environ['VPHO_WINOGRAD'] = '1'
     conv_mfma = os.environ.get('VPHO_CONV_MFMA', 'f32') if args.conv_mfma == 'f32' else args.conv_mfma
     os.environ['VPHO_CONV_MFMA'] = conv_mfma
     model._engine = Engine(model)
@@ -192,7 +195,7 @@ def main():
     # ---- roofline leg: the same K steps again with HIP events recorded around every launch of the timed kernel
     # classes on their launch streams (kept out of the timed region: ~500 event pairs per step perturb it by 10-15 %)
     hbm_classes = ('mano_fk', 'obj_physics', 'hand_fuse', 'roi_align', 'resize_bilinear')
-    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head') + hbm_classes
+    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head', 'conv_winograd') + hbm_classes
     prof = {c: dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0) for c in timed_classes}
     if not args.no_kernel_timing:
         for c in timed_classes:
@@ -244,7 +247,7 @@ def main():
                                     else 'non-default config (see the keys below)'),
                        'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
-                       'pipeline_depth': args.pipeline, 'score_mfma': score_mfma, 'conv_mfma': conv_mfma,
+                       'pipeline_depth': args.pipeline, 'score_mfma': score_mfma, 'conv_mfma': conv_mfma, 'winograd_3x3': bool(eng.winograd),
                        'fpn_roi_window': {'enabled': bool(eng.roi_window), 'what': 'the last convolution of each FPN branch is computed only on the pixels its '
                                           'RoIAligns read (VPHO.py:126-129 are the maps\' only readers); bit-identical results, --no_roi_window computes the full maps',
                                           'pixel_share_hand_obj_per_batch': roi_frac,
@@ -260,7 +263,7 @@ def main():
                          'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),
                                                'kernel_ms_per_step': v['total_ms'] / max(args.steps, 1),
                                                'launches_per_step': v['launches'] / max(args.steps, 1)}
-                                           for k, v in prof.items() if k in ('conv_igemm_128x64', 'conv_igemm_64x64')},
+                                           for k, v in prof.items() if k in ('conv_igemm_128x64', 'conv_igemm_64x64', 'conv_winograd')},
                          'launches_per_step': conv['launches'] / max(args.steps, 1),
                          'avg_launch_us': conv['total_ms'] * 1e3 / max(conv['launches'], 1),
                          'flop_per_launch_avg': conv['flops'] / max(conv['launches'], 1),

@@ -135,3 +135,26 @@ def test_mixed_uniform_and_generic_tap_paths_agree():
         ref = F.conv2d(x, w, None, 2, 1)
         y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), None, kh=3, kw=3, stride=2, pad=1)
         _close(y.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(8, 32, 32, 128, 128), (4, 16, 16, 256, 256), (3, 8, 8, 512, 64), (2, 4, 6, 8, 64), (5, 64, 64, 64, 64)])
+def test_winograd_3x3_matches_fp64_and_the_direct_kernel(N, H, W, Cin, Cout, capsys):
+    """Opt-in Winograd F(2x2,3x3) kernel (csrc/conv_winograd.hip): bias + LeakyReLU epilogue, zero padding at the borders, tile counts
+    that do not fill a workgroup; error against an fp64 convolution no larger than 2x the direct kernel's (observed: smaller)."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv, winograd_weights
+    g = torch.Generator().manual_seed(N * H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.01)
+    xg, wg, bg = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda()
+    direct = ops.conv2d_nhwc(xg, wg, bg, kh=3, kw=3, pad=1, out_slope=0.01).permute(0, 3, 1, 2).cpu().double()
+    wino = ops.conv3x3_winograd(xg, winograd_weights(wg), bg, out_slope=0.01).permute(0, 3, 1, 2).cpu().double()
+    auto = ops.conv3x3(xg, wg, bg, out_slope=0.01, winograd=True).permute(0, 3, 1, 2).cpu().double()
+    assert torch.equal(auto, wino)
+    sc = ref.abs().max().item()
+    ed, ew = (direct - ref).abs().max().item() / sc, (wino - ref).abs().max().item() / sc
+    assert ew <= 2 * ed + 1e-9 and ew < 5e-6, (ed, ew)
+    with capsys.disabled():
+        print(f'\n[winograd] {(N, H, W, Cin, Cout)}: max error vs fp64: direct {ed:.2e}, winograd {ew:.2e}', end='')

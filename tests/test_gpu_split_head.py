@@ -125,3 +125,34 @@ def test_split_bf16_conv_on_a_pixel_list():
         rows = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, rows=win)
     scat, mask = win.to_map(rows)
     assert 0 < int(mask.sum()) < N * H * W and torch.equal(scat[mask], full[mask])
+
+
+def test_predict_with_winograd_agrees_with_the_default(model_cpu, assets):
+    """opt-in VPHO_WINOGRAD=1 (3x3 / stride-1 convolutions of the feature path in Winograd form) against the default engine: same step
+    sequences of both solves, feature-path outputs to 1e-5 of their range, samples within the north-star 1e-3 (observed ~1e-5)."""
+    import copy
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.model.engine import Engine
+    from vpho_amd.synth import synth_batch
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 16, 10, 8, 4, 0.65
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(5, assets, seed=3).items()}
+        eng = Engine(m)
+        assert not eng.winograd
+        g = torch.Generator().manual_seed(9)
+        nh, no = torch.randn(5 * 16, 96, generator=g), torch.randn(5 * 16, 9, generator=g)
+        ref = {k: v.clone() for k, v in eng.predict(data, nh, no).items() if torch.is_tensor(v)}
+        info = {k: (eng.last_info[k]['nfev'], [s[3] for s in eng.last_info[k]['steps']]) for k in ('hand_ode', 'obj_ode')}
+        eng.winograd = True
+        out = eng.predict(data, nh, no)
+        for k in ('hand_ode', 'obj_ode'):
+            assert (eng.last_info[k]['nfev'], [s[3] for s in eng.last_info[k]['steps']]) == info[k]
+        for k in ('hand_heatmap', 'obj_heatmap', 'reg_hand_joint', 'force_local'):
+            d = (out[k].double() - ref[k].double()).abs().max().item()
+            assert 0 < d < 1e-5 * max(1.0, ref[k].abs().max().item()), (k, d)
+        for k in ('diff_final_hand_mano', 'diff_final_obj_6d', 'diff_final_hand_joint'):
+            assert (out[k].double() - ref[k].double()).abs().max().item() < 1e-3, k
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved

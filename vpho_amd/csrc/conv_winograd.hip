@@ -1,0 +1,194 @@
+// Winograd F(2x2, 3x3) convolution (stride 1, padding 1) on the gfx950 fp32 matrix cores -- EXPERIMENT, see the launch condition in
+// vpho_conv3x3_winograd_nhwc_f32 and DESIGN.md for where (if anywhere) the plan uses it.
+//
+// Y(2x2) = A^T [ sum_c (G g_c G^T) o (B^T d_c B) ] A: the 16 element-wise products are 16 independent GEMMs
+//   M_f[tile][cout] = sum_cin V_f[tile][cin] * U_f[cout][cin]      (f = 4*fy + fx)
+// with 2.25 x fewer multiply-adds than the direct 3x3.  U = G g G^T is computed once on the host (model/pack.py); V = B^T d B is
+// formed by the workgroup from the NHWC input (additions only) and written straight into the LDS stage; the output transform runs on
+// the accumulators in registers.
+//
+// Workgroup = 4 waves = 64 tiles x 64 output channels x all 16 frequencies; wave = 32 tiles x 32 channels x 16 frequencies: 16
+// independent 32x32 accumulator tiles (256 registers), so a (tile, channel) pair has all its frequencies in ONE lane and the output
+// transform needs no exchange.  One wave per SIMD: latency is hidden by the 16 independent MFMA chains per k step.
+// Stage = 8 input channels: V [16][64][8] and U [16][64][8] fp32 (32-byte rows, 16-byte chunks exchanged on odd 8-row groups),
+// double buffered (128 KB).
+#include "common.h"
+#include "../../include/vpho_hip.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int WK = 8;                          // input channels per stage
+constexpr int W_TB = 64, W_CB = 64;            // tiles / output channels per workgroup
+constexpr int W_STAGE = 2 * 16 * 64 * WK;      // floats per stage: V | U
+
+struct WinoArgs {
+    const float* x; const float* u; const float* bias; float* y;
+    int N, H, W, Cin, x_ld, Cout, y_ld;
+    int TH, TW, T;                             // tiles per column / row / in total
+    float out_slope;
+};
+
+__global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+    const int wt = wave & 1, wc = wave >> 1;
+    const int ncb = a.Cout / W_CB;
+    const int tb = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+    const int t0 = tb * W_TB, c0 = cb * W_CB;
+
+    // ---- V producer: thread = (tile tl, channel pair cp): its 4 x 4 input patch, two channels (8-byte loads)
+    // the four channel pairs of a pixel sit on four neighbouring lanes: one wave instruction reads 16 pixels x 32 contiguous bytes
+    const int tl = wave * 16 + (lane >> 2), cp = lane & 3;
+    const int t = t0 + tl;
+    const bool tile_live = t < a.T;
+    int pn = 0, py0 = 0, px0 = 0;
+    if (tile_live) {
+        pn = t / (a.TH * a.TW);
+        const int rem = t - pn * a.TH * a.TW;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        py0 = 2 * ty - 1; px0 = 2 * tx - 1;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 patch[16];
+    auto load_patch = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
+            f32x2 v = {0.f, 0.f};
+            if (tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const f32x2*>(a.x + ((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + kc * WK + 2 * cp);
+            patch[p] = v;
+        }
+    };
+    auto store_v = [&](int buf) {
+        // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+        f32x2 r[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r[0 * 4 + c] = patch[0 * 4 + c] - patch[2 * 4 + c];
+            r[1 * 4 + c] = patch[1 * 4 + c] + patch[2 * 4 + c];
+            r[2 * 4 + c] = patch[2 * 4 + c] - patch[1 * 4 + c];
+            r[3 * 4 + c] = patch[1 * 4 + c] - patch[3 * 4 + c];
+        }
+        float* V = smem + buf * W_STAGE;
+        const int sw = (tl >> 3) & 1;
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+            const f32x2 v0 = r[fy * 4 + 0] - r[fy * 4 + 2];
+            const f32x2 v1 = r[fy * 4 + 1] + r[fy * 4 + 2];
+            const f32x2 v2 = r[fy * 4 + 2] - r[fy * 4 + 1];
+            const f32x2 v3 = r[fy * 4 + 1] - r[fy * 4 + 3];
+            const f32x2 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int fx = 0; fx < 4; ++fx) {
+                const int f = fy * 4 + fx;
+                // row (f, tl): 8 floats; channel pair cp lives in 16-byte chunk (cp >> 1) ^ sw, 8-byte half cp & 1
+                *reinterpret_cast<f32x2*>(V + (f * 64 + tl) * WK + (((cp >> 1) ^ sw) * 4) + (cp & 1) * 2) = vv[fx];
+            }
+        }
+    };
+    // ---- U fill: direct to LDS, 32-byte rows: one wave instruction = 32 rows; 16 f x 64 rows = 32 instructions per stage, 8 per wave
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int uoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int fr = (wave * 8 + j) * 32 + (lane >> 1);          // flat row over (f, cout-in-block): f = fr / 64, r = fr % 64
+        const int f = fr >> 6, r = fr & 63;
+        const int ch = (lane & 1) ^ ((r >> 3) & 1);
+        const int co = c0 + r;
+        uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * a.Cin + ch * 4) * 4) : -1;
+    }
+    auto fill_u = [&](int buf, int kc) {
+        float* U = smem + buf * W_STAGE + 16 * 64 * WK + wave * 8 * 32 * WK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * WK * 4, 0, 0);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+
+    const int nk = a.Cin / WK;
+    const int fsw = (li >> 3) & 1;
+    load_patch(0);
+    fill_u(0, 0);
+    store_v(0);
+    VPHO_SYNC_LDS_DMA();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) { load_patch(kc + 1); fill_u(buf ^ 1, kc + 1); }
+        const float* V = smem + buf * W_STAGE + (wt * 32 + li) * WK + ((lh ^ fsw) * 4);
+        const float* U = smem + buf * W_STAGE + 16 * 64 * WK + (wc * 32 + li) * WK + ((lh ^ fsw) * 4);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(V + f * 64 * WK);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(U + f * 64 * WK);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[f], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_v(buf ^ 1);
+        // issue order of the stage: one MFMA, then a slice of the next stage's transform (vector adds, LDS writes) and of this stage's
+        // fragment reads -- one wave per SIMD, so whatever is not interleaved with the matrix pipe runs in front of it
+#pragma unroll
+        for (int gq = 0; gq < 64; ++gq) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+        }
+        VPHO_SYNC_LDS_DMA();
+    }
+
+    // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
+    const int co = c0 + wc * 32 + li;
+    const float bias = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int trow = t0 + wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+            s0[fx] = acc[0 * 4 + fx][e] + acc[1 * 4 + fx][e] + acc[2 * 4 + fx][e];
+            s1[fx] = acc[1 * 4 + fx][e] - acc[2 * 4 + fx][e] - acc[3 * 4 + fx][e];
+        }
+        const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+        const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+        if (trow < a.T && co < a.Cout) {
+            const int n = trow / (a.TH * a.TW), rem = trow - n * a.TH * a.TW;
+            const int ty = rem / a.TW, tx = rem - ty * a.TW;
+            float* yp = a.y + ((long long)(n * a.H + 2 * ty) * a.W + 2 * tx) * a.y_ld + co;
+            const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
+            const long long offs[4] = {0, (long long)a.y_ld, (long long)a.W * a.y_ld, (long long)(a.W + 1) * a.y_ld};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { const float v = o[p]; yp[offs[p]] = v > 0.f ? v : v * a.out_slope; }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+                                              float out_slope, float* y, int y_ld, void* stream) {
+    VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
+    VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % WK == 0 && Cout % W_CB == 0 && x_ld % 2 == 0 && x_ld >= Cin && y_ld >= Cout,
+                 "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 8 == 0, Cout %% 64 == 0");
+    VPHO_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)u & 15) == 0 && 64.0 * Cout * Cin < 3.9e9, "vpho_conv3x3_winograd_nhwc_f32: alignment / size");
+    WinoArgs a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
+    a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
+    const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
+    static bool opt_in = false;
+    if (!opt_in) {
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        opt_in = true;
+    }
+    const int tbs = (a.T + W_TB - 1) / W_TB;
+    // executed flops: 16 GEMMs of T x Cout x Cin (the direct 3x3 would be 2.25 x this)
+    vpho::ProfScope prof(vpho::PROF_WINOGRAD, (hipStream_t)stream, 2.0 * 16.0 * a.T * Cout * (double)Cin,
+                         4.0 * ((double)N * H * W * Cin + 16.0 * Cout * Cin + (double)N * H * W * Cout));
+    hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)(tbs * (Cout / W_CB))), dim3(256), lds, (hipStream_t)stream, a);
+    return vpho::check_launch("conv_winograd_kernel");
+}

@@ -118,6 +118,9 @@ class Engine:
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
+        # opt-in: 3x3 / stride-1 convolutions in Winograd F(2x2,3x3) form (VPHO_WINOGRAD=1; default: the direct implicit GEMM, the path the
+        # pinned parity batches were recorded on -- DESIGN 4c)
+        self.winograd = os.environ.get('VPHO_WINOGRAD', '0') == '1'
         # opt-in split-bf16 convolution products (default: fp32 MFMA); see ops.conv_split
         self.conv_terms = {'f32': 0, 'bf16x6': 6, 'bf16x9': 9}[os.environ.get('VPHO_CONV_MFMA', 'f32')]
         self.serial_samplers = False            # True: object sampler after the hand sampler on one stream (exclusive kernel timings)
@@ -132,7 +135,10 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ feature path
     def _bottleneck(self, x, b):
         y = ops.conv2d_nhwc(x, *b['c1'], out_slope=0.01)
-        y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01)
+        if b['stride'] == 1:
+            y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd)
+        else:
+            y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01)
         r = x if b['down'] is None else ops.conv2d_nhwc(x, *b['down'], stride=b['stride'])
         return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01)
 
@@ -197,8 +203,8 @@ class Engine:
         return ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1, rows=None if windows is None else windows[br][0])
 
     def _hm_head(self, x, h):
-        y = ops.conv2d_nhwc(x, *h['c0'], kh=3, kw=3, pad=1)
-        y = ops.conv2d_nhwc(y, *h['c1'], kh=3, kw=3, pad=1)                              # BN folded; LeakyReLU(1.0) = identity (Q1)
+        y = ops.conv3x3(x, *h['c0'], winograd=self.winograd)
+        y = ops.conv3x3(y, *h['c1'], winograd=self.winograd)                             # BN folded; LeakyReLU(1.0) = identity (Q1)
         N, H, W, _ = y.shape
         co = h['deconv_b'].shape[0]
         up = torch.empty((N, 2 * H, 2 * W, co), device=y.device)
@@ -212,7 +218,7 @@ class Engine:
         stages = []
         for i, b in enumerate(e['blocks']):
             y = ops.conv2d_nhwc(x, *b['c1'], in_scale=b['pre'][0], in_shift=b['pre'][1], in_slope=0.01, out_slope=0.01)
-            y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, pad=1, out_slope=0.01)
+            y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd)
             x = ops.conv2d_nhwc(y, *b['c3'], res=x)
             if i % 2 == 1:
                 x = ops.maxpool_nhwc(x, 2, 2, 0)
@@ -222,8 +228,8 @@ class Engine:
 
     def _cross(self, c, st_h, st_o, grav, flip_u8):
         bs = st_h.shape[0]
-        ph = ops.conv2d_nhwc(st_h, *c['proj_hand'], kh=3, kw=3, pad=1)
-        po = ops.conv2d_nhwc(st_o, *c['proj_obj'], kh=3, kw=3, pad=1)
+        ph = ops.conv3x3(st_h, *c['proj_hand'], winograd=self.winograd)
+        po = ops.conv3x3(st_o, *c['proj_obj'], winograd=self.winograd)
         ge = ops.linear(ops.nerf_embed(grav, flip_u8), *c['grav'])
         x = ops.cross_tokens(ph, po, ge, c['pe']).view(bs * 65, 512)
         qkv = ops.linear(x, *c['in_proj'])
@@ -384,7 +390,7 @@ class Engine:
         S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
         with torch.cuda.device(self.dev):
             if self.use_graphs:
-                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams))
+                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams, self.winograd))
                 keep = lambda t: t.clone()                 # graph-owned buffers are overwritten by the next replay
             else:
                 f = self.features(data)

@@ -42,3 +42,14 @@ def pack_deconv4x4s2(w):
             # sub: (Cin, Cout, 2(dy), 2(dx)) -> conv weight (Cout, Cin, 2, 2)
             out[(py, px)] = (pack_conv(sub.permute(1, 0, 2, 3).contiguous()), 1 - py, 1 - px)
     return out
+
+
+def winograd_weights(w_packed, cin=None):
+    """packed 3x3 weights (Cout, 9*Cin) -> U (16, Cout, Cin) = G g G^T of Winograd F(2x2, 3x3), computed in fp64
+    (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]); frequency f = 4*fy + fx."""
+    cout = w_packed.shape[0]
+    cin = w_packed.shape[1] // 9 if cin is None else cin
+    g = w_packed.double().view(cout, 3, 3, cin)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=w_packed.device)
+    U = torch.einsum('ar,orsc,bs->aboc', G, g, G)                     # (4, 4, Cout, Cin)
+    return U.reshape(16, cout, cin).float().contiguous()

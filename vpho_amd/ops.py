@@ -178,6 +178,34 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     return ret
 
 
+def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True):
+    """3x3 / stride 1 / pad 1 convolution + bias + LeakyReLU of the inference plan: the Winograd F(2x2,3x3) kernel where its shape
+    conditions hold (even H and W, Cin % 8 == 0, Cout % 64 == 0), else the direct implicit GEMM.  The transformed weights live on the
+    weight tensor object and follow its version."""
+    N, H, W, x_ld = x.shape
+    cout, k9 = w.shape
+    cin = k9 // 9
+    if not winograd or H % 2 or W % 2 or cin % 8 or cout % 64 or x_ld != cin or getattr(_conv_split, 'terms', 0):
+        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope)
+    c = getattr(w, '_vpho_wino', None)
+    if c is None or c[0] != w._version:
+        from .model.pack import winograd_weights
+        c = (w._version, winograd_weights(w))
+        w._vpho_wino = c
+    return conv3x3_winograd(x, c[1], bias, out_slope)
+
+
+def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None):
+    """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (16, Cout, Cin)"""
+    N, H, W, x_ld = x.shape
+    _, cout, cin = u.shape
+    if out is None:
+        out = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    _call('vpho_conv3x3_winograd_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope), _f32(out),
+          I(out.shape[-1]))
+    return out
+
+
 def linear(x, w, bias=None, out_slope=1.0, out=None):
     """x: (rows, cin) fp32, w: (cout, cin) -> (rows, cout).  Same kernel as conv2d_nhwc (1x1)."""
     rows, cin = x.shape
@@ -977,7 +1005,7 @@ def physics_loss(scale_raw, logits, com, anchor, frame, point, gt_force_local, g
 
 # ----------------------------------------------------------------------------------------------- profiling hooks
 PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3,
-                'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8}
+                'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8, 'conv_winograd': 9}
 
 
 _prof_on = False
