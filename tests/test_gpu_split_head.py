@@ -140,7 +140,7 @@ def test_predict_with_winograd_agrees_with_the_default(model_cpu, assets):
         m = copy.deepcopy(model_cpu).cuda().eval()
         data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(5, assets, seed=3).items()}
         eng = Engine(m)
-        assert not eng.winograd
+        eng.winograd = False                                 # the default; set explicitly so the test also runs under VPHO_WINOGRAD=1
         g = torch.Generator().manual_seed(9)
         nh, no = torch.randn(5 * 16, 96, generator=g), torch.randn(5 * 16, 9, generator=g)
         ref = {k: v.clone() for k, v in eng.predict(data, nh, no).items() if torch.is_tensor(v)}
