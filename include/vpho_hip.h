@@ -85,6 +85,17 @@ int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
  * of the transforms (~1e-6 relative). */
 int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                    float out_slope, float* y, int y_ld, void* stream);
+/* The same convolution on RoI windows only (the FPN smoothing convolutions, backbone_FPN_HFL.py:105-108, whose maps are read only
+ * through RoIAlign, VPHO.py:126-129): wins = the (N,5) window table of vpho_roi_windows_i32, tile_base (N+1 ints, written by
+ * vpho_winograd_window_tiles_i32) = first tile of every image on the list of 2 x 2 output tiles -- on each image's EVEN pixel grid,
+ * so every pixel comes from the same 4 x 4 patch as in the full-map launch: bit-identical -- that touch its window.  y_rows is the
+ * COMPACT (rows, Cout) matrix vpho_roi_align_window_nhwc_f32 reads; x is the ordinary (N,H,W,x_ld) map, of which only the windows
+ * dilated by one pixel need to hold data.  Device-side lists: the grid is sized for all tiles, blocks past the last live tile exit
+ * (no host round trip, replays in a HIP graph with new boxes).  tiles_hint (0 = unknown) only feeds the profiling counters. */
+int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
+int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+                                        float out_slope, const int* wins, const int* tile_base, int tiles_hint, float* y_rows, int y_ld,
+                                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Score network (GenPose-style conditional denoiser) and the probability-flow ODE sampler.
@@ -243,9 +254,11 @@ int vpho_hand_candidates_f32(const float* diff_pose, int ld_diff, const float* r
 int vpho_hand_heat_f32(const float* joints, const float* root, const float* Kmat, const float* bbox, const float* heatmap,
                        int bs, int C, int J, int H, int W, const int* observe_host, int n_obs, float* out, void* stream);
 /* one cascade level (aggregation.py:215-269): score -> top-k -> weighted quaternion mean -> broadcast into all candidates.
- * val/idx: [bs][F][k] with F = 1 (level 0) or 5; topk_pose (optional) [bs][k][F][3] */
+ * val/idx: [bs][F][k] with F = 1 (level 0) or 5, in torch.topk's order (larger score first; equal scores: smaller index first);
+ * topk_pose (optional) [bs][k][F][3]; score_out (optional) [bs][C][F] = the level score of EVERY candidate exactly as ranked
+ * (aggregation.py:215-218,244-247: sum over the observed joints at level 0, per-finger mean at levels 1-3) */
 int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
-                             float* val, int* idx, float* topk_pose, void* stream);
+                             float* val, int* idx, float* topk_pose, float* score_out, void* stream);
 /* generic wavefront top-k: element c of row (o,f) at scores[(o*n + c)*F + f]; val/idx [o][f][k] */
 int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream);
 int vpho_topk_weights_f32(const float* val, int rows, int k, float* w, void* stream);

@@ -61,8 +61,8 @@ def average_rot6d(rot6d, weights=None):
 def vert2anchor(anchor, anchor_skeleton, verts):
     """physics_fn.py:224-257 -> anchors (...,32,3), frames (...,32,3,3) [columns x,y,z]."""
     face = torch.as_tensor(anchor['face_vert_idx']).reshape(-1).long()
-    aw = torch.as_tensor(anchor['anchor_weight']).float()
-    v2j = torch.as_tensor(anchor['vert2joint']).float()
+    aw = torch.as_tensor(anchor['anchor_weight']).to(verts.dtype)
+    v2j = torch.as_tensor(anchor['vert2joint']).to(verts.dtype)
     sk = torch.as_tensor(anchor_skeleton).long()
     iv = verts[..., face, :].reshape(verts.shape[:-2] + (-1, 3, 3))
     b1 = iv[..., 1, :] - iv[..., 0, :]
@@ -88,7 +88,7 @@ def local_to_global(anchor, anchor_skeleton, force_local, verts):
 
 def object_points(ycb, pose, names, which):
     """head_object.py:36-61: R(rot6d) @ p + t for the per-name table ``which`` in {kpt3d, verts_sampled, CoM}."""
-    pts = torch.stack([torch.as_tensor(ycb[n][which]).float().reshape(-1, 3) for n in names], 0)
+    pts = torch.stack([torch.as_tensor(ycb[n][which]).to(pose.dtype).reshape(-1, 3) for n in names], 0)
     rot = R.rotation_6d_to_matrix(pose[..., :6])
     return torch.einsum('bvi,b...ji->b...vj', pts, rot) + pose[..., 6:].unsqueeze(-2)
 
@@ -116,24 +116,35 @@ def _norm_to_bbox(pt2d, bbox):
 
 
 # ------------------------------------------------------------------ hand cascade  (aggregation.py:115-284)
+def hand_level_scores(mano, pose, betas, root_flip, K, heatmap, bbox, level):
+    """aggregation.py:196-218,242-248: FK of every candidate, projection, bicubic look-up of the joints of the deeper levels,
+    level sum (level 0) / per-finger mean (levels 1-3).  pose (bs,C,48), betas (bs,10) -> (bs,C) | (bs,C,5).  The arithmetic runs
+    in pose.dtype (fp32 = the reference's; fp64 = the referee of oracle/referee.py)."""
+    bs, C = pose.shape[:2]
+    observe = [j for l in range(level + 1, 5) for j in MANO_JOINT_LEVEL[l]]
+    shape = betas[:, None].expand(bs, C, 10).reshape(-1, 10)
+    _, joint = get_hand_verts(mano, pose.reshape(-1, 48), shape)
+    joint = joint.reshape(bs, C, 21, 3) + root_flip[:, None, None]
+    pt2d = _norm_to_bbox(project(joint, K), bbox)
+    hv = _bicubic_lookup(heatmap, pt2d, observe)                                            # (bs,C,m)
+    if level == 0:
+        return hv.sum(-1)
+    return hv.reshape(bs, C, len(observe) // 5, 5).mean(dim=-2)                             # (bs,C,5)
+
+
 def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, k):
     """pose_diff (bs,S,48) f32, pose_reg (bs,48), betas (bs,10).  Returns dict with fused pose (bs,48), per-level
     top-k indices, level-3 top-k distal poses (bs,k,5,3), verts/joints of the fused pose."""
     bs, S = pose_diff.shape[:2]
     pose = torch.cat([pose_diff, pose_reg[:, None].expand(bs, S, 48)], 1).clone()          # (bs,2S,48)
-    shape = betas[:, None].expand(bs, 2 * S, 10).reshape(-1, 10)
-    out = dict(topk=[], val=[], weight=[], score=[])
+    out = dict(topk=[], val=[], weight=[], score=[], state=[])
     for level in range(4):
         fuse = MANO_PARAMS_LEVEL[level]
-        observe = [j for l in range(level + 1, 5) for j in MANO_JOINT_LEVEL[l]]
         if level == 0:
             pose[:, S:, fuse] = pose[:, :S, fuse]                                           # quirk Q7
-        _, joint = get_hand_verts(mano, pose.reshape(-1, 48), shape)
-        joint = joint.reshape(bs, 2 * S, 21, 3) + root_flip[:, None, None]
-        pt2d = _norm_to_bbox(project(joint, K), bbox)
-        hv = _bicubic_lookup(heatmap, pt2d, observe)                                        # (bs,2S,m)
+        out['state'].append(pose.clone())                                                   # the candidates this level scores
+        hv = hand_level_scores(mano, pose, betas, root_flip, K, heatmap, bbox, level)       # (bs,2S) | (bs,2S,5)
         if level == 0:
-            hv = hv.sum(-1)
             val, idx = topk_stable(hv, k, dim=1)                                            # (bs,k)
             w = (val + 1e-8) / (val.sum(dim=1, keepdim=True) + 1e-8)
             sel = torch.gather(pose[:, :, fuse], 1, idx[:, :, None].expand(bs, k, 3))       # (bs,k,3)
@@ -141,8 +152,6 @@ def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, 
             aa = R.quaternion_to_axis_angle(average_quaternion(q, w[:, None])).reshape(bs, 3)
             pose[:, :, fuse] = pose[:, :, fuse] * 0 + aa[:, None]
         else:
-            n_obs = len(observe) // 5
-            hv = hv.reshape(bs, 2 * S, n_obs, 5).mean(dim=-2)                               # (bs,2S,5)
             val, idx = topk_stable(hv, k, dim=1)                                            # (bs,k,5)
             w = ((val + 1e-8) / (val.sum(dim=1, keepdim=True) + 1e-8)).permute(0, 2, 1)     # (bs,5,k)
             jid = torch.tensor(fuse).reshape(5, 3)[:, 0] // 3
@@ -164,12 +173,17 @@ def hand_cascade(mano, pose_diff, pose_reg, betas, root_flip, K, heatmap, bbox, 
 
 
 # ------------------------------------------------------------------ object selection (aggregation.py:742-780,947-997)
-def obj_heat_topk(ycb, pose6d, root, names, is_right, K, heatmap, bbox, k):
-    p = pose6d.clone().float()
+def obj_heat_scores(ycb, pose6d, root, names, is_right, K, heatmap, bbox, dtype=torch.float32):
+    """aggregation.py:753-777 (the reference casts the fp64 poses with .float(), :753; dtype=float64: the referee)"""
+    p = pose6d.clone().to(dtype)
     p[..., 6:] = p[..., 6:] + root.unsqueeze(1)
     pt = flip_x(object_points(ycb, p, names, 'kpt3d'), is_right)
     pt2d = _norm_to_bbox(project(pt, K), bbox)
-    hv = _bicubic_lookup(heatmap, pt2d, list(range(heatmap.shape[1]))).sum(-1)
+    return _bicubic_lookup(heatmap, pt2d, list(range(heatmap.shape[1]))).sum(-1)
+
+
+def obj_heat_topk(ycb, pose6d, root, names, is_right, K, heatmap, bbox, k):
+    hv = obj_heat_scores(ycb, pose6d, root, names, is_right, K, heatmap, bbox)
     val, idx = topk_stable(hv, k, dim=1)
     return idx, (val + 1e-8) / (val.sum(dim=1, keepdim=True) + 1e-8), hv
 
@@ -180,8 +194,9 @@ def nearest(x, y):
     return d.min(dim=-1)
 
 
-def obj_physics_topk(ycb, pose6d, root, names, is_right, force_point, force_global, k):
-    p = pose6d.clone().float()
+def obj_physics_scores(ycb, pose6d, root, names, is_right, force_point, force_global, dtype=torch.float32):
+    """aggregation.py:958-987"""
+    p = pose6d.clone().to(dtype)
     p[..., 6:] = p[..., 6:] + root.unsqueeze(1)
     verts = flip_x(object_points(ycb, p, names, 'verts_sampled'), is_right)                # (bs,n,2048,3)
     com = flip_x(object_points(ycb, p, names, 'CoM'), is_right)                            # (bs,n,1,3)
@@ -193,7 +208,11 @@ def obj_physics_topk(ycb, pose6d, root, names, is_right, force_point, force_glob
     nn_v = torch.gather(verts, 2, amin[..., None].expand(*amin.shape, 3))
     r = force_point[:, None] - nn_v - com
     L = torch.cross(fg[:, None].expand_as(r), r, dim=-1).sum(-2).norm(dim=-1)
-    score = -(score * L)
+    return -(score * L)
+
+
+def obj_physics_topk(ycb, pose6d, root, names, is_right, force_point, force_global, k):
+    score = obj_physics_scores(ycb, pose6d, root, names, is_right, force_point, force_global)
     val, idx = topk_stable(score, k, dim=1)
     return idx, torch.ones_like(val) / k, score
 
@@ -207,7 +226,8 @@ def fuse_topk(pose6d, idx, weight):
 
 
 # ------------------------------------------------------------------ hand physics (aggregation.py:537-626)
-def hand_physics(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, obj_vert, k):
+def hand_physics_scores(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, obj_vert):
+    """aggregation.py:553-592: per-finger pseudo-force score of every candidate -> (bs,5,n)"""
     bs, n = pose58.shape[:2]
     p = pose58.reshape(-1, 58)
     vert, _ = get_hand_verts(mano, p[:, :48], p[:, 48:])
@@ -219,10 +239,16 @@ def hand_physics(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, 
     dmin, _ = nearest(fp, obj_vert[:, None])
     I = (fg / fn[..., None]).sum(-2).norm(dim=-1)
     score = -(fw * dmin * I[:, :, None])
+    return torch.stack([score[:, :, FINGER_FORCE_LEVEL[f]].sum(dim=-1) for f in range(5)], 1)
+
+
+def hand_physics(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, obj_vert, k):
+    bs, n = pose58.shape[:2]
+    score = hand_physics_scores(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, obj_vert)
     fuse = pose58[:, 0].clone()
     topks, scores = [], []
     for f in range(5):
-        fs = score[:, :, FINGER_FORCE_LEVEL[f]].sum(dim=-1)
+        fs = score[:, f]
         _, idx = topk_stable(fs, k, dim=1)
         fidx = MANO_PARAMS_LEVEL[2][3 * f:3 * f + 3] + MANO_PARAMS_LEVEL[3][3 * f:3 * f + 3]
         sel = torch.gather(pose58[:, :, fidx], 1, idx[:, :, None].expand(bs, k, 6)).reshape(bs, k, 2, 3)
@@ -277,4 +303,5 @@ def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, ro
     return dict(obj_agg_6d=obj_fused, pose6d_candidate=cand, agg_obj_vert=obj_vert,
                 hand_agg_mano=hp['agg_pose'], hand_agg_vert=hp['agg_vert'], hand_agg_joint=hp['agg_joint'],
                 dbg=dict(hand=h, transl_topk=t_idx, rot_topk=r_idx, phys_topk=p_idx, heat_topk=m_idx,
-                         phys_score=p_score, transl_score=t_hv, rot_score=r_hv, heat_score=m_hv, hand_phys=hp, cascade_mano=agg_mano, force_point=fpnt, force_global=fglob))
+                         phys_score=p_score, transl_score=t_hv, rot_score=r_hv, heat_score=m_hv, hand_phys=hp, cascade_mano=agg_mano, force_point=fpnt, force_global=fglob,
+                         transl=transl, obj_vert=obj_vert, pose6d_candidate=cand))

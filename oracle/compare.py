@@ -61,6 +61,63 @@ def _list_diff(got, want, score, ranked):
     return len(only_a), max(gaps)
 
 
+def _margin(sc, lst, ranked):
+    """smallest score distance a perturbation has to bridge to change the list: sc (C,), lst (k,).  Sets: min over (picked i, unpicked
+    j, sc_i != sc_j) of |sc_i - sc_j|; ranked: the smallest positive gap between neighbours of the k + 1 best."""
+    if ranked:
+        d = torch.sort(sc, descending=True).values[:lst.numel() + 1]
+        g = d[:-1] - d[1:]
+        g = g[g > 0]
+    else:
+        m = torch.zeros(sc.numel(), dtype=torch.bool)
+        m[lst] = True
+        g = (sc[m][:, None] - sc[~m][None, :]).abs().reshape(-1)
+        g = g[g > 0]
+    return float(g.min()) if g.numel() else float('inf')
+
+
+def guaranteed_identical(gd, od):
+    """Which lists MUST come out identical on the two sides, from their own score vectors: if every candidate's score differs by at most d
+    between the sides and the reference's list has a margin above 2 d, both top-k are the same list (order statistics of vectors that
+    differ by <= d differ by <= d) -- no bound is chosen, d is the measured deviation of that (image, stage).  gd needs the tested
+    side's complete score vectors (Engine.keep_states).  -> {stage: (bs,) bool}; a stage only counts when its dependencies do."""
+    h, hp = od['hand'], od['hand_phys']
+    bs = h['topk'][0].shape[0]
+    pairs = {}
+    for lvl in range(4):
+        want, sc = h['topk'][lvl].long(), h['score'][lvl].double()
+        if want.dim() == 2:
+            want, sc = want[:, :, None], sc[:, :, None]
+        pairs[f'hand_level{lvl}'] = (_c(gd['hand_score'][lvl]).double().reshape(sc.shape), sc, want, lvl == 3)
+    for st, key, skey in (('obj_transl', 'transl_topk', 'transl_score'), ('obj_rot', 'rot_topk', 'rot_score'),
+                          ('obj_physics', 'phys_topk', 'phys_score'), ('obj_heat', 'heat_topk', 'heat_score')):
+        sc = od[skey].double()[:, :, None]
+        pairs[st] = (_c(gd[skey]).double().reshape(sc.shape), sc, od[key].long()[:, :, None], False)
+    sc = hp['score'].double().permute(0, 2, 1)
+    pairs['hand_physics'] = (_c(gd['hand_phys_score']).double().reshape(sc.shape), sc, hp['topk'].long().permute(0, 2, 1), False)
+    ok = {}
+    for st, (got, ref, lst, ranked) in pairs.items():
+        g = torch.ones(bs, dtype=torch.bool)
+        for b in range(bs):
+            for f in range(ref.shape[2]):
+                d = float((got[b, :, f] - ref[b, :, f]).abs().max())
+                g[b] &= _margin(ref[b, :, f], lst[b, :, f], ranked) > 2 * d
+        ok[st] = g
+    hand_chain = ['hand_level0', 'hand_level1', 'hand_level2', 'hand_level3']
+    obj_chain = ['obj_transl', 'obj_rot', 'obj_heat']
+    deps = {s_: hand_chain[:i] for i, s_ in enumerate(hand_chain)}
+    deps.update({s_: obj_chain[:i] for i, s_ in enumerate(obj_chain)})
+    deps['obj_physics'] = hand_chain + ['obj_transl', 'obj_rot']
+    deps['hand_physics'] = hand_chain + obj_chain + ['obj_physics']
+    out = {}
+    for st in hand_chain + obj_chain + ['obj_physics', 'hand_physics']:
+        g = ok[st].clone()
+        for d_ in deps[st]:
+            g &= out[d_]
+        out[st] = g
+    return out
+
+
 def selection_report(gd, od, S):
     """gd: ``Engine.last_info['agg']`` of the HIP path (hand_topk[lvl] (bs,F,k) int32, hand_phys_topk (bs,5,kp), transl_topk ...);
     od: the oracle's ``dbg`` (oracle.aggregation.hoi_aggregate) for the SAME images.
@@ -156,8 +213,15 @@ def selection_report(gd, od, S):
                          images_consequent=int(((n_diff[s] > 0) & ~clean_before).sum()))
     hand_diff = sum(n_diff[s] for s in hand_chain + ['hand_physics'])
     obj_diff = sum(n_diff[s] for s in obj_chain + ['obj_physics'])
-    return dict(hand_differences_per_image=hand_diff, object_differences_per_image=obj_diff, primary_gap_per_image=primary_gap,
-                detail=detail)
+    rep = dict(hand_differences_per_image=hand_diff, object_differences_per_image=obj_diff, primary_gap_per_image=primary_gap,
+               detail=detail)
+    if 'hand_score' in gd:
+        # lists the two sides' own scores force to be identical (guaranteed_identical): a difference there is a selection error
+        g = guaranteed_identical(gd, od)
+        rep['guaranteed_lists'] = int(sum(int(v.sum()) for v in g.values()))
+        rep['guaranteed_images'] = int(torch.stack(list(g.values())).all(0).sum())
+        rep['guaranteed_but_different'] = {st: int((g[st] & (n_diff[st] > 0)).sum()) for st in stages if bool((g[st] & (n_diff[st] > 0)).any())}
+    return rep
 
 
 def parity_summary(out, ref, gd, od, S, bound=TIE_REL):
@@ -176,6 +240,9 @@ def parity_summary(out, ref, gd, od, S, bound=TIE_REL):
                images_first_difference_is_a_tie=int(((~all_clean) & (pg <= TIE_REL)).sum()),
                images_with_wrong_selection=int((pg > TIE_REL).sum()),
                max_rel_score_gap_at_first_differences=float(pg.max()), tie_bound=TIE_REL, per_stage=rep['detail'])
+    for k in ('guaranteed_lists', 'guaranteed_images', 'guaranteed_but_different'):
+        if k in rep:
+            res[k] = rep[k]
     for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_hand_mano'):
         e = d(k)
         res[f'max_abs_{k}_where_identical'] = float(e[hand_clean].max()) if bool(hand_clean.any()) else None

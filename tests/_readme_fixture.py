@@ -1,8 +1,9 @@
 """Shared comparison against the reference's own forward at the README config (tests/golden/golden_predict_readme.npz, written by
 tests/golden/make_golden_readme.py: 8 images in one batch, sample_num=100, sampling_steps=50, top-k 30/10, sample_T0=0.65).
 
-Continuous outputs to a tolerance; every selected index list against the reference's through oracle/compare.py: indices equal,
-except where the two candidates' scores -- both read from the REFERENCE's own score vector -- differ by less than a FIXED bound
+Continuous outputs to a tolerance; every selected index list against the reference's through oracle/compare.py: indices equal
+(every list the two sides' own score vectors force to be identical -- guaranteed_identical -- must be, when the tested side supplies
+its score vectors), except where the two candidates' scores -- both read from the REFERENCE's own score vector -- differ by less than a FIXED bound
 (oracle/compare.py: E2E_TIE_REL when each side ranks its own hypotheses).  The aggregated poses are asserted on every image whose
 selections are identical, and -- for the HIP path -- on ALL images."""
 import os

@@ -1,0 +1,42 @@
+"""Shared helpers of the referee-based top-k parity tests (oracle/referee.py)."""
+import copy
+
+import torch
+
+BS, S, STEPS, KH, KO, T0 = 64, 100, 50, 30, 10, 0.65
+
+
+def run_hip(model_cpu, assets, data, nh, no, cfg_values=None):
+    """HIP predict at the README config with the cascade states kept -> (out, last_info)"""
+    from vpho_amd.configs.args import cfg
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = cfg_values or (S, STEPS, KH, KO, T0)
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        gdata = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        m(gdata, mode='predict')                                   # builds the engine
+        m._engine.keep_states = True
+        out = m._engine.predict(gdata, noise_hand=nh, noise_obj=no)
+        torch.cuda.synchronize()
+        return out, m._engine.last_info
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+
+
+def assert_within_reference_noise(rep, tag=''):
+    from oracle import referee as RF
+    s = RF.summary(rep)
+    print(f'[referee]{tag} images {s["images"]}: fp64-optimal in every list: HIP {s["images_identical_to_fp64_order"]}, fp32 oracle on the same '
+          f'candidates {s["images_identical_to_fp64_order_fp32_reference"]}; regret max HIP {s["regret_max_rel"]:.2e}, oracle {s["regret_max_rel_fp32_reference"]:.2e}')
+    for st, p in s['per_stage'].items():
+        print(f'   {st:13s} eps32 {p["eps32_rel"]:.2e} (tested side {p["eps_tested_rel"] or 0:.2e})  regret HIP {p["regret_max_rel"]:.2e} / oracle {p["regret32_max_rel"]:.2e}  optimal {p["images_optimal"]}/{p["images_optimal_fp32_reference"]}'
+              f'  lists differ {p["images_list_differs_from_fp32_reference"]} (exchange gap {p["exchange_gap_max_rel"]:.2e})')
+    for st, r in rep.items():
+        if r['list_is_topk_of_own_scores'] is not None:                # the top-k kernels: exactly the stable descending order of their own scores
+            assert r['list_is_topk_of_own_scores'], st
+        assert float(r['regret_rel'].max()) <= r['bound_rel'], (st, float(r['regret_rel'].max()), r['bound_rel'])
+        assert float(r['exchange_gap_rel'].max()) <= r['bound_rel'], (st, float(r['exchange_gap_rel'].max()), r['bound_rel'])
+        # sanity: the noise of the reference's arithmetic is fp32 rounding (1e-6 ... 1e-5 of the score scale for the heat-map sums after FK and
+        # projection; ~1e-3 for the object physics score, whose torque term sums 32 cross products that nearly cancel), not a formula difference
+        assert r['eps32_rel'] < 1e-2, (st, r['eps32_rel'])
+    return s

@@ -129,6 +129,48 @@ def test_roi_windows_give_bit_identical_roi_align(C, k):
     assert int(win.count) == N * H * W and torch.equal(win.row_map.cpu(), torch.arange(N * H * W, dtype=torch.int32))
 
 
+@pytest.mark.parametrize('Cin,Cout', [(32, 64), (64, 256)])
+def test_winograd_on_roi_windows_is_bit_identical_to_the_full_map(Cin, Cout):
+    """vpho_conv3x3_winograd_rows_nhwc_f32: the tiles of every image's even grid that touch its window, written as the compact window
+    matrix, equal the full-map Winograd launch bit for bit on every window pixel -- also when everything outside the window dilated by
+    the 3x3 halo is NaN (a tile row / column that only serves pixels outside the window never mixes into the ones inside) -- and
+    RoIAlign through the window table gives the full map's result."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import winograd_weights
+    g = torch.Generator().manual_seed(Cin + Cout)
+    N, H, W, R = 10, 64, 64, 32
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 9 * Cin, generator=g) * 0.1).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    u = winograd_weights(w)
+    full = ops.conv3x3_winograd(x, u, b, out_slope=0.3)
+    ba, bb = _window_boxes(g, N, 256.0).cuda(), _window_boxes(torch.Generator().manual_seed(9), N, 256.0).roll(2, 0).cuda()
+    for boxes_b in (bb, None):
+        win = ops.roi_windows(ba, boxes_b, N, H, W, 0.25)
+        halo = ops.roi_windows(ba, boxes_b, N, H, W, 0.25, dilate=1)
+        _, hmask = halo.to_map(torch.zeros(N * H * W, 1).cuda())
+        xn = torch.where(hmask[..., None], x, torch.full_like(x, float('nan')))
+        rows = torch.full((N * H * W, Cout), -7.0).cuda()
+        ops.conv3x3_winograd(xn, u, b, out_slope=0.3, rows=win, out=rows)
+        n_rows = int(win.count)
+        scat, mask = win.to_map(rows)
+        assert torch.equal(scat[mask], full[mask]) and bool((rows[n_rows:] == -7.0).all())
+        wins, tiles = win.wins.cpu(), win.tiles().cpu()
+        per = (((wins[:, 1] + wins[:, 4] - 1) >> 1) - (wins[:, 1] >> 1) + 1) * (((wins[:, 2] + wins[:, 3] - 1) >> 1) - (wins[:, 2] >> 1) + 1)
+        assert torch.equal(tiles[1:], torch.cumsum(per, 0).int()) and int(tiles[0]) == 0 and bool((wins[:, 1:3] % 2 == 1).any())
+        got = ops.roi_align_nhwc(rows, ba, R, 0.25, win=win)
+        assert torch.equal(got, ops.roi_align_nhwc(full, ba, R, 0.25))
+    # through ops.conv3x3 (weights transformed on first use); shapes the Winograd kernel does not take fall back to the direct pixel list
+    win = ops.roi_windows(ba, None, N, H, W, 0.25)
+    assert torch.equal(ops.conv3x3(x, w, b, out_slope=0.3, rows=win)[:int(win.count)], win_rows(full, win))
+    assert torch.equal(ops.conv3x3(x, w, b, winograd=False, rows=win), ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, rows=win))
+
+
+def win_rows(full, win):
+    n = int(win.count)
+    return full.reshape(-1, full.shape[-1])[win.row_map[:n].long()]
+
+
 def test_features_with_and_without_roi_windows_are_identical(model_cpu, assets):
     """Engine.features with the FPN outputs restricted to the RoI windows (default) against VPHO_ROI_WINDOW=0 (full maps): every
     tensor downstream of the RoIAligns is bit-identical."""

@@ -128,8 +128,8 @@ def test_split_bf16_conv_on_a_pixel_list():
 
 
 def test_predict_with_winograd_agrees_with_the_default(model_cpu, assets):
-    """opt-in VPHO_WINOGRAD=1 (3x3 / stride-1 convolutions of the feature path in Winograd form) against the default engine: same step
-    sequences of both solves, feature-path outputs to 1e-5 of their range, samples within the north-star 1e-3 (observed ~1e-5)."""
+    """the default plan (3x3 / stride-1 convolutions of the feature path in Winograd form) against VPHO_WINOGRAD=0 (the direct implicit
+    GEMM everywhere): same step sequences of both solves, feature-path outputs to 1e-5 of their range, samples within the north-star 1e-3 (observed ~1e-5)."""
     import copy
     from vpho_amd.configs.args import cfg
     from vpho_amd.model.engine import Engine
@@ -140,7 +140,7 @@ def test_predict_with_winograd_agrees_with_the_default(model_cpu, assets):
         m = copy.deepcopy(model_cpu).cuda().eval()
         data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(5, assets, seed=3).items()}
         eng = Engine(m)
-        eng.winograd = False                                 # the default; set explicitly so the test also runs under VPHO_WINOGRAD=1
+        eng.winograd = False                                 # direct kernels; set explicitly so the test does not depend on VPHO_WINOGRAD
         g = torch.Generator().manual_seed(9)
         nh, no = torch.randn(5 * 16, 96, generator=g), torch.randn(5 * 16, 9, generator=g)
         ref = {k: v.clone() for k, v in eng.predict(data, nh, no).items() if torch.is_tensor(v)}

@@ -163,53 +163,86 @@ struct FuseArgs {
     int jid[5];
     float* val; int* idx;                 // [b][f][k]
     float* topk_pose;                     // [b][k][F][3] gathered axis-angle (aggregation.py:254) or NULL
+    float* score_out;                     // [b][C][F] the score of every candidate as ranked here, or NULL
 };
-template <int TOPK_SLOTS>
-__global__ __launch_bounds__(64) void hand_fuse_kernel(const FuseArgs a) {
-    __shared__ float s_val[64];
+// One 256-thread workgroup per (image, slot).  Ranking by COUNTING instead of k rounds of arg-max: thread c holds candidate c (+256, ...)
+// and counts the candidates that precede it in "larger value first, then smaller index" order -- every thread reads the same LDS
+// word per step (broadcast), no dependent shuffles -- so rank < k IS the position in the stable descending sort (torch.topk's order
+// wherever that is defined).  The k picks are then converted to quaternions by k lanes at once; the weighted moment matrix
+// sum_r w_r q_r q_r^T is accumulated entry by entry (16 lanes) in ascending r, the same order and the same operations as a serial
+// loop, so the fused rotation is bit-identical to it.
+constexpr int FUSE_THREADS = 256;
+template <int SLOTS>
+__global__ __launch_bounds__(FUSE_THREADS) void hand_fuse_kernel(const FuseArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_v[SLOTS * FUSE_THREADS];
+    __shared__ float s_val[64], s_w[64], s_q[64][4], s_A[16], s_aa[3];
     __shared__ int s_idx[64];
-    __shared__ float s_aa[3];
     const int F = a.level == 0 ? 1 : 5;
-    const int b = blockIdx.x / F, f = blockIdx.x % F, lane = threadIdx.x;
+    const int b = blockIdx.x / F, f = blockIdx.x % F, tid = threadIdx.x;
     const int n_obs = a.level == 0 ? a.n_obs_total : a.n_obs_total / 5;
-    float v[TOPK_SLOTS];
+    float v[SLOTS];
 #pragma unroll
-    for (int s = 0; s < TOPK_SLOTS; ++s) {
-        const int c = s * 64 + lane;
+    for (int s = 0; s < SLOTS; ++s) {
+        const int c = s * FUSE_THREADS + tid;
         float sc = -INFINITY;
         if (c < a.C) {
             const float* h = a.hv + ((long long)b * a.C + c) * a.n_obs_total;
             sc = 0.f;
             if (a.level == 0) { for (int o = 0; o < n_obs; ++o) sc += h[o]; }
             else { for (int l = 0; l < n_obs; ++l) sc += h[l * 5 + f]; sc = sc / (float)n_obs; }
+            if (a.score_out) a.score_out[((long long)b * a.C + c) * F + f] = sc;
             if (sc != sc) sc = INFINITY;           // NaN ranks first, as in torch.topk; keeps every index in range
         }
         v[s] = sc;
+        s_v[c] = sc;                               // entries past C: -inf with an index above every candidate's
     }
-    wave_topk(v, a.C, a.k, lane, s_val, s_idx);
+    __syncthreads();
+    int rank[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) rank[s] = 0;
+    const int n4 = (a.C + 3) & ~3;
+    for (int j = 0; j < n4; j += 4) {
+        const float4 o = *reinterpret_cast<const float4*>(s_v + j);
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) rank[s] += (ov[u] > v[s] || (ov[u] == v[s] && j + u < s * FUSE_THREADS + tid)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int c = s * FUSE_THREADS + tid;
+        if (c < a.C && rank[s] < a.k) { s_val[rank[s]] = v[s]; s_idx[rank[s]] = c; }
+    }
     __syncthreads();
     const int joint = a.level == 0 ? 0 : a.jid[f];
     float* P = a.pose + (long long)b * a.C * 48 + joint * 3;
-    if (lane == 0) {
+    if (tid < a.k) {
+        const int r = tid;
         float vsum = 0.f;
-        for (int r = 0; r < a.k; ++r) vsum += s_val[r];
-        float A[4][4] = {{0}};
-        float wsum = 0.f;
-        for (int r = 0; r < a.k; ++r) {
-            const float w = (s_val[r] + 1e-8f) / (vsum + 1e-8f);
-            const float* aa = P + (long long)s_idx[r] * 48;
-            float q[4];
-            vpho::axis_angle_to_quaternion(aa, q);
-            const float sg = q[0] > 0.f ? 1.f : -1.f;
-            for (int i = 0; i < 4; ++i) q[i] *= sg;
-            for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) A[i][j] += (q[i] * q[j]) * w;
-            wsum += w;
-            a.val[((long long)b * F + f) * a.k + r] = s_val[r];
-            a.idx[((long long)b * F + f) * a.k + r] = s_idx[r];
-            if (a.topk_pose) { float* tp = a.topk_pose + (((long long)b * a.k + r) * F + f) * 3; tp[0] = aa[0]; tp[1] = aa[1]; tp[2] = aa[2]; }
-        }
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) A[i][j] /= wsum;
-        float qa[4], aa[3];
+        for (int i = 0; i < a.k; ++i) vsum += s_val[i];
+        const float* aa = P + (long long)s_idx[r] * 48;
+        const float ax[3] = {aa[0], aa[1], aa[2]};
+        float q[4];
+        vpho::axis_angle_to_quaternion(ax, q);
+        const float sg = q[0] > 0.f ? 1.f : -1.f;
+        for (int i = 0; i < 4; ++i) s_q[r][i] = q[i] * sg;
+        s_w[r] = (s_val[r] + 1e-8f) / (vsum + 1e-8f);
+        a.val[((long long)b * F + f) * a.k + r] = s_val[r];
+        a.idx[((long long)b * F + f) * a.k + r] = s_idx[r];
+        if (a.topk_pose) { float* tp = a.topk_pose + (((long long)b * a.k + r) * F + f) * 3; tp[0] = ax[0]; tp[1] = ax[1]; tp[2] = ax[2]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int i = tid >> 2, j = tid & 3;
+        float acc = 0.f, wsum = 0.f;
+        for (int r = 0; r < a.k; ++r) { acc += (s_q[r][i] * s_q[r][j]) * s_w[r]; wsum += s_w[r]; }
+        s_A[tid] = acc / wsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float A[4][4], qa[4], aa[3];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) A[i][j] = s_A[i * 4 + j];
         vpho::sym4_top_eigenvector(A, qa);
         const float sg = qa[0] > 0.f ? 1.f : -1.f;
         for (int i = 0; i < 4; ++i) qa[i] *= sg;
@@ -218,8 +251,7 @@ __global__ __launch_bounds__(64) void hand_fuse_kernel(const FuseArgs a) {
     }
     __syncthreads();
     // broadcast the fused value into every candidate: x*0 + fused (NaN/Inf in x propagate like the reference)
-    for (int c = lane; c < a.C; c += 64)
-        for (int e = 0; e < 3; ++e) { float* p = P + (long long)c * 48 + e; *p = *p * 0.f + s_aa[e]; }
+    for (int i = tid; i < a.C * 3; i += FUSE_THREADS) { float* p = P + (long long)(i / 3) * 48 + (i % 3); *p = *p * 0.f + s_aa[i % 3]; }
 }
 
 // ---------------------------------------------------------------------------------------- CPF anchors / forces
@@ -537,7 +569,7 @@ extern "C" int vpho_hand_heat_f32(const float* joints, const float* root, const 
 }
 
 extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
-                                        float* val, int* idx, float* topk_pose, void* stream) {
+                                        float* val, int* idx, float* topk_pose, float* score_out, void* stream) {
     VPHO_REQUIRE(hv && pose && val && idx && bs > 0 && C > 0 && level >= 0 && level <= 3, "vpho_hand_fuse_level_f32: bad argument");
     VPHO_REQUIRE(k > 0 && k <= C && k <= 64, "selected index k out of range (topk_hand=%d, candidates=%d, max 64)", k, C);
     VPHO_REQUIRE(C <= 64 * TOPK_MAX_SLOTS, "vpho_hand_fuse_level_f32: at most %d candidates per image", 64 * TOPK_MAX_SLOTS);
@@ -546,12 +578,14 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
     FuseArgs a;
     a.hv = hv; a.n_obs_total = n_obs; a.pose = pose; a.bs = bs; a.C = C; a.k = k; a.level = level;
     for (int f = 0; f < 5; ++f) a.jid[f] = jid[level][f];
-    a.val = val; a.idx = idx; a.topk_pose = topk_pose;
+    a.val = val; a.idx = idx; a.topk_pose = topk_pose; a.score_out = score_out;
     // algorithmic bytes: the score table read once, the fused joints (3 or 5 x 3 floats) written into every candidate's pose
     vpho::ProfScope prof(vpho::PROF_HAND_FUSE, (hipStream_t)stream, 0.0,
                          (double)bs * C * ((double)n_obs * 4 + (level == 0 ? 3 : 15) * 4) + (double)bs * (level == 0 ? 1 : 5) * k * 8);
-    if (C <= 512) hipLaunchKernelGGL(hand_fuse_kernel<8>, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(hand_fuse_kernel<16>, dim3(bs * (level == 0 ? 1 : 5)), dim3(64), 0, (hipStream_t)stream, a);
+    const dim3 grid(bs * (level == 0 ? 1 : 5));
+    if (C <= FUSE_THREADS) hipLaunchKernelGGL(hand_fuse_kernel<1>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
+    else if (C <= 2 * FUSE_THREADS) hipLaunchKernelGGL(hand_fuse_kernel<2>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(hand_fuse_kernel<4>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
     return vpho::check_launch("hand_fuse_kernel");
 }
 

@@ -27,7 +27,31 @@ struct WinoArgs {
     int N, H, W, Cin, x_ld, Cout, y_ld;
     int TH, TW, T;                             // tiles per column / row / in total
     float out_slope;
+    // RoI windows (vpho_roi_windows_i32): only the 2 x 2 tiles -- on the image's even grid, so a pixel is computed from the same 4 x 4
+    // patch as in the full map: bit-identical -- that touch an image's window; y = the COMPACT (rows, Cout) matrix of the window pixels
+    const int* wins;                           // [N][5] = (first row, y0, x0, w, h) or NULL
+    const int* tile_base;                      // [N + 1] first tile of every image; [N] = live tiles (vpho_winograd_window_tiles_i32)
 };
+
+// tile t -> image n, tile coordinates (ty, tx) on the image's even grid; false past the last live tile
+__device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int& tx) {
+    if (!a.wins) {
+        if (t >= a.T) return false;
+        n = t / (a.TH * a.TW);
+        const int rem = t - n * a.TH * a.TW;
+        ty = rem / a.TW; tx = rem - ty * a.TW;
+        return true;
+    }
+    if (t >= a.tile_base[a.N]) return false;
+    int lo = 0, hi = a.N - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_base[mid] <= t) lo = mid; else hi = mid - 1; }
+    n = lo;
+    const int* w = a.wins + 5 * n;
+    const int tx0 = w[2] >> 1, ntx = ((w[2] + w[3] - 1) >> 1) - tx0 + 1;
+    const int lt = t - a.tile_base[n];
+    ty = (w[1] >> 1) + lt / ntx; tx = tx0 + lt % ntx;
+    return true;
+}
 
 __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -36,17 +60,32 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     const int ncb = a.Cout / W_CB;
     const int tb = blockIdx.x / ncb, cb = blockIdx.x % ncb;
     const int t0 = tb * W_TB, c0 = cb * W_CB;
+    if (a.wins && t0 >= a.tile_base[a.N]) return;      // the grid is sized for every tile of the full maps; uniform per workgroup
+    // destination of every tile of this block (output transform): row of its top-left pixel in y, row pitch, which of the 4 pixels exist
+    __shared__ int s_row[W_TB], s_pitch[W_TB];
+    if (tid < W_TB) {
+        int n, ty, tx, row = 0, pitch = (a.W << 4);
+        if (wino_tile(a, t0 + tid, n, ty, tx)) {
+            if (!a.wins) { row = (n * a.H + 2 * ty) * a.W + 2 * tx; pitch = (a.W << 4) | 0xF; }
+            else {
+                const int* w = a.wins + 5 * n;
+                const int y = 2 * ty - w[1], x = 2 * tx - w[2];              // window coordinates of the tile's top-left pixel (may be -1)
+                const int my = (y >= 0 ? 1 : 0) | (y + 1 < w[4] ? 2 : 0), mx = (x >= 0 ? 1 : 0) | (x + 1 < w[3] ? 2 : 0);
+                row = w[0] + y * w[3] + x;
+                pitch = (w[3] << 4) | ((my & 1) && (mx & 1) ? 1 : 0) | ((my & 1) && (mx & 2) ? 2 : 0) | ((my & 2) && (mx & 1) ? 4 : 0) | ((my & 2) && (mx & 2) ? 8 : 0);
+            }
+        }
+        s_row[tid] = row; s_pitch[tid] = pitch;
+    }
 
     // ---- V producer: thread = (tile tl, channel pair cp): its 4 x 4 input patch, two channels (8-byte loads)
     // the four channel pairs of a pixel sit on four neighbouring lanes: one wave instruction reads 16 pixels x 32 contiguous bytes
     const int tl = wave * 16 + (lane >> 2), cp = lane & 3;
-    const int t = t0 + tl;
-    const bool tile_live = t < a.T;
     int pn = 0, py0 = 0, px0 = 0;
-    if (tile_live) {
-        pn = t / (a.TH * a.TW);
-        const int rem = t - pn * a.TH * a.TW;
-        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    bool tile_live;
+    {
+        int ty = 0, tx = 0;
+        tile_live = wino_tile(a, t0 + tl, pn, ty, tx);
         py0 = 2 * ty - 1; px0 = 2 * tx - 1;
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -147,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     const float bias = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int trow = t0 + wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float s0[4], s1[4];
 #pragma unroll
         for (int fx = 0; fx < 4; ++fx) {
@@ -156,22 +195,55 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         }
         const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
         const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-        if (trow < a.T && co < a.Cout) {
-            const int n = trow / (a.TH * a.TW), rem = trow - n * a.TH * a.TW;
-            const int ty = rem / a.TW, tx = rem - ty * a.TW;
-            float* yp = a.y + ((long long)(n * a.H + 2 * ty) * a.W + 2 * tx) * a.y_ld + co;
+        const int pm = s_pitch[trow];
+        if ((pm & 0xF) && co < a.Cout) {
+            const int pitch = pm >> 4;
+            float* yp = a.y + (long long)s_row[trow] * a.y_ld + co;
             const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
-            const long long offs[4] = {0, (long long)a.y_ld, (long long)a.W * a.y_ld, (long long)(a.W + 1) * a.y_ld};
+            const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { const float v = o[p]; yp[offs[p]] = v > 0.f ? v : v * a.out_slope; }
+            for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) { const float v = o[p]; yp[offs[p]] = v > 0.f ? v : v * a.out_slope; }
         }
     }
 }
 
 }  // namespace
 
+// tile_base[n] = first tile of image n, tile_base[N] = number of live tiles: the 2 x 2 tiles of the even grid that touch window n
+__global__ void wino_tile_base_kernel(const int* __restrict__ wins, int N, int* __restrict__ tile_base) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int n = 0; n < N; ++n) {
+        const int* w = wins + 5 * n;
+        tile_base[n] = base;
+        base += (((w[1] + w[4] - 1) >> 1) - (w[1] >> 1) + 1) * (((w[2] + w[3] - 1) >> 1) - (w[2] >> 1) + 1);
+    }
+    tile_base[N] = base;
+}
+
+static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
+                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream);
+
+extern "C" int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream) {
+    VPHO_REQUIRE(wins && tile_base && N > 0, "vpho_winograd_window_tiles_i32: bad argument");
+    hipLaunchKernelGGL(wino_tile_base_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wins, N, tile_base);
+    return vpho::check_launch("wino_tile_base_kernel");
+}
+
+extern "C" int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld,
+                                                   int Cout, float out_slope, const int* wins, const int* tile_base, int tiles_hint,
+                                                   float* y_rows, int y_ld, void* stream) {
+    VPHO_REQUIRE(wins && tile_base, "vpho_conv3x3_winograd_rows_nhwc_f32: bad argument");
+    return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, wins, tile_base, tiles_hint, y_rows, y_ld, stream);
+}
+
 extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                               float out_slope, float* y, int y_ld, void* stream) {
+    return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, nullptr, nullptr, 0, y, y_ld, stream);
+}
+
+static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
+                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream) {
     VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
     VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % WK == 0 && Cout % W_CB == 0 && x_ld % 2 == 0 && x_ld >= Cin && y_ld >= Cout,
                  "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 8 == 0, Cout %% 64 == 0");
@@ -179,6 +251,7 @@ extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, co
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
+    a.wins = wins; a.tile_base = tile_base;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {
@@ -187,8 +260,10 @@ extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, co
     }
     const int tbs = (a.T + W_TB - 1) / W_TB;
     // executed flops: 16 GEMMs of T x Cout x Cin (the direct 3x3 would be 2.25 x this)
-    vpho::ProfScope prof(vpho::PROF_WINOGRAD, (hipStream_t)stream, 2.0 * 16.0 * a.T * Cout * (double)Cin,
-                         4.0 * ((double)N * H * W * Cin + 16.0 * Cout * Cin + (double)N * H * W * Cout));
+    // (with windows: the live tiles when the caller knows them -- tiles_hint, profiling passes only --, else all)
+    const double tl = (wins && tiles_hint > 0) ? (double)tiles_hint : (double)a.T;
+    vpho::ProfScope prof(vpho::PROF_WINOGRAD, (hipStream_t)stream, 2.0 * 16.0 * tl * Cout * (double)Cin,
+                         4.0 * (4.0 * tl * Cin + 16.0 * Cout * Cin + 4.0 * tl * Cout));
     hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)(tbs * (Cout / W_CB))), dim3(256), lds, (hipStream_t)stream, a);
     return vpho::check_launch("conv_winograd_kernel");
 }

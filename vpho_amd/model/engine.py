@@ -118,12 +118,15 @@ class Engine:
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
-        # opt-in: 3x3 / stride-1 convolutions in Winograd F(2x2,3x3) form (VPHO_WINOGRAD=1; default: the direct implicit GEMM, the path the
-        # pinned parity batches were recorded on -- DESIGN 4c)
-        self.winograd = os.environ.get('VPHO_WINOGRAD', '0') == '1'
+        # 3x3 / stride-1 convolutions in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25 x fewer multiply-adds, smaller error
+        # against fp64 than the direct kernel).  VPHO_WINOGRAD=0: the direct implicit GEMM everywhere
+        self.winograd = os.environ.get('VPHO_WINOGRAD', '1') != '0'
         # opt-in split-bf16 convolution products (default: fp32 MFMA); see ops.conv_split
         self.conv_terms = {'f32': 0, 'bf16x6': 6, 'bf16x9': 9}[os.environ.get('VPHO_CONV_MFMA', 'f32')]
         self.serial_samplers = False            # True: object sampler after the hand sampler on one stream (exclusive kernel timings)
+        # True: last_info['agg'] also keeps the candidates every cascade level scored (4 copies of (bs, 2S, 48)); what the fp64 referee
+        # of the selection chain is given (tests / bench parity block)
+        self.keep_states = False
         self._feat_side = None
         from .graphs import GraphedCall
         self._features_graph = GraphedCall(self.features, dev)
@@ -200,7 +203,7 @@ class Engine:
             halo = windows[br][1] if (windows is not None and c is c2) else None
             q = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None)
             p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
-        return ops.conv2d_nhwc(p, *self.fpn[f'smooth3_{br}'], kh=3, kw=3, pad=1, rows=None if windows is None else windows[br][0])
+        return ops.conv3x3(p, *self.fpn[f'smooth3_{br}'], winograd=self.winograd, rows=None if windows is None else windows[br][0])
 
     def _hm_head(self, x, h):
         y = ops.conv3x3(x, *h['c0'], winograd=self.winograd)
@@ -330,7 +333,7 @@ class Engine:
         t.update({'d_' + k: data[k] for k in self._AGG_D})
         t.update(final58=final58, obj_pose=obj_pose, oid=self.agg.obj_ids(data['obj_name']))
         self._agg_k = (k_hand, k_obj)
-        return self._aggregate_graph(t, (k_hand, k_obj))
+        return self._aggregate_graph(t, (k_hand, k_obj, self.keep_states))
 
     def aggregate(self, f, data, final58, obj_pose, S, k_hand, k_obj, oid=None):
         """aggregation.py:1167-1353.  final58 (bs*S,58) f32, obj_pose (bs,S,9) f64."""
@@ -344,14 +347,22 @@ class Engine:
         oid = A.obj_ids(data['obj_name']) if oid is None else oid
         ctx = f['mano_ctx']
         dbg = dict(hand_topk=[], hand_val=[])
+        if self.keep_states:
+            dbg['cascade_state'], dbg['hand_score'] = [], []
         # 1. hand cascade
         pose = A.hand_candidates(final58, f['mano_pose'], bs, S)
         tp = None
         for level in range(4):
             observe = [j for l in range(level + 1, 5) for j in MANO_JOINT_LEVEL[l]]
+            if self.keep_states:
+                dbg['cascade_state'].append(pose.clone())
             _, joints = M.fk(pose.view(-1, 48), ctx, 2 * S, False)
             hv = A.hand_heat(joints.view(bs, 2 * S, 21, 3), root_flip, Kmat, bb_h, f['hand_heatmap'], observe)
-            val, idx, tp = A.hand_fuse_level(hv, pose, k_hand, level, want_topk_pose=(level == 3))
+            if self.keep_states:
+                val, idx, tp, sc = A.hand_fuse_level(hv, pose, k_hand, level, want_topk_pose=(level == 3), want_scores=True)
+                dbg['hand_score'].append(sc)
+            else:
+                val, idx, tp = A.hand_fuse_level(hv, pose, k_hand, level, want_topk_pose=(level == 3))
             dbg['hand_topk'].append(idx)
             dbg['hand_val'].append(val)
         fused_rows = pose.view(bs, 2 * S * 48)                                          # row b starts with candidate 0 = fused pose
@@ -381,7 +392,7 @@ class Engine:
         out58 = A.hand_phys_fuse(cand58, fidx)
         out_vert, out_joint = M.fk(out58, ctx, 1, True)
         dbg.update(transl_topk=ti, rot_topk=ri, phys_topk=pi, heat_topk=hi, phys_score=ps, transl_score=sc, rot_score=sc2, heat_score=hs, hand_phys_topk=fidx, hand_phys_score=fs, cand58=cand58, cand_vert=cverts, cand_force_point=fp2, cand_force_global=fg2,
-                   cascade_pose=fused_rows[:, :48], force_point=fpnt, force_global=fglob, obj_vert=obj_vert, pose6d_candidate=cand)
+                   cascade_pose=fused_rows[:, :48], force_point=fpnt, force_global=fglob, obj_vert=obj_vert, pose6d_candidate=cand, transl=transl)
         return dict(obj_agg_6d=obj_fused, hand_agg_mano=out58, hand_agg_vert=out_vert, hand_agg_joint=out_joint), dbg
 
     # ------------------------------------------------------------------------------------------------ whole path

@@ -178,27 +178,35 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     return ret
 
 
-def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True):
+def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None):
     """3x3 / stride 1 / pad 1 convolution + bias + LeakyReLU of the inference plan: the Winograd F(2x2,3x3) kernel where its shape
     conditions hold (even H and W, Cin % 8 == 0, Cout % 64 == 0), else the direct implicit GEMM.  The transformed weights live on the
-    weight tensor object and follow its version."""
+    weight tensor object and follow its version.  ``rows`` = a ``RoiWindows``: only the window pixels, as the compact (N*H*W, Cout)
+    matrix (see conv2d_nhwc)."""
     N, H, W, x_ld = x.shape
     cout, k9 = w.shape
     cin = k9 // 9
     if not winograd or H % 2 or W % 2 or cin % 8 or cout % 64 or x_ld != cin or getattr(_conv_split, 'terms', 0):
-        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope)
+        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, rows=rows)
     c = getattr(w, '_vpho_wino', None)
     if c is None or c[0] != w._version:
         from .model.pack import winograd_weights
         c = (w._version, winograd_weights(w))
         w._vpho_wino = c
-    return conv3x3_winograd(x, c[1], bias, out_slope)
+    return conv3x3_winograd(x, c[1], bias, out_slope, rows=rows)
 
 
-def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None):
+def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None, rows=None):
     """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (16, Cout, Cin)"""
     N, H, W, x_ld = x.shape
     _, cout, cin = u.shape
+    if rows is not None:
+        assert rows.shape == (N, H, W)
+        if out is None:
+            out = torch.empty((N * H * W, cout), device=x.device, dtype=torch.float32)
+        _call('vpho_conv3x3_winograd_rows_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope),
+              _i32(rows.wins), _i32(rows.tiles()), I(int(rows.tiles()[N].item()) if _prof_on else 0), _f32(out), I(out.shape[-1]))
+        return out
     if out is None:
         out = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
     _call('vpho_conv3x3_winograd_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope), _f32(out),
@@ -389,6 +397,14 @@ class RoiWindows:
     the linear pixel index of every window pixel, ``count`` (1,) their number.  See vpho_roi_windows_i32."""
     def __init__(self, wins, row_map, count, shape):
         self.wins, self.row_map, self.count, self.shape = wins, row_map, count, shape
+        self._tiles = None
+
+    def tiles(self):
+        """(N+1,) int32: first 2 x 2 Winograd tile of every image's window, [N] = their number (vpho_winograd_window_tiles_i32)"""
+        if self._tiles is None:
+            self._tiles = torch.empty((self.shape[0] + 1,), device=self.wins.device, dtype=torch.int32)
+            _call('vpho_winograd_window_tiles_i32', _i32(self.wins), I(self.shape[0]), _i32(self._tiles))
+        return self._tiles
 
     def to_map(self, rows):
         """Inspection helper (synchronises): the compact matrix scattered back to (N,H,W,C), zeros outside the windows, and the
@@ -580,13 +596,14 @@ class Aggregation:
               I(len(observe)), _f32(out))
         return out
 
-    def hand_fuse_level(self, hv, pose, k, level, want_topk_pose=False):
+    def hand_fuse_level(self, hv, pose, k, level, want_topk_pose=False, want_scores=False):
         bs, Cn, n_obs = hv.shape
         Fn = 1 if level == 0 else 5
         val, idx = _new((bs, Fn, k), hv), _new((bs, Fn, k), hv, torch.int32)
         tp = _new((bs, k, Fn, 3), hv) if want_topk_pose else None
-        _call('vpho_hand_fuse_level_f32', _f32(hv), I(n_obs), _f32(pose), I(bs), I(Cn), I(k), I(level), _f32(val), _i32(idx), _f32(tp))
-        return val, idx, tp
+        sc = _new((bs, Cn, Fn), hv) if want_scores else None
+        _call('vpho_hand_fuse_level_f32', _f32(hv), I(n_obs), _f32(pose), I(bs), I(Cn), I(k), I(level), _f32(val), _i32(idx), _f32(tp), _f32(sc))
+        return (val, idx, tp, sc) if want_scores else (val, idx, tp)
 
     def topk(self, scores, k, F_=1):
         """scores (rows, n) [F_=1] or (rows, n, F_) -> val, idx (rows, F_, k)"""
