@@ -51,6 +51,10 @@ def parse():
     p.add_argument('--conv_mfma', choices=('f32', 'bf16x6', 'bf16x9'), default='f32', help='the same switch for the convolutions of the feature path (opt-in)')
     p.add_argument('--winograd', action='store_true', help='(default since round 3; kept so old command lines still parse)')
     p.add_argument('--no_winograd', action='store_true', help='A/B aid: the direct implicit GEMM for the 3x3 / stride-1 convolutions too (VPHO_WINOGRAD=0)')
+    p.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                   help='weak (default): every rank its own batch of --bs images, like accelerate\'s prepared DataLoader (train_diff_hand_obj.py:121-124); '
+                        'strong: ONE global batch of --bs images per step, rank r takes images [r*bs/N, (r+1)*bs/N) (SURVEY 8e); the batch-coupled '
+                        'quirks Q3 / Q5 then see the LOCAL batch of bs/N images')
     p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
@@ -76,12 +80,8 @@ def main():
     dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if rehearse:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
+    from vpho_amd.launch import init_process_group
+    init_process_group(dev)                               # loud on failure: bounded timeout, expected vs observed world, first collective
 
     cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = \
         args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj, args.sample_T0
@@ -95,9 +95,16 @@ def main():
     model = model.to(dev).eval()
     torch.manual_seed(206 + rank * 100000000)            # base_trainer.py:39-50 (seed + rank*1e8)
     batches = []
+    strong = args.scaling == 'strong'
+    lo, hi = E.shard_range(args.bs, rank, world) if strong else (0, args.bs)
+    lbs = hi - lo                                         # images of THIS rank per step
+    if strong and (lbs <= 0 or args.bs % world):
+        raise SystemExit(f'--scaling strong needs --bs ({args.bs}) to be a multiple of the rank count ({world})')
     for i in range(2):                                    # two resident batches, alternated
-        b = synth_batch(args.bs, assets, seed=206 + i, rank=rank)
-        batches.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+        # strong scaling: every rank builds the SAME global batch and keeps its contiguous shard
+        b = synth_batch(args.bs, assets, seed=206 + i, rank=0 if strong else rank)
+        b = {k: v[lo:hi] for k, v in b.items()}
+        batches.append({k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in b.items()})
     # synthetic ground truth for the metric rows: MANO FK of a seeded small pose (through the HIP FK)
     from vpho_amd.model.engine import Engine
     if args.no_roi_window:
@@ -114,12 +121,12 @@ def main():
     roi_frac = []
     for b in batches:
         fh, fw = b['rgb'].shape[2] // 4, b['rgb'].shape[3] // 4
-        wh = ops.roi_windows(b['bbox_hand'].float().contiguous(), b['bbox_hand_rect'].float().contiguous(), args.bs, fh, fw, 0.25)
-        wo = ops.roi_windows(b['bbox_obj_rect'].float().contiguous(), None, args.bs, fh, fw, 0.25)
-        roi_frac.append((int(wh.count) / (args.bs * fh * fw), int(wo.count) / (args.bs * fh * fw)))
+        wh = ops.roi_windows(b['bbox_hand'].float().contiguous(), b['bbox_hand_rect'].float().contiguous(), lbs, fh, fw, 0.25)
+        wo = ops.roi_windows(b['bbox_obj_rect'].float().contiguous(), None, lbs, fh, fw, 0.25)
+        roi_frac.append((int(wh.count) / (lbs * fh * fw), int(wo.count) / (lbs * fh * fw)))
     g = torch.Generator().manual_seed(1234 + rank)
-    gt_pose = (torch.randn(args.bs, 48, generator=g) * 0.2).to(dev)
-    gt_ctx = eng.mano.shape((torch.randn(args.bs, 10, generator=g) * 0.5).to(dev))
+    gt_pose = (torch.randn(lbs, 48, generator=g) * 0.2).to(dev)
+    gt_ctx = eng.mano.shape((torch.randn(lbs, 10, generator=g) * 0.5).to(dev))
     gt_vert, gt_joint = eng.mano.fk(gt_pose, gt_ctx, 1, True)
     gt_vert = gt_vert + batches[0]['root_joint'][:, None]
     gt_joint = gt_joint + batches[0]['root_joint'][:, None]
@@ -155,7 +162,7 @@ def main():
                 return None
             futs = []
             for i in range(k):
-                first = (rank * k + i) * args.bs
+                first = (rank * k + i) * lbs
                 futs.append(pipe.submit(batches[i % 2], lambda out, batch, engine, first=first: (
                     E.metric_rows(out, batch, gt_joint, gt_vert, first, assets),
                     (engine.last_info['hand_ode']['nfev'], engine.last_info['obj_ode']['nfev']))))
@@ -169,7 +176,7 @@ def main():
                 ev.record()
                 step_events.append(ev)
                 out = model(batches[i % 2], mode='predict')
-                rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * args.bs, assets))
+                rows.append(E.metric_rows(out, batches[i % 2], gt_joint, gt_vert, (rank * k + i) * lbs, assets))
                 nfev.append((eng.last_info['hand_ode']['nfev'], eng.last_info['obj_ode']['nfev']))
         return E.gather_rows(torch.cat(rows, 0)), nfev     # the ONE collective of the evaluation
 
@@ -225,11 +232,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    assert all_rows.shape[0] == world * args.steps * args.bs
+    assert all_rows.shape[0] == world * args.steps * lbs
 
     result = None
     if rank == 0:
-        images = world * args.steps * args.bs
+        images = world * args.steps * lbs                  # strong: world * lbs = --bs per step
         host_cpu = {'cpu_seconds_per_step': host_cpu_s / args.steps, 'busy_threads_equivalent': host_cpu_s / dt}
         conv_tf = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
         head_tf = head['flops'] / (head['total_ms'] * 1e-3) / 1e12 if head['total_ms'] > 0 else 0.0
@@ -240,13 +247,15 @@ def main():
         result = {
             'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32' if (score_mfma, conv_mfma) == ('f32', 'f32') else f'f32 storage and accumulation; products as split-bf16 (score head {score_mfma}, convolutions {conv_mfma}; opt-in, NOT the default)',
             'data': 'synthetic',
             'config': {'workload': 'vpho_net.forward(mode=predict), ' + ('README eval config (BASELINE.json configs[1])' if
                                     (args.bs, args.sample_num, args.sampling_steps, args.topk_hand, args.topk_obj) == (64, 100, 50, 30, 10)
                                     else 'non-default config (see the keys below)'),
-                       'per_gpu_batch': args.bs, 'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
+                       'per_gpu_batch': lbs, 'global_batch_per_step': world * lbs,
+                       'batch_coupling': 'CrossModule attention over the batch axis (Q3) and the one RK45 controller per solve (Q5) act on each rank\'s LOCAL batch, as per DDP rank in the reference',
+                       'sample_num': args.sample_num, 'sampling_steps': args.sampling_steps,
                        'topk_hand': args.topk_hand, 'topk_obj': args.topk_obj, 'sample_T0': args.sample_T0, 'crop': '256x256',
                        'pipeline_depth': args.pipeline, 'score_mfma': score_mfma, 'conv_mfma': conv_mfma, 'winograd_3x3': bool(eng.winograd),
                        'fpn_roi_window': {'enabled': bool(eng.roi_window), 'what': 'the last convolution of each FPN branch is computed only on the pixels its '

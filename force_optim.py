@@ -36,9 +36,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo' if rehearse else 'nccl', **({} if rehearse else {'device_id': dev}))
+    from vpho_amd.launch import init_process_group
+    init_process_group(dev)                               # loud on failure: bounded timeout, expected vs observed world, first collective
     assets = load_assets('asset')
     n_batches = (args.pairs + args.batch_size - 1) // args.batch_size
     lo, hi = shard_range(n_batches, rank, world)

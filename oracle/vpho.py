@@ -127,4 +127,4 @@ def predict(sd, assets, anchor_skeleton, data, *, sample_num, sample_T0, samplin
     out['agg_hand_mano'] = agg['hand_agg_mano']
     out['agg_hand_vert'] = agg['hand_agg_vert']
     out['agg_hand_joint'] = agg['hand_agg_joint']
-    return out, dict(features=f, hand_ode=info_h, obj_ode=info_o, agg=agg['dbg'])
+    return out, dict(features=f, hand_ode=info_h, obj_ode=info_o, agg=agg['dbg'], hand_x6d=x_h)

@@ -40,3 +40,23 @@ def assert_within_reference_noise(rep, tag=''):
         # projection; ~1e-3 for the object physics score, whose torque term sums 32 cross products that nearly cancel), not a formula difference
         assert r['eps32_rel'] < 1e-2, (st, r['eps32_rel'])
     return s
+
+
+def assert_hand_hypotheses_agree(out, info, ref, ref_info, betas, tol_x6d=1e-4, tol_post=2e-4):
+    """The hand hypotheses of the two sides, stated where each statement is well conditioned:
+    * the sampler's raw output (16 x rot6d per hypothesis) agrees to ``tol_x6d``;
+    * the HIP post-processing (Gram-Schmidt -> matrix -> axis-angle, VPHO.py:306-331) of the HIP path's OWN samples agrees with the
+      oracle's conversion of those same samples to ``tol_post``.
+    The axis-angle hypotheses of the two sides are NOT compared entry by entry: a rot6d whose two columns are nearly parallel turns a
+    1e-5 difference of the sample into 1e-3 of the rotation (Gram-Schmidt divides by the orthogonal remainder), on either side alike;
+    their largest difference is returned for the log."""
+    from oracle.vpho import postprocess_diffusion_hand
+    c = lambda t: t.detach().cpu()
+    x_hip, x_ref = c(info['hand_x6d']).float(), c(ref_info['hand_x6d']).float()
+    d6 = float((x_hip - x_ref).abs().max())
+    assert d6 < tol_x6d, ('sampler output (rot6d)', d6)
+    bs, S = out['diff_final_hand_mano'].shape[:2]
+    post = postprocess_diffusion_hand(x_hip.reshape(bs, S, 96), c(betas))
+    dp = float((c(out['diff_final_hand_mano']) - post).abs().max())
+    assert dp < tol_post, ('rot6d -> axis-angle of identical samples', dp)
+    return d6, dp, float((c(out['diff_final_hand_mano']).double() - ref['diff_final_hand_mano'].double()).abs().max())

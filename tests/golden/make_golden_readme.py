@@ -10,7 +10,11 @@ model's: with purely random weights the T0=0.65 object hypotheses stay metres ou
 and torch.topk's unspecified order among equal values decides the reference's own result).
 
 Run in the build container only (needs /root/reference); same stubs / assets as make_golden.py.  The in-process trajectories
-are not stored (size)."""
+are not stored (size).
+
+    python make_golden_readme.py             -> golden_predict_readme.npz    (8 images; also the CPU pin of the oracle)
+    python make_golden_readme.py --bs 64     -> golden_predict_readme64.npz  (the benchmark's batch: the batch-coupled quirks Q3 / Q5 see
+                                                64 images; hypotheses stored for every 4th sample, heat-maps every 8th pixel)"""
 import os
 import sys
 import tempfile
@@ -26,6 +30,15 @@ CFG = dict(bs=8, sample_num=100, sampling_steps=50, topk_hand=30, topk_obj=10, s
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--bs', type=int, default=CFG['bs'])
+    args = ap.parse_args()
+    big = args.bs != CFG['bs']
+    CFG['bs'] = args.bs
+    if big:
+        CFG.update(data_seed=4264, draw_seed=6)
+    hyp_stride, hm_stride = (4, 8) if big else (1, 4)
     from vpho_amd.assets import synthetic_assets
     from vpho_amd.synth import bench_state_dict, synth_batch
     assets = synthetic_assets(0)
@@ -89,11 +102,13 @@ def main():
     assert len(topk_calls) == 4 + 2 + 2 + 5, len(topk_calls)
     P = dict(cfg=np.array([c['bs'], c['sample_num'], c['sampling_steps'], c['topk_hand'], c['topk_obj']]), sample_T0=np.array(c['sample_T0']),
              data_seed=np.array(c['data_seed']), noise_hand_crc=np.array(float(nh.double().sum())), noise_obj_crc=np.array(float(no.double().sum())),
-             draw_seed=np.array(c['draw_seed']))
-    for k in ('reg_hand_joint', 'force_local', 'diff_final_hand_mano', 'diff_final_obj_6d', 'agg_obj_6d', 'agg_hand_mano', 'agg_hand_joint', 'agg_hand_vert'):
+             draw_seed=np.array(c['draw_seed']), hyp_stride=np.array(hyp_stride), hm_stride=np.array(hm_stride))
+    for k in ('reg_hand_joint', 'force_local', 'agg_obj_6d', 'agg_hand_mano', 'agg_hand_joint', 'agg_hand_vert'):
         P[k] = out[k].numpy()
+    for k in ('diff_final_hand_mano', 'diff_final_obj_6d'):
+        P[k] = out[k].numpy()[:, ::hyp_stride]
     for k in ('hand_heatmap', 'obj_heatmap'):
-        P[k] = out[k].numpy()[:, :, ::4, ::4]
+        P[k] = out[k].numpy()[:, :, ::hm_stride, ::hm_stride]
     for lvl in range(4):
         sc, val, idx = topk_calls[lvl]
         P[f'hand_score_l{lvl}'], P[f'hand_val_l{lvl}'], P[f'hand_topk_l{lvl}'] = sc.numpy(), val.numpy(), idx.numpy()
@@ -104,7 +119,7 @@ def main():
     P['hand_phys_topk'] = torch.stack([topk_calls[8 + f][2] for f in range(5)], 1).numpy()       # (bs,5,5)
     P['hand_phys_cand'] = rec['phys_cand'].numpy()                                               # (bs,31,58)
     P['tcalls_hand'], P['tcalls_obj'] = np.array(tcalls['hand']), np.array(tcalls['obj'])
-    path = os.path.join(HERE, 'golden_predict_readme.npz')
+    path = os.path.join(HERE, 'golden_predict_readme64.npz' if big else 'golden_predict_readme.npz')
     np.savez_compressed(path, **P)
     print({k: v.shape for k, v in P.items()})
     print('nfev hand/obj', len(tcalls['hand']), len(tcalls['obj']), '|', os.path.getsize(path) // 1024, 'KiB')

@@ -207,3 +207,61 @@ def test_bucketed_gradient_exchange_world2_gloo():
                 want -= 0.1 * 0.5 * (_grad(k, 0, step) + _grad(k, 1, step))
         assert torch.allclose(p0[k], want, atol=1e-6), k
     assert float(p0[_NEVER].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ vpho_net.forward('train') under DDP
+class _Toy(torch.nn.Module):
+    """stand-in with the structure of vpho_net._forward_train: the step computes loss and gradients itself and returns the loss
+    through vpho_amd.model.VPHO._DepositGrads"""
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.zeros(3))
+        self.b = torch.nn.Parameter(torch.zeros(2, 2))
+        self.unreached = torch.nn.Parameter(torch.zeros(4))          # no loss of the batch reaches it: explicit zero gradient
+
+    def forward(self, scale):
+        from vpho_amd.model.VPHO import _DepositGrads
+        grads = {'a': torch.full((3,), float(scale)), 'b': torch.full((4,), 2.0 * float(scale))}          # flat, like the step's buffers
+        named = [(k, p) for k, p in self.named_parameters() if p.requires_grad]
+        return _DepositGrads.apply(torch.tensor(10.0 * float(scale)), [grads.get(k) for k, _ in named], *[p for _, p in named])
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    m = DDP(_Toy())
+    out = []
+    for it in range(2):                                              # two iterations: DDP's "finished reduction" bookkeeping holds
+        m.zero_grad()
+        loss = m(rank + 1.0)
+        (loss * 3.0).backward()                                      # the incoming gradient scales the deposited ones
+        out.append({k: p.grad.tolist() for k, p in m.module.named_parameters()})
+    with m.no_sync():                                                # gradient accumulation: local gradients, added to .grad
+        m(rank + 1.0).backward()
+    out.append({k: p.grad.tolist() for k, p in m.module.named_parameters()})
+    q.put((rank, float(loss.detach()), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_forward_loss_node_takes_part_in_ddp_gradient_averaging():
+    """the loss returned by forward(mode='train') must let DistributedDataParallel average the gradients --
+    parameters are real inputs of the autograd node, so the per-parameter hooks fire; rank gradients 1 and 2 average to 1.5"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (l, o) for r, l, o in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        loss, outs = got[r]
+        assert loss == 10.0 * (r + 1)
+        for it in range(2):
+            assert outs[it]['a'] == [4.5] * 3 and outs[it]['b'] == [[9.0, 9.0], [9.0, 9.0]] and outs[it]['unreached'] == [0.0] * 4
+        # no_sync: the averaged gradient of the second iteration + this rank's own
+        assert outs[2]['a'] == [4.5 + (r + 1.0)] * 3

@@ -101,3 +101,24 @@ def test_full_batch_rk45_follows_the_reference_step_by_step(sd_contrast, name, D
     assert st['nan_count'] == 0
     ex, exs = OF.check(name, xs.cpu(), x.cpu(), st['steps'], st['nfev'])
     print(name, 'max abs x', ex, 'xs', exs)
+
+
+@pytest.mark.parametrize('name,D', [('obj', 9), ('hand', 96)])
+def test_nan_guard_matches_reference(sd_contrast, name, D):
+    """The guard of score_based_model.py:65-72 against the reference's own sampler run on a score network that returns NaN in one head and
+    +-inf in another at every evaluation (make_golden_nan_guard.py): NaN and +-inf are zeroed inside the solve (same RHS-evaluation
+    count as scipy, the planted dimensions keep their start value, the NaNs are counted), and the final denoise evaluation is NOT
+    guarded, so the returned sample is NaN / -inf / +inf exactly where the reference's is."""
+    from oracle import nets as N
+    from tests import _nan_fixture as NF
+    from vpho_amd import ops
+    net = ops.ScoreNet(NF.planted_state_dict(sd_contrast, name), f'denoiser_{name}', 'cuda')
+    enc, init = NF.inputs(name, D, N.ve_prior_sigma(NF.T0))
+    xs, x, st = net.sample(enc.cuda(), init.cuda(), NF.S, NF.T0, NF.STEPS, xs_f64=True)
+    torch.cuda.synchronize()
+    assert st['nan_count'] == 3 * NF.BS * NF.S * (st['nfev'] - 1)            # three NaN entries per row and guarded evaluation
+    NF.check(name, xs, x, init, st['nfev'], tol=1e-4)
+    # the bare score (denoiser.py:68-82 without the sampler's wrapper) passes NaN / inf through
+    sc = net.score(enc.cuda(), init.cuda(), 0.3, NF.S).cpu()
+    nh, ih = (int(v) for v in NF.F[f'{name}_plant'])
+    assert bool(torch.isnan(sc[:, 3 * nh:3 * nh + 3]).all()) and bool(torch.isinf(sc[:, 3 * ih:3 * ih + 3]).all())

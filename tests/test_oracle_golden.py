@@ -242,6 +242,18 @@ def test_oracle_rk45_at_the_full_batch_matches_reference(sd_contrast):
     ex, exs = OF.check('obj', xs, x, info['steps'], info['nfev'], x_tol=1e-4)
 
 
+@pytest.mark.parametrize('name,D', [('obj', 9), ('hand', 96)])
+def test_oracle_nan_guard_matches_reference(sd_contrast, name, D, capsys):
+    """score_based_model.py:65-72 on scores with NaN and +-inf in them (make_golden_nan_guard.py: the reference's own sampler): guarded
+    inside the solve (same evaluation count, planted dimensions frozen), unguarded in the final denoise evaluation (NaN / +-inf in x)"""
+    from tests import _nan_fixture as NF
+    sdp = NF.planted_state_dict(sd_contrast, name)
+    enc, init = NF.inputs(name, D, N.ve_prior_sigma(NF.T0))
+    feat = enc[:, None].repeat(1, NF.S, 1).reshape(-1, 1024)
+    xs, x, info = N.ode_sample(sdp, f'denoiser_{name}', feat, init, NF.T0, NF.STEPS)
+    NF.check(name, xs, x, init, info['nfev'], tol=1e-5)
+
+
 def test_oracle_force_optimisation_loop_matches_reference(assets):
     """oracle.force_optim.optimize vs the reference's OWN ForceOptimizer.optimize_batch (tests/golden/make_golden_force_optim.py:
     the real loop, 3000 AdamW iterations with torch.optim.AdamW, HeadForce and VERT2ANCHOR): parameters after 40 / 400 / 1000 /

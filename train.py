@@ -45,12 +45,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if rehearse:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
+    from vpho_amd.launch import init_process_group
+    init_process_group(dev)                               # loud on failure: bounded timeout, expected vs observed world, first collective
     # base_trainer.py:39-50: seed + rank * 1e8 -- every rank draws its own DSM times / noise from the device generator
     torch.manual_seed(args.seed + rank * 100000000)
     torch.cuda.manual_seed(args.seed + rank * 100000000)

@@ -39,11 +39,12 @@ def main():
     world, rank, local = world_from_env(args.gpus)
     torch.manual_seed(206 + rank * 100000000)             # base_trainer.py:39-50
     torch.cuda.manual_seed(206 + rank * 100000000)
+    if os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1':      # every rank on cuda:0 over gloo (1-GPU box; timings meaningless)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+    from vpho_amd.launch import init_process_group
+    init_process_group(dev)                               # loud on failure: bounded timeout, expected vs observed world, first collective
     sd = synth_state_dict(vpho_net(synthetic_assets(0)), seed=1)
     hand, obj = ScoreTrainer(sd, 'denoiser_hand', dev), ScoreTrainer(sd, 'denoiser_obj', dev)
     g = torch.Generator().manual_seed(100 + rank)

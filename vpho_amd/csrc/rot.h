@@ -105,15 +105,17 @@ __device__ inline void mano_rodrigues(const float* aa, float* R) {
     R[6] = 2 * xz - 2 * wy;      R[7] = 2 * wx + 2 * yz;      R[8] = w2 - x2 - y2 + z2;
 }
 
-// Largest-eigenvalue eigenvector of a symmetric 4x4 (cyclic Jacobi in the matrix' own precision, 12 sweeps) --
+// Largest-eigenvalue eigenvector of a symmetric 4x4 (cyclic Jacobi in the matrix' own precision; sweeps until the off-diagonal mass is
+// below the rounding of the diagonal -- 3-5 sweeps, quadratic convergence -- at most 12) --
 // transform_fn.average_quaternion's torch.linalg.eigh(A)[1][..., -1]; sign fixed by the caller.
 template <typename T>
 __device__ inline void sym4_top_eigenvector(T A[4][4], T* v) {
     T V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     for (int sweep = 0; sweep < 12; ++sweep) {
-        T off = 0;
-        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-        if (off < (T)1e-40) break;
+        T off = 0, dg = 0;
+        for (int p = 0; p < 4; ++p) { dg += A[p][p] * A[p][p]; for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q]; }
+        // converged: a rotation by an angle below eps / 4 no longer changes a digit of A or V (c = 1, s * a < ulp(a))
+        if (off < (T)1e-40 || off <= dg * (sizeof(T) == 4 ? (T)2e-16 : (T)1e-33)) break;
         for (int p = 0; p < 3; ++p) {
             for (int q = p + 1; q < 4; ++q) {
                 // exactly (or denormally) zero off-diagonal: nothing to rotate.  Matters for rank-deficient moment matrices

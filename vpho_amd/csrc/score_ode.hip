@@ -428,8 +428,14 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
 #pragma unroll
                 for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + tid) * 4 + dd];
                 float sv = (acc2 + a.b2[n * 3 + dd]) / inv_std;
-                if (sv != sv) { sv = 0.f; ++nans; }
-                if (a.rhs_mode) sv = 0.f - coef * sv;
+                if (a.rhs_mode) {
+                    // score_eval_wrapper (score_based_model.py:65-72): nan_to_num(nan=0, posinf=0, neginf=0) on the RHS evaluations of the
+                    // solve -- there, when ANY entry of the evaluation is NaN; here entry by entry: the same result whenever a NaN is
+                    // present, and +-inf without any NaN has no defined outcome in the reference (scipy's controller never recovers).
+                    // The bare score (vpho_score_eval, the final denoise evaluation :100) is NOT guarded, as in the reference.
+                    if (sv != sv) { sv = 0.f; ++nans; } else if (fabsf(sv) == INFINITY) sv = 0.f;
+                    sv = 0.f - coef * sv;
+                }
                 outp[(long long)orow * a.D + n * 3 + dd] = sv;
             }
             if (nans) atomicAdd(a.nan_count, nans);
@@ -621,8 +627,14 @@ __device__ __forceinline__ void head_tile_split(const HeadArgs& a, float* smem, 
 #pragma unroll
                 for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + tid) * 4 + dd];
                 float sv = (acc2 + a.b2[n * 3 + dd]) / inv_std;
-                if (sv != sv) { sv = 0.f; ++nans; }
-                if (a.rhs_mode) sv = 0.f - coef * sv;
+                if (a.rhs_mode) {
+                    // score_eval_wrapper (score_based_model.py:65-72): nan_to_num(nan=0, posinf=0, neginf=0) on the RHS evaluations of the
+                    // solve -- there, when ANY entry of the evaluation is NaN; here entry by entry: the same result whenever a NaN is
+                    // present, and +-inf without any NaN has no defined outcome in the reference (scipy's controller never recovers).
+                    // The bare score (vpho_score_eval, the final denoise evaluation :100) is NOT guarded, as in the reference.
+                    if (sv != sv) { sv = 0.f; ++nans; } else if (fabsf(sv) == INFINITY) sv = 0.f;
+                    sv = 0.f - coef * sv;
+                }
                 outp[(long long)orow * a.D + n * 3 + dd] = sv;
             }
             if (nans) atomicAdd(a.nan_count, nans);

@@ -151,12 +151,19 @@ def gather_rows(rows):
         return rows
     world = dist.get_world_size()
     out = torch.empty((world * rows.shape[0], rows.shape[1]), device=rows.device, dtype=rows.dtype)
-    if dist.get_backend() == 'gloo' and rows.is_cuda:       # CPU rehearsal backend: stage through host memory
-        host = torch.empty(out.shape, dtype=rows.dtype)
-        dist.all_gather_into_tensor(host, rows.cpu().contiguous())
-        out.copy_(host)
-    else:
-        dist.all_gather_into_tensor(out, rows.contiguous())
+    try:
+        if dist.get_backend() == 'gloo' and rows.is_cuda:       # CPU rehearsal backend: stage through host memory
+            host = torch.empty(out.shape, dtype=rows.dtype)
+            dist.all_gather_into_tensor(host, rows.cpu().contiguous())
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, rows.contiguous())
+            if rows.is_cuda:
+                torch.cuda.current_stream(rows.device).synchronize()      # an RCCL failure surfaces HERE, with the context below
+    except Exception as e:
+        raise RuntimeError(f'gather_rows: the all-gather of the metric rows failed on rank {dist.get_rank()} of {world} (backend '
+                           f'{dist.get_backend()}, {tuple(rows.shape)} rows on {rows.device}; every rank must contribute the same '
+                           f'number of rows): {type(e).__name__}: {e}') from e
     return out
 
 

@@ -12,6 +12,7 @@ Host threads: every rank's launch threads share one host.  Unless the caller alr
 threads + OpenMP workers of the CPU prior draw) do not oversubscribe the node (8 x 4.3 busy threads were measured at N=1).
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -52,8 +53,69 @@ def maybe_spawn(gpus, script=None, argv=None):
     script = script or os.path.abspath(sys.argv[0])
     argv = sys.argv[1:] if argv is None else argv
     cmd = launch_command(script, gpus, argv)
-    r = subprocess.run(cmd, env=child_env(gpus))
-    sys.exit(r.returncode)
+    # the ranks run in their own session (process group): a SIGTERM / SIGINT that reaches only this parent (a scheduler or watchdog
+    # killing one PID) is forwarded to the whole group, so no rank is left behind holding a GPU; still a CHILD, never an exec
+    child = subprocess.Popen(cmd, env=child_env(gpus), start_new_session=True)
+
+    def forward(signum, frame):
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        rc = child.wait()
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        if child.poll() is None:                                   # parent is leaving for another reason: take the ranks along
+            forward(signal.SIGTERM, None)
+            try:
+                child.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                forward(signal.SIGKILL, None)
+    if rc != 0:
+        print(f'[vpho_amd.launch] the {gpus}-rank job ended with code {rc}: {" ".join(cmd)}', file=sys.stderr)
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+def init_process_group(dev=None, timeout_s=None):
+    """torch.distributed rendezvous of a rank process, loud on failure: backend 'nccl' (= RCCL over xGMI on ROCm) bound to ``dev``,
+    or gloo for the one-GPU rehearsal (VPHO_REHEARSE_ONE_GPU=1: every rank on cuda:0, timings meaningless).  A bounded timeout
+    (VPHO_DIST_TIMEOUT_S, default 180 s) instead of torch's 10-30 minutes, the world that was EXPECTED next to the one observed, and a
+    first collective right away so that a broken fabric shows here and not in the middle of a run."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world <= 1:
+        return 'none'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
+    backend = 'gloo' if (rehearse or dev is None) else 'nccl'
+    timeout = datetime.timedelta(seconds=float(timeout_s or os.environ.get('VPHO_DIST_TIMEOUT_S', '180')))
+    where = f'rank {rank}/{world}, backend {backend}, device {dev}, MASTER {os.environ.get("MASTER_ADDR")}:{os.environ.get("MASTER_PORT")}'
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, timeout=timeout)
+        else:
+            dist.init_process_group('gloo', timeout=timeout)
+        probe = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(probe)
+        if backend == 'nccl':
+            torch.cuda.synchronize(dev)
+        seen = int(probe.item())
+    except Exception as e:
+        raise SystemExit(f'[vpho_amd] process-group initialisation FAILED ({where}): {type(e).__name__}: {e}')
+    if seen != world or dist.get_world_size() != world:
+        raise SystemExit(f'[vpho_amd] process group is incomplete ({where}): a first all-reduce saw {seen} ranks, '
+                         f'get_world_size() = {dist.get_world_size()}, expected {world}')
+    if rank == 0:
+        print(f'[vpho_amd] process group up: {world} ranks, backend {dist.get_backend()}' + (' (one-GPU rehearsal)' if rehearse else ''),
+              file=sys.stderr, flush=True)
+    return backend
 
 
 def world_from_env(gpus):

@@ -80,14 +80,15 @@ class vpho_net(nn.Module):
             losses, grads, pd_dt = ts.loss_and_grads(data, gt_hand, data['gt_obj'].float(), draws, want_outputs=True)
             # running statistics live in the step's own buffers: mirror them into the module (nn.BatchNorm2d updates them in forward)
             own = dict(self.named_buffers())
-            for k, v in ts.state_dict().items():
-                if k.endswith(('running_mean', 'running_var')) and k in own:
+            for k, v in ts._running_stats().items():                  # the live tensors: no clone of the 569 masters per forward
+                if k in own:
                     own[k].copy_(v)
         object.__setattr__(self, '_train_sig', _signature(self))
-        params = dict(self.named_parameters())
-        names = [k for k in grads if k in params]
-        total = _DepositGrads.apply(torch.zeros((), device=dev, requires_grad=True), losses['total_loss'].detach().float(),
-                                    [params[k] for k in names], [grads[k] for k in names])
+        # every trainable parameter is a real input of the loss node, so autograd itself accumulates into .grad: DistributedDataParallel's
+        # per-parameter hooks fire (bucketed all-reduce), no_sync / gradient accumulation work, find_unused_parameters is not needed --
+        # a parameter no loss of this batch reaches gets an explicit zero, as it does under the reference's autograd
+        named = [(k, p) for k, p in self.named_parameters() if p.requires_grad]
+        total = _DepositGrads.apply(losses['total_loss'].detach().float(), [grads.get(k) for k, _ in named], *[p for _, p in named])
         loss_dt = {k: v.detach().float() for k, v in losses.items()}
         loss_dt['total_loss'] = total
         return loss_dt, pd_dt
@@ -115,16 +116,19 @@ def ops_error(msg):
 
 
 class _DepositGrads(torch.autograd.Function):
-    """total_loss with a backward that writes the step's analytic gradients into ``.grad`` of the module's parameters"""
+    """total_loss as a function of the module's parameters whose backward hands autograd the step's analytic gradients (scaled by the
+    incoming gradient).  The parameters are genuine inputs of the node: accumulation into ``.grad``, DistributedDataParallel's
+    gradient hooks, ``no_sync`` and ``retain_grad`` behave as for any other autograd function."""
 
     @staticmethod
-    def forward(ctx, anchor, value, params, grads):
-        ctx.params, ctx.grads = params, grads
+    def forward(ctx, value, grads, *params):
+        ctx.grads = grads
+        ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
         return value.clone()
 
     @staticmethod
     def backward(ctx, g):
-        for p, gr in zip(ctx.params, ctx.grads):
-            gr = gr.reshape(p.shape).to(p.dtype) * g
-            p.grad = gr.clone() if p.grad is None else p.grad + gr
-        return None, None, None, None
+        out = []
+        for gr, (shape, dtype, device) in zip(ctx.grads, ctx.meta):
+            out.append(torch.zeros(shape, dtype=dtype, device=device) if gr is None else gr.reshape(shape).to(dtype) * g)
+        return (None, None, *out)

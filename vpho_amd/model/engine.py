@@ -464,5 +464,5 @@ class Engine:
             out['agg_hand_mano'] = keep(agg['hand_agg_mano'])
             out['agg_hand_vert'] = keep(agg['hand_agg_vert'])
             out['agg_hand_joint'] = keep(agg['hand_agg_joint'])
-            self.last_info = dict(features=f, hand_ode=st_h, obj_ode=st_o, agg=dbg)
+            self.last_info = dict(features=f, hand_ode=st_h, obj_ode=st_o, agg=dbg, hand_x6d=x_h)      # x_h: the sampler's raw rot6d hypotheses
         return out

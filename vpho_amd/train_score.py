@@ -26,7 +26,12 @@ def allreduce_mean_scale(flat_grad):
     """DDP gradient averaging: SUM all-reduce of the flat buffer (RCCL under backend 'nccl'), the 1/world factor is returned
     and folded into the optimiser kernel.  No-op (scale 1) without a process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == 'gloo' and flat_grad.is_cuda:      # one-GPU rehearsal backend: through host memory
+            host = flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(host)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
 

@@ -295,7 +295,13 @@ class DiffusionTrainStep:
         losses, grads = self.loss_and_grads(data, gt_hand, gt_obj, draws, sink=self.buckets)
         unknown = set(grads) - set(self.names)
         assert not unknown, sorted(unknown)[:5]
-        live = [k for k in self.names if k in grads]             # tensors no loss of this batch reached keep their value (grad None)
+        # single process: tensors no loss of this batch reached keep their value (grad None, like torch.optim skips them).  Data
+        # parallel: WHICH tensors a batch reaches is decided per rank (e.g. the physics keys of a batch), but the bucket exchange
+        # delivers the other ranks' gradients for them all the same, and under DDP every parameter has a (possibly zero) gradient on
+        # every rank -- so every tensor is stepped on every rank and the replicas cannot drift apart
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        live = list(self.names) if multi else [k for k in self.names if k in grads]
         scale = self.buckets.finish()                            # waits for the bucket exchanges still in flight
         clip = cfg.gradient_clip if gradient_clip is None else gradient_clip
         if clip > 0:                                       # accel.clip_grad_norm_ (train_diff_hand_obj.py:182-183): global L2 norm of the averaged gradients

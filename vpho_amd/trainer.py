@@ -63,8 +63,8 @@ class Trainer:
         self.device = torch.device('cuda', self.local_rank)
         torch.cuda.set_device(self.device)
         if self.world > 1 and not dist.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl', device_id=self.device)
+            from .launch import init_process_group
+            init_process_group(self.device)                # loud on failure: bounded timeout, expected vs observed world
         self.setup_seed()
         self.assets = load_assets(cfg.asset_root)
         self.model = self.get_model()
