@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh): 1 no patch loads, 2 no U fill, 4 no transform /
+#endif                                         // V stores, 8 no stage barrier, 16 no fragment reads -- wrong results, never in the product build
 constexpr int WK = 8;                          // input channels per stage
 constexpr int W_TB = 64, W_CB = 64;            // tiles / output channels per workgroup
 constexpr int W_STAGE = 2 * 16 * 64 * WK;      // floats per stage: V | U
@@ -89,20 +92,27 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         py0 = 2 * ty - 1; px0 = 2 * tx - 1;
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 patch[16];
-    auto load_patch = [&](int kc) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // patch loads through a buffer resource: the 16 byte offsets are loop constants, a pixel outside the image (or of a dead tile) carries
+    // an out-of-range offset and the hardware returns zeros -- no branch per pixel, the channel advance rides in the scalar offset
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0xFFFFFFF0u, 0x00020000);
+    int poff[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
-            f32x2 v = {0.f, 0.f};
-            if (tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const f32x2*>(a.x + ((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + kc * WK + 2 * cp);
-            patch[p] = v;
+    for (int p = 0; p < 16; ++p) {
+        const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
+        const bool in = tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        poff[p] = in ? (int)((((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + 2 * cp) * 4) : -1;
+    }
+    f32x2 patch[16], r[16];
+    auto load_patch = [&](int kc, int p0 = 0, int p1 = 16) {
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            if (WINO_ABLATE & 1) { patch[p] = f32x2{(float)p, 1.f}; continue; }
+            patch[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, poff[p], kc * WK * 4, 0));
         }
     };
-    auto store_v = [&](int buf) {
-        // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
-        f32x2 r[16];
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first (row_transform), then columns of one frequency row fy
+    auto row_transform = [&]() {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             r[0 * 4 + c] = patch[0 * 4 + c] - patch[2 * 4 + c];
@@ -110,21 +120,21 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             r[2 * 4 + c] = patch[2 * 4 + c] - patch[1 * 4 + c];
             r[3 * 4 + c] = patch[1 * 4 + c] - patch[3 * 4 + c];
         }
+    };
+    const int sw = (tl >> 3) & 1;
+    auto store_v_row = [&](int buf, int fy) {
+        if (WINO_ABLATE & 4) return;
         float* V = smem + buf * W_STAGE;
-        const int sw = (tl >> 3) & 1;
+        const f32x2 v0 = r[fy * 4 + 0] - r[fy * 4 + 2];
+        const f32x2 v1 = r[fy * 4 + 1] + r[fy * 4 + 2];
+        const f32x2 v2 = r[fy * 4 + 2] - r[fy * 4 + 1];
+        const f32x2 v3 = r[fy * 4 + 1] - r[fy * 4 + 3];
+        const f32x2 vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-        for (int fy = 0; fy < 4; ++fy) {
-            const f32x2 v0 = r[fy * 4 + 0] - r[fy * 4 + 2];
-            const f32x2 v1 = r[fy * 4 + 1] + r[fy * 4 + 2];
-            const f32x2 v2 = r[fy * 4 + 2] - r[fy * 4 + 1];
-            const f32x2 v3 = r[fy * 4 + 1] - r[fy * 4 + 3];
-            const f32x2 vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-            for (int fx = 0; fx < 4; ++fx) {
-                const int f = fy * 4 + fx;
-                // row (f, tl): 8 floats; channel pair cp lives in 16-byte chunk (cp >> 1) ^ sw, 8-byte half cp & 1
-                *reinterpret_cast<f32x2*>(V + (f * 64 + tl) * WK + (((cp >> 1) ^ sw) * 4) + (cp & 1) * 2) = vv[fx];
-            }
+        for (int fx = 0; fx < 4; ++fx) {
+            const int f = fy * 4 + fx;
+            // row (f, tl): 8 floats; channel pair cp lives in 16-byte chunk (cp >> 1) ^ sw, 8-byte half cp & 1
+            *reinterpret_cast<f32x2*>(V + (f * 64 + tl) * WK + (((cp >> 1) ^ sw) * 4) + (cp & 1) * 2) = vv[fx];
         }
     };
     // ---- U fill: direct to LDS, 32-byte rows: one wave instruction = 32 rows; 16 f x 64 rows = 32 instructions per stage, 8 per wave
@@ -134,15 +144,16 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int fr = (wave * 8 + j) * 32 + (lane >> 1);          // flat row over (f, cout-in-block): f = fr / 64, r = fr % 64
-        const int f = fr >> 6, r = fr & 63;
-        const int ch = (lane & 1) ^ ((r >> 3) & 1);
-        const int co = c0 + r;
+        const int f = fr >> 6, r_ = fr & 63;
+        const int ch = (lane & 1) ^ ((r_ >> 3) & 1);
+        const int co = c0 + r_;
         uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * a.Cin + ch * 4) * 4) : -1;
     }
-    auto fill_u = [&](int buf, int kc) {
+    auto fill_u = [&](int buf, int kc, int j0 = 0, int j1 = 8) {
+        if (WINO_ABLATE & 2) return;
         float* U = smem + buf * W_STAGE + 16 * 64 * WK + wave * 8 * 32 * WK;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * WK * 4, 0, 0);
+        for (int j = j0; j < j1; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * WK * 4, 0, 0);
     };
 
     f32x16 acc[16];
@@ -155,30 +166,50 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     const int fsw = (li >> 3) & 1;
     load_patch(0);
     fill_u(0, 0);
-    store_v(0);
+    row_transform();
+#pragma unroll
+    for (int fy = 0; fy < 4; ++fy) store_v_row(0, fy);
     VPHO_SYNC_LDS_DMA();
+    // One wave per SIMD: nothing hides a latency unless the instruction stream does.  A stage is 16 frequency groups of 4 MFMAs (64
+    // cycles each); the A / B fragments of group f + 1 are requested BEFORE the products of group f issue (register double buffer), the
+    // next stage's work rides in the groups' shadows, ONE memory instruction per MFMA (a burst of 16 vector-memory instructions stalls
+    // the wave's issue -- and with it the matrix pipe -- for longer than the four MFMAs in flight last): the 16 patch loads in groups
+    // 0-3, the 8 U fills in groups 4-5, the row transform in group 11 (by then the loads have landed), one frequency row of the column
+    // transform + its 4 LDS writes in each of groups 12-15.
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) { load_patch(kc + 1); fill_u(buf ^ 1, kc + 1); }
+        // branch-free: the last stage prefetches itself once more into the idle buffer (nobody reads it) -- a loop body that is ONE
+        // basic block is what lets the scheduler place each memory instruction behind its own MFMA
+        const int kn = kc + 1 < nk ? kc + 1 : kc;
         const float* V = smem + buf * W_STAGE + (wt * 32 + li) * WK + ((lh ^ fsw) * 4);
         const float* U = smem + buf * W_STAGE + 16 * 64 * WK + (wc * 32 + li) * WK + ((lh ^ fsw) * 4);
+        f32x4 av[2], bv[2];
+        av[0] = *reinterpret_cast<const f32x4*>(V);
+        bv[0] = *reinterpret_cast<const f32x4*>(U);
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(V + f * 64 * WK);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(U + f * 64 * WK);
+            if (f < 15 && !(WINO_ABLATE & 16)) {
+                av[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(V + (f + 1) * 64 * WK);
+                bv[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(U + (f + 1) * 64 * WK);
+            }
+            if (f < 4) load_patch(kn, 4 * f, 4 * f + 4);
+            if (f == 4 || f == 5) fill_u(buf ^ 1, kn, 4 * (f - 4), 4 * (f - 4) + 4);
+            if (f == 11) row_transform();
+            if (f >= 12) store_v_row(buf ^ 1, f - 12);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[f], 0, 0, 0);
-        }
-        if (kc + 1 < nk) store_v(buf ^ 1);
-        // issue order of the stage: one MFMA, then a slice of the next stage's transform (vector adds, LDS writes) and of this stage's
-        // fragment reads -- one wave per SIMD, so whatever is not interleaved with the matrix pipe runs in front of it
+            for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f & 1][q], bv[f & 1][q], acc[f], 0, 0, 0);
+            // order inside the group: the next fragments first, then each MFMA followed by a share of the group's other work
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-        for (int gq = 0; gq < 64; ++gq) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        VPHO_SYNC_LDS_DMA();
+        if (!(WINO_ABLATE & 8)) VPHO_SYNC_LDS_DMA();
     }
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
