@@ -2,9 +2,29 @@
 (roi_align_kernel.cpp: legacy aligned=False, sampling_ratio=-1 adaptive grid, bilinear
 with the y<-1||y>H => 0 rule, clamp to [0,H-1]); call sites VPHO.py:125-128
 (output_size=32, spatial_scale=1/4).
+
+All RoI geometry in float32, like the kernel instantiated for float tensors (T = float): box edges, width / height, bin sizes,
+the adaptive grid counts ceil(roi_width / pooled_width) and the sample coordinates.  This is not a nicety: the square hull of a
+hand box that spans the whole 256-pixel crop is exactly 64 map pixels wide in float32 (grid count 2) and 64.000002 in double (grid
+count 3) -- a different set of sample points for the whole RoI.
 """
 import math
+
+import numpy as np
 import torch
+
+_f = np.float32
+
+
+def _geometry(roi, spatial_scale, ph, pw, offset=0.0, aligned=False):
+    """float32 RoI geometry of roi_align_kernel.cpp: (x1, y1, bin_h, bin_w, grid_h, grid_w) with x1.. as np.float32"""
+    sc, off = _f(spatial_scale), _f(offset)
+    x1, y1, x2, y2 = (_f(_f(v) * sc - off) for v in roi)
+    rw, rh = _f(x2 - x1), _f(y2 - y1)
+    if not aligned:
+        rw, rh = max(rw, _f(1.0)), max(rh, _f(1.0))
+    bh, bw = _f(rh / _f(ph)), _f(rw / _f(pw))
+    return x1, y1, bh, bw, int(math.ceil(_f(rh / _f(ph)))), int(math.ceil(_f(rw / _f(pw))))
 
 
 def _bilinear(feat, y, x):
@@ -41,26 +61,17 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, ali
     offset = 0.5 if aligned else 0.0
     for k in range(K):
         b = int(rois[k, 0])
-        # float32 arithmetic like the C++ kernel (T = float)
-        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
-        x1 = f32(f32(rois[k, 1]) * spatial_scale - offset)
-        y1 = f32(f32(rois[k, 2]) * spatial_scale - offset)
-        x2 = f32(f32(rois[k, 3]) * spatial_scale - offset)
-        y2 = f32(f32(rois[k, 4]) * spatial_scale - offset)
-        rw, rh = x2 - x1, y2 - y1
-        if not aligned:
-            rw, rh = max(rw, 1.0), max(rh, 1.0)
-        bh, bw = rh / ph, rw / pw
-        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
-        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
+        x1, y1, bh, bw, gh, gw = _geometry([float(v) for v in rois[k, 1:5]], spatial_scale, ph, pw, offset, aligned)
+        if sampling_ratio > 0:
+            gh = gw = sampling_ratio
         count = max(gh * gw, 1)
         for i in range(ph):
             for j in range(pw):
                 acc = feat.new_zeros(C)
                 for iy in range(gh):
-                    y = y1 + i * bh + (iy + 0.5) * bh / gh
+                    y = float(_f(_f(y1 + _f(_f(i) * bh)) + _f(_f(_f(iy + 0.5) * bh) / _f(gh))))
                     for ix in range(gw):
-                        x = x1 + j * bw + (ix + 0.5) * bw / gw
+                        x = float(_f(_f(x1 + _f(_f(j) * bw)) + _f(_f(_f(ix + 0.5) * bw) / _f(gw))))
                         acc = acc + _bilinear(feat[b], y, x)
                 out[k, :, i, j] = acc / count
     return out
@@ -76,17 +87,15 @@ def roi_align_fast(feat, rois, output_size, spatial_scale=1.0):
     rois = rois.float()
     for k in range(K):
         b = int(rois[k, 0])
-        x1, y1, x2, y2 = [(rois[k, i] * spatial_scale).item() for i in range(1, 5)]
-        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
-        bh, bw = rh / ph, rw / pw
-        gh, gw = int(math.ceil(rh / ph)), int(math.ceil(rw / pw))
+        x1, y1, bh, bw, gh, gw = _geometry([float(v) for v in rois[k, 1:5]], spatial_scale, ph, pw)
+        t32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
         ii = torch.arange(ph, dtype=torch.float32)
         jj = torch.arange(pw, dtype=torch.float32)
         acc = feat.new_zeros(C, ph, pw)
         for iy in range(gh):
-            y = y1 + ii * bh + (iy + 0.5) * bh / gh
+            y = (t32(y1) + ii * t32(bh)) + (t32(iy + 0.5) * t32(bh)) / t32(gh)          # float32 tensor arithmetic, the kernel's order
             for ix in range(gw):
-                x = x1 + jj * bw + (ix + 0.5) * bw / gw
+                x = (t32(x1) + jj * t32(bw)) + (t32(ix + 0.5) * t32(bw)) / t32(gw)
                 acc = acc + _bilinear_grid(feat[b], y, x)
         out[k] = acc / max(gh * gw, 1)
     return out

@@ -241,3 +241,24 @@ def test_rk45_is_bit_identical_to_scipy(case):
     assert np.array_equal(out['y'], res.y)                  # dense output at every stamp, bit for bit
     assert len(out['steps']) == (res.nfev - 2) // 6
     assert any(not s[3] for s in out['steps']) or case != 'stiffish'   # the stiff case exercises step rejection
+
+
+def test_roi_align_geometry_is_float32_like_the_kernel():
+    """roi_align_kernel.cpp runs its RoI geometry in T = float for float tensors.  The square hull of a hand box that spans the whole
+    256-pixel crop, [1.9469828605651855, 0, 257.9469909667969, 256] x 1/4: 64.48674774 - 0.48674572 is exactly 64 in float32 ->
+    ceil(64 / 32) = 2 samples per bin; in double it is 64.000002 -> 3 samples, other sample points for the whole RoI.  (Found by the
+    64-image reference fixture: the HIP kernel computed 2, the double-precision restatement 3.)"""
+    import numpy as np
+    from oracle import roi_align as RA
+    box = [1.9469828605651855, 0.0, 257.9469909667969, 256.0]
+    x1, y1, bh, bw, gh, gw = RA._geometry(box, 0.25, 32, 32)
+    assert (gh, gw) == (2, 2) and bw == np.float32(2.0) and isinstance(x1, np.float32)
+    assert (257.9469909667969 * 0.25 - 1.9469828605651855 * 0.25) / 32 > 2.0          # what double arithmetic would have rounded up
+    # scalar and vectorised forms agree on that box, and 2 x 2 samples per bin it is: a map that is linear in x is reproduced at the
+    # mean sample position of every bin
+    feat = torch.arange(64, dtype=torch.float32)[None, None, None, :].expand(1, 1, 64, 64).contiguous()
+    rois = torch.tensor([[0.0] + box])
+    a, b = RA.roi_align(feat, rois, 32, 0.25), RA.roi_align_fast(feat, rois, 32, 0.25)
+    assert torch.allclose(a, b, atol=1e-5)
+    want = float(x1) + 2.0 * torch.arange(32, dtype=torch.float32) + 1.0                # bin centre = mean of the samples at +0.5, +1.5
+    assert torch.allclose(b[0, 0, 5, :31], want[:31], atol=1e-5)                      # the last bin reaches past the map edge

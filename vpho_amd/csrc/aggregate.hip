@@ -324,7 +324,11 @@ __global__ void obj_verts_kernel(const double* __restrict__ pose, const float* _
 }
 
 // select_topk_object_by_physics3 (aggregation.py:947-997): one block per (image, candidate); the candidate's 2048 vertices
-// are transformed into LDS once, 32 force points search them (8 lanes per force point, shuffle arg-min).
+// are transformed into LDS once (16-byte records: one LDS read per vertex), 32 force points search them (8 lanes per force point,
+// shuffle arg-min).  The search compares SQUARED distances and takes the square root of the winner only: sqrt is monotone, so the
+// nearest vertex is the same one, with the tie rule "smaller squared distance, then smaller vertex index" (the reference's
+// torch.cdist + min leaves the order of equal distances to its kernel; two squared distances that differ in their last bit but
+// round to the same root are told apart here and not there).
 struct ObjPhysArgs {
     const double* cand; int n;                       // (bs, n, 9)
     const float* root; const float* vert_tab; const float* com_tab; const int* obj_id; const unsigned char* is_right; int nv;
@@ -332,7 +336,7 @@ struct ObjPhysArgs {
     float* score;                                     // (bs, n)
 };
 __global__ __launch_bounds__(256) void obj_physics_kernel(const ObjPhysArgs a) {
-    extern __shared__ float lds[];               // nv*3 transformed vertices
+    extern __shared__ __attribute__((aligned(16))) float lds[];               // nv x (x, y, z, -) transformed vertices
     __shared__ float s_d[32], s_r[32][3];
     const int b = blockIdx.x / a.n;
     const double* pp = a.cand + (long long)blockIdx.x * 9;
@@ -343,24 +347,30 @@ __global__ __launch_bounds__(256) void obj_physics_kernel(const ObjPhysArgs a) {
     const float sgn = a.is_right[b] ? 1.f : -1.f;
     const float* tab = a.vert_tab + (long long)a.obj_id[b] * a.nv * 3;
     for (int v = threadIdx.x; v < a.nv; v += blockDim.x) {
+        float o[3];
         for (int r = 0; r < 3; ++r) {
-            float val = (tab[v * 3 + 0] * R[r * 3 + 0] + tab[v * 3 + 1] * R[r * 3 + 1] + tab[v * 3 + 2] * R[r * 3 + 2]) + t[r];
-            lds[v * 3 + r] = r == 0 ? val * sgn : val;
+            const float val = (tab[v * 3 + 0] * R[r * 3 + 0] + tab[v * 3 + 1] * R[r * 3 + 1] + tab[v * 3 + 2] * R[r * 3 + 2]) + t[r];
+            o[r] = r == 0 ? val * sgn : val;
         }
+        *reinterpret_cast<float4*>(lds + v * 4) = make_float4(o[0], o[1], o[2], 0.f);
     }
     __syncthreads();
     const int an = threadIdx.x >> 3, sub = threadIdx.x & 7;       // 32 anchors x 8 lanes
     const float* fp = a.force_point + ((long long)b * 32 + an) * 3;
+    const float fx = fp[0], fy = fp[1], fz = fp[2];
     float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll 4
     for (int v = sub; v < a.nv; v += 8) {
-        const float dx = fp[0] - lds[v * 3 + 0], dy = fp[1] - lds[v * 3 + 1], dz = fp[2] - lds[v * 3 + 2];
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-        if (d < best || (d == best && v < bi)) { best = d; bi = v; }
+        const float4 p = *reinterpret_cast<const float4*>(lds + v * 4);
+        const float dx = fx - p.x, dy = fy - p.y, dz = fz - p.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < best) { best = d2; bi = v; }                      // v only grows within a lane: the first minimum stays
     }
     for (int o = 4; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    best = sqrtf(best);
     if (sub == 0) {
         // CoM of the candidate: R com + t, flipped
         const float* cm = a.com_tab + (long long)a.obj_id[b] * 3;
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256) void obj_physics_kernel(const ObjPhysArgs a) {
         for (int r = 0; r < 3; ++r) com[r] = (cm[0] * R[r * 3 + 0] + cm[1] * R[r * 3 + 1] + cm[2] * R[r * 3 + 2]) + t[r];
         com[0] *= sgn;
         s_d[an] = best;
-        for (int c = 0; c < 3; ++c) s_r[an][c] = (fp[c] - lds[bi * 3 + c]) - com[c];
+        for (int c = 0; c < 3; ++c) s_r[an][c] = (fp[c] - lds[bi * 4 + c]) - com[c];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -481,21 +491,24 @@ __constant__ int c_finger_anchor[5][4] = {{1, 2, 3, 4}, {8, 9, 10, 11}, {14, 15,
 __global__ __launch_bounds__(256) void hand_phys_score_kernel(const float* __restrict__ force_point, const float* __restrict__ force_global,
                                                               const float* __restrict__ obj_vert, int nv, int n_cand,
                                                               float* __restrict__ finger_score) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // nv x (x, y, z, -): one LDS read per vertex
     __shared__ float s_d[32];
     const int b = blockIdx.x / n_cand;
     const float* ov = obj_vert + (long long)b * nv * 3;
-    for (int i = threadIdx.x; i < nv * 3; i += blockDim.x) lds[i] = ov[i];
+    for (int v = threadIdx.x; v < nv; v += blockDim.x) *reinterpret_cast<float4*>(lds + v * 4) = make_float4(ov[v * 3], ov[v * 3 + 1], ov[v * 3 + 2], 0.f);
     __syncthreads();
     const int an = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const float* fp = force_point + ((long long)blockIdx.x * 32 + an) * 3;
-    float best = INFINITY;
+    const float fx = fp[0], fy = fp[1], fz = fp[2];
+    float best = INFINITY;                                               // min of the SQUARED distances; sqrt is monotone and correctly
+#pragma unroll 4                                                         // rounded, so sqrt(min d2) == min sqrt(d2) bit for bit
     for (int v = sub; v < nv; v += 8) {
-        const float dx = fp[0] - lds[v * 3 + 0], dy = fp[1] - lds[v * 3 + 1], dz = fp[2] - lds[v * 3 + 2];
-        best = fminf(best, sqrtf(dx * dx + dy * dy + dz * dz));
+        const float4 p = *reinterpret_cast<const float4*>(lds + v * 4);
+        const float dx = fx - p.x, dy = fy - p.y, dz = fz - p.z;
+        best = fminf(best, dx * dx + dy * dy + dz * dz);
     }
     for (int o = 4; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));
-    if (sub == 0) s_d[an] = best;
+    if (sub == 0) s_d[an] = sqrtf(best);
     __syncthreads();
     if (threadIdx.x == 0) {
         const float* fg = force_global + (long long)blockIdx.x * 32 * 3;
@@ -622,14 +635,14 @@ extern "C" int vpho_obj_physics_score(const double* cand, int n, const float* ro
                                       const unsigned char* is_right, const float* force_point, const float* force_global, int bs,
                                       float* score, void* stream) {
     VPHO_REQUIRE(cand && root && t && t->vert && t->com && obj_id && is_right && force_point && force_global && score && bs > 0 && n > 0, "vpho_obj_physics_score: bad argument");
-    VPHO_REQUIRE(t->n_vert > 0 && (size_t)t->n_vert * 12 <= 64 * 1024, "vpho_obj_physics_score: object point cloud of %d vertices does not fit LDS", t->n_vert);
+    VPHO_REQUIRE(t->n_vert > 0 && (size_t)t->n_vert * 16 <= 64 * 1024, "vpho_obj_physics_score: object point cloud of %d vertices does not fit LDS", t->n_vert);
     ObjPhysArgs a;
     a.cand = cand; a.n = n; a.root = root; a.vert_tab = t->vert; a.com_tab = t->com; a.obj_id = obj_id; a.is_right = is_right; a.nv = t->n_vert;
     a.force_point = force_point; a.force_global = force_global; a.score = score;
     // algorithmic bytes: the object's vertex table and the 32 force points / forces once per image, 72-byte pose + score per candidate
     vpho::ProfScope prof(vpho::PROF_OBJ_PHYSICS, (hipStream_t)stream, 0.0,
                          (double)bs * ((double)t->n_vert * 12 + 2 * 32 * 12) + (double)bs * n * (72 + 4));
-    hipLaunchKernelGGL(obj_physics_kernel, dim3(bs * n), dim3(256), (size_t)t->n_vert * 12, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(obj_physics_kernel, dim3(bs * n), dim3(256), (size_t)t->n_vert * 16, (hipStream_t)stream, a);
     return vpho::check_launch("obj_physics_kernel");
 }
 
@@ -672,7 +685,7 @@ extern "C" int vpho_hand_phys_score_f32(const float* force_point, const float* f
                                         int bs, int n_cand, float* finger_score, void* stream) {
     VPHO_REQUIRE(force_point && force_global && obj_vert && finger_score && bs > 0 && n_cand > 0 && n_vert > 0 && (size_t)n_vert * 12 <= 64 * 1024,
                  "vpho_hand_phys_score_f32: bad argument");
-    hipLaunchKernelGGL(hand_phys_score_kernel, dim3(bs * n_cand), dim3(256), (size_t)n_vert * 12, (hipStream_t)stream,
+    hipLaunchKernelGGL(hand_phys_score_kernel, dim3(bs * n_cand), dim3(256), (size_t)n_vert * 16, (hipStream_t)stream,
                        force_point, force_global, obj_vert, n_vert, n_cand, finger_score);
     return vpho::check_launch("hand_phys_score_kernel");
 }
