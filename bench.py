@@ -312,7 +312,7 @@ def main():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` (name prefix) from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE; profiles/r0N_pmc_hbm_traffic.json, produced by scripts/pmc_summary.py, newest round first); None when absent."""
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_hbm_traffic.json')
         try:
             with open(path) as f:

@@ -1,11 +1,12 @@
 """Copy the summaries scripts/profile_round.sh left under gpurun_out/ (r02b_*) into profiles/ with their command headers."""
 import json, shutil, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[2] if len(sys.argv) > 2 else rnd + 'b'
 g = 'gpurun_out/'
-seq, pipe = json.load(open(g + 'r02b_seq.json')), json.load(open(g + 'r02b_pipe.json'))
-A, As, B = open(g + 'r02b_seq_all.txt').read(), open(g + 'r02b_seq_ss.txt').read(), open(g + 'r02b_pipe_ss.txt').read()
+seq, pipe = json.load(open(g + tag + '_seq.json')), json.load(open(g + tag + '_pipe.json'))
+A, As, B = open(g + tag + '_seq_all.txt').read(), open(g + tag + '_seq_ss.txt').read(), open(g + tag + '_pipe_ss.txt').read()
 r = seq['roofline']
-txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --pipeline 1 --steps 10   (MI355X, round 2, final kernels: FPN stride-4 outputs on the RoI windows, score-head tail tiles, pre-activation prologue on the direct-to-LDS kernel; sequential steps: 3 warm-up + 10 timed + the instrumented repeats that feed the roofline / hbm blocks; README config bs=64, sample_num=100, sampling_steps=50, T0=0.65; weights = vpho_amd.synth.bench_state_dict: nfev 51/51)
+txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --pipeline 1 --steps 10   (MI355X, {rnd}, default plan: Winograd F(2x2,3x3) for the 3x3 / stride-1 convolutions incl. the RoI-windowed FPN ones, score-head tail tiles; sequential steps: 3 warm-up + 10 timed + the instrumented repeats that feed the roofline / hbm blocks; README config bs=64, sample_num=100, sampling_steps=50, T0=0.65; weights = vpho_amd.synth.bench_state_dict: nfev 51/51)
 # this run's bench line:
 #   value {seq['value']:.1f} images/s (sequential, under the profiler), roofline.avg_launch_us {r['avg_launch_us']:.2f} -> {r['achieved']:.1f} TFLOP/s, frac {r['frac']:.3f}; score_head {r['score_head']['achieved']:.1f} TFLOP/s in-run, {r['score_head']['samplers_serialised']['achieved']:.1f} with the samplers serialised
 # summary produced from the rocpd database by scripts/rocpd_stats.py (whole trace); recipe: scripts/profile_round.sh + scripts/install_profiles.py
@@ -16,13 +17,13 @@ txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_ba
 #   this run's bench line: {pipe['value']:.1f} images/s, {pipe['ms_per_step']:.2f} ms/step under the profiler
 {B}"""
 open(f'profiles/{rnd}_kernel_stats_bench_cfg2.txt', 'w').write(txt)
-hdr = open(f'profiles/{rnd}_pmc_hbm_traffic.txt').read().split('\n')[:2]
-open(f'profiles/{rnd}_pmc_hbm_traffic.txt', 'w').write('\n'.join(hdr) + '\n' + open(g + 'r02b_pmc_hbm.txt').read())
-hdr = open(f'profiles/{rnd}_pmc_mfma_busy.txt').read().split('\n')[:1]
-open(f'profiles/{rnd}_pmc_mfma_busy.txt', 'w').write('\n'.join(hdr) + '\n' + open(g + 'r02b_pmc_mfma.txt').read())
-shutil.copy(g + 'r02b_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic.json')
-shutil.copy(g + 'r02b_bench_default.json', f'profiles/{rnd}_bench_default.json')
-d = json.load(open(g + 'r02b_bench_default.json'))
+hdr = f"# HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of  VPHO_GRAPHS=0 python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing --pipeline 1  ({rnd}; scripts/profile_round.sh, summary by scripts/pmc_summary.py)\n# per-launch averages over all launches of each kernel; HBM column = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (counters in KB; gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md)"
+open(f'profiles/{rnd}_pmc_hbm_traffic.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_hbm.txt').read())
+hdr = f"# MFMA pipe utilisation from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT) of the same command ({rnd}; summary by scripts/pmc_mfma_summary.py)"
+open(f'profiles/{rnd}_pmc_mfma_busy.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_mfma.txt').read())
+shutil.copy(g + tag + '_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic.json')
+shutil.copy(g + tag + '_bench_default.json', f'profiles/{rnd}_bench_default.json')
+d = json.load(open(g + tag + '_bench_default.json'))
 print('default bench:', d['value'], d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'traffic', d['roofline']['traffic'])
 print('head:', d['roofline']['score_head'])
 print('hbm:', {k: (round(v['GB/s']), round(v['frac'], 3), round(v['avg_launch_us'], 1)) for k, v in d['hbm']['kernels'].items()})

@@ -1049,10 +1049,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     // Tile plan: 128-row tiles; when the last round of the launch would be less than half full, the rows beyond the last full round
     // become 32-row tail tiles (see head_tile).  VPHO_HEAD_TAIL=0: ordinary tiles only.
     static const int tail_on = getenv("VPHO_HEAD_TAIL") ? atoi(getenv("VPHO_HEAD_TAIL")) : 1;
-    static int slots = 0;
+    static int slots_of[64] = {0};                          // per device: one process may drive several GPUs of different sizes
+    int dev = 0;
+    VPHO_HIP(hipGetDevice(&dev));
+    int& slots = slots_of[dev & 63];
     if (!slots) {
-        int dev = 0; hipDeviceProp_t prop;
-        VPHO_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
         VPHO_HIP(hipGetDeviceProperties(&prop, dev));
         slots = 2 * prop.multiProcessorCount;               // two 57 KB workgroups per CU
     }

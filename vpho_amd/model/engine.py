@@ -136,18 +136,20 @@ class Engine:
         return _signature(model) != self.sig
 
     # ------------------------------------------------------------------------------------------------ feature path
-    def _bottleneck(self, x, b):
+    def _bottleneck(self, x, b, out=None):
         y = ops.conv2d_nhwc(x, *b['c1'], out_slope=0.01)
         if b['stride'] == 1:
             y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd)
         else:
             y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01)
         r = x if b['down'] is None else ops.conv2d_nhwc(x, *b['down'], stride=b['stride'])
-        return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01)
+        return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01, out=out)
 
-    def _layer(self, x, name):
-        for b in self.layers[name]:
-            x = self._bottleneck(x, b)
+    def _layer(self, x, name, out=None):
+        """``out``: where the layer's LAST block writes its result (a slice of a larger buffer)"""
+        blocks = self.layers[name]
+        for i, b in enumerate(blocks):
+            x = self._bottleneck(x, b, out if i == len(blocks) - 1 else None)
         return x
 
     def _fpn(self, rgb, windows=None):
@@ -182,16 +184,18 @@ class Engine:
         x = ops.nchw_to_nhwc(rgb, 4)
         c1 = ops.maxpool_nhwc(ops.conv2d_nhwc(x, *self.stem, kh=7, kw=7, stride=2, pad=3, out_slope=0.01), 3, 2, 1)
         c2 = self._layer(c1, 'layer1_h')
+        # shared layer4 (quirk Q6): both branches go through the same weights, so they run as ONE batch of 2N images
+        # (twice the tiles per launch at 8x8 resolution, half the launches); convolutions are per-image, results unchanged.  The two
+        # layer3 stacks write their last block straight into the halves of that batch: no concatenation copy
+        n = c2.shape[0]
+        c4 = torch.empty((2 * n, c2.shape[1] // 4, c2.shape[2] // 4, self.layers['layer3_h'][-1]['c3'][0].shape[0]), device=c2.device)
         with self._side():
             c3o = self._layer(c2, 'layer2_o')
-            c4o = self._layer(c3o, 'layer3_o')
+            c4o = self._layer(c3o, 'layer3_o', out=c4[n:])
         c3h = self._layer(c2, 'layer2_h')
-        c4h = self._layer(c3h, 'layer3_h')
+        c4h = self._layer(c3h, 'layer3_h', out=c4[:n])
         self._join()
-        # shared layer4 (quirk Q6): both branches go through the same weights, so they run as ONE batch of 2N images
-        # (twice the tiles per launch at 8x8 resolution, half the launches); convolutions are per-image, results unchanged
-        n = c4h.shape[0]
-        c5 = self._layer(torch.cat([c4h, c4o], 0), 'layer4_h')
+        c5 = self._layer(c4, 'layer4_h')
         return dict(c2=c2, h=(c5[:n], c4h, c3h), o=(c5[n:], c4o, c3o))
 
     def _fpn_branch(self, br, tr, windows):
