@@ -79,9 +79,9 @@ typedef struct {
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
-/* Winograd F(2x2, 3x3) form of a 3x3 / stride 1 / padding 1 convolution (+ bias, LeakyReLU): u = G g G^T, (16, Cout, Cin) fp32 from
- * model/pack.py::winograd_weights; 2.25 x fewer multiply-adds on the matrix cores, input / output transforms inside the kernel
- * (csrc/conv_winograd.hip).  Needs even H, W, Cin % 8 == 0, Cout % 64 == 0.  Results differ from vpho_conv2d_nhwc_f32 by fp32 rounding
+/* Winograd F(2x2, 3x3) form of a 3x3 / stride 1 / padding 1 convolution (+ bias, LeakyReLU): u = G g G^T, fp32, stage-tiled as
+ * (Cin/8, 16 frequencies, Cout, 8 input channels) by model/pack.py::winograd_weights; 2.25 x fewer multiply-adds on the matrix cores, input / output transforms inside the kernel
+ * (csrc/conv_winograd.hip).  Needs even H, W, Cin % 16 == 0, Cout % 64 == 0.  Results differ from vpho_conv2d_nhwc_f32 by fp32 rounding
  * of the transforms (~1e-6 relative). */
 int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                    float out_slope, float* y, int y_ld, void* stream);

@@ -60,8 +60,16 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int wt = wave & 1, wc = wave >> 1;
+    // XCD-aware block order: workgroup i runs on XCD i % 8, and every XCD has its own L2.  All tile blocks that share an output-channel
+    // block share its 16 x 64 x Cin slice of u (1 MB at Cin = 256), so XCD x takes ONE channel block (x % ncb) and every (8 / ncb)-th
+    // tile block: its L2 holds that slice instead of all of u, and tile blocks beyond the last live one (RoI windows) are spread evenly.
     const int ncb = a.Cout / W_CB;
-    const int tb = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+    int tb, cb;
+    if (ncb <= 8 && (8 % ncb) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, G = 8 / ncb;
+        cb = xcd % ncb; tb = slot * G + xcd / ncb;
+    } else { tb = blockIdx.x / ncb; cb = blockIdx.x % ncb; }
+    if (tb * W_TB >= a.T) return;                        // grid rounded up to whole XCD rounds
     const int t0 = tb * W_TB, c0 = cb * W_CB;
     if (a.wins && t0 >= a.tile_base[a.N]) return;      // the grid is sized for every tile of the full maps; uniform per workgroup
     // destination of every tile of this block (output transform): row of its top-left pixel in y, row pitch, which of the 4 pixels exist
@@ -101,18 +109,27 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     for (int p = 0; p < 16; ++p) {
         const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
         const bool in = tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        poff[p] = in ? (int)((((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + 2 * cp) * 4) : -1;
+        poff[p] = in ? (int)((((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + 4 * cp) * 4) : -1;
     }
-    f32x2 patch[16], r[16];
-    auto load_patch = [&](int kc, int p0 = 0, int p1 = 16) {
+    // A load is 16 bytes = 4 channels of a 16-channel SUPER-STAGE (half the vector-memory instructions of 8-byte loads, and a wave
+    // instruction asks for 64 contiguous bytes of a pixel instead of 32).  A k stage takes one channel PAIR of every lane: stage e
+    // (0 / 1) of super-stage ss multiplies channels 16 ss + {0,1,4,5,8,9,12,13} + 2 e -- any 8 channels will do as long as u holds the
+    // same ones in the same slots (pack.winograd_weights).  pc: the super-stage being consumed, pnx: the next one, in flight.
+    f32x4 pc[16], pnx[16];
+    f32x2 r[16];
+    auto load_patch = [&](f32x4 (&dst)[16], int ss, int p0 = 0, int p1 = 16) {
 #pragma unroll
         for (int p = p0; p < p1; ++p) {
-            if (WINO_ABLATE & 1) { patch[p] = f32x2{(float)p, 1.f}; continue; }
-            patch[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, poff[p], kc * WK * 4, 0));
+            if ((WINO_ABLATE & 1) || ((WINO_ABLATE & 32) && (p & 1))) { dst[p] = f32x4{(float)p, 1.f, 2.f, 3.f}; continue; }
+            dst[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, poff[p], ss * 64, 0));
+            if (WINO_ABLATE & 64) { asm volatile("" :: "v"(dst[p])); dst[p] = f32x4{(float)p, 1.f, 2.f, 3.f}; }      // load issued, result unused
         }
     };
     // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first (row_transform), then columns of one frequency row fy
-    auto row_transform = [&]() {
+    auto row_transform = [&](const f32x4 (&src)[16], int e) {
+        f32x2 patch[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) patch[p] = e ? f32x2{src[p][2], src[p][3]} : f32x2{src[p][0], src[p][1]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             r[0 * 4 + c] = patch[0 * 4 + c] - patch[2 * 4 + c];
@@ -140,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // ---- U fill: direct to LDS, 32-byte rows: one wave instruction = 32 rows; 16 f x 64 rows = 32 instructions per stage, 8 per wave
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, 0xFFFFFFF0u, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int ustage = 16 * a.Cout * WK * 4;                        // bytes of one k stage of u (stage-tiled: [Cin/8][16][Cout][8])
     int uoff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -147,13 +165,13 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         const int f = fr >> 6, r_ = fr & 63;
         const int ch = (lane & 1) ^ ((r_ >> 3) & 1);
         const int co = c0 + r_;
-        uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * a.Cin + ch * 4) * 4) : -1;
+        uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * WK + ch * 4) * 4) : -1;       // within the stage's block of u
     }
     auto fill_u = [&](int buf, int kc, int j0 = 0, int j1 = 8) {
         if (WINO_ABLATE & 2) return;
         float* U = smem + buf * W_STAGE + 16 * 64 * WK + wave * 8 * 32 * WK;
 #pragma unroll
-        for (int j = j0; j < j1; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * WK * 4, 0, 0);
+        for (int j = j0; j < j1; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * ustage, 0, 0);
     };
 
     f32x16 acc[16];
@@ -162,25 +180,24 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
 
-    const int nk = a.Cin / WK;
+    const int nss = a.Cin / (2 * WK);                              // super-stages of 16 channels = 2 k stages
     const int fsw = (li >> 3) & 1;
-    load_patch(0);
+    load_patch(pc, 0);
     fill_u(0, 0);
-    row_transform();
+    row_transform(pc, 0);
 #pragma unroll
     for (int fy = 0; fy < 4; ++fy) store_v_row(0, fy);
     VPHO_SYNC_LDS_DMA();
     // One wave per SIMD: nothing hides a latency unless the instruction stream does.  A stage is 16 frequency groups of 4 MFMAs (64
-    // cycles each); the A / B fragments of group f + 1 are requested BEFORE the products of group f issue (register double buffer), the
-    // next stage's work rides in the groups' shadows, ONE memory instruction per MFMA (a burst of 16 vector-memory instructions stalls
-    // the wave's issue -- and with it the matrix pipe -- for longer than the four MFMAs in flight last): the 16 patch loads in groups
-    // 0-3, the 8 U fills in groups 4-5, the row transform in group 11 (by then the loads have landed), one frequency row of the column
-    // transform + its 4 LDS writes in each of groups 12-15.
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        // branch-free: the last stage prefetches itself once more into the idle buffer (nobody reads it) -- a loop body that is ONE
-        // basic block is what lets the scheduler place each memory instruction behind its own MFMA
-        const int kn = kc + 1 < nk ? kc + 1 : kc;
+    // cycles each); the A / B fragments of a group are requested two groups ahead (register double buffer), and the next stage's work
+    // rides in the groups' shadows, ONE memory instruction per MFMA (a burst of vector-memory instructions stalls the wave's issue --
+    // and with it the matrix pipe -- for longer than the MFMAs in flight last): in the EVEN stage of a super-stage the 16 patch loads
+    // of the next super-stage (groups 0-3), in both the 8 U fills (groups 4-5), the row transform (group 11) and one frequency row
+    // of the column transform + its 4 LDS writes (groups 12-15).  Branch-free -- the last stages prefetch the last super-stage once
+    // more into registers / the idle buffer -- so that the loop body is ONE basic block the scheduler can interleave.
+    auto stage = [&](int kc, int e, int ssn) {
+        const int buf = e;                                          // stage kc = 2 ss + e computes from buffer e
+        const int kn = kc + 1 < 2 * nss ? kc + 1 : kc;              // the stage whose V / U this one prepares (into buffer e ^ 1)
         const float* V = smem + buf * W_STAGE + (wt * 32 + li) * WK + ((lh ^ fsw) * 4);
         const float* U = smem + buf * W_STAGE + 16 * 64 * WK + (wc * 32 + li) * WK + ((lh ^ fsw) * 4);
         f32x4 av[2], bv[2];
@@ -192,9 +209,9 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
                 av[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(V + (f + 1) * 64 * WK);
                 bv[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(U + (f + 1) * 64 * WK);
             }
-            if (f < 4) load_patch(kn, 4 * f, 4 * f + 4);
+            if (e == 0 && f < 4) load_patch(pnx, ssn, 4 * f, 4 * f + 4);
             if (f == 4 || f == 5) fill_u(buf ^ 1, kn, 4 * (f - 4), 4 * (f - 4) + 4);
-            if (f == 11) row_transform();
+            if (f == 11) { if (e == 0) row_transform(pc, 1); else row_transform(pnx, 0); }
             if (f >= 12) store_v_row(buf ^ 1, f - 12);
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f & 1][q], bv[f & 1][q], acc[f], 0, 0, 0);
@@ -204,12 +221,19 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(WINO_ABLATE & 8)) VPHO_SYNC_LDS_DMA();
+    };
+    for (int ss = 0; ss < nss; ++ss) {
+        const int ssn = ss + 1 < nss ? ss + 1 : ss;
+        stage(2 * ss, 0, ssn);
+        stage(2 * ss + 1, 1, ssn);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
     }
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
@@ -276,9 +300,10 @@ extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, co
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
                        const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream) {
     VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
-    VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % WK == 0 && Cout % W_CB == 0 && x_ld % 2 == 0 && x_ld >= Cin && y_ld >= Cout,
-                 "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 8 == 0, Cout %% 64 == 0");
-    VPHO_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)u & 15) == 0 && 64.0 * Cout * Cin < 3.9e9, "vpho_conv3x3_winograd_nhwc_f32: alignment / size");
+    VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % (2 * WK) == 0 && Cout % W_CB == 0 && x_ld % 4 == 0 && x_ld >= Cin && y_ld >= Cout,
+                 "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 16 == 0, Cout %% 64 == 0, x_ld %% 4 == 0");
+    VPHO_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)u & 15) == 0 && 64.0 * Cout * Cin < 3.9e9 && 4.0 * N * H * W * x_ld < 3.9e9,
+                 "vpho_conv3x3_winograd_nhwc_f32: alignment / size (16-byte aligned x and u, tensors below 3.9 GB: 32-bit buffer offsets)");
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
@@ -295,6 +320,9 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     const double tl = (wins && tiles_hint > 0) ? (double)tiles_hint : (double)a.T;
     vpho::ProfScope prof(vpho::PROF_WINOGRAD, (hipStream_t)stream, 2.0 * 16.0 * tl * Cout * (double)Cin,
                          4.0 * (4.0 * tl * Cin + 16.0 * Cout * Cin + 4.0 * tl * Cout));
-    hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)(tbs * (Cout / W_CB))), dim3(256), lds, (hipStream_t)stream, a);
+    const int ncb = Cout / W_CB;
+    unsigned blocks = (unsigned)(tbs * ncb);
+    if (ncb <= 8 && (8 % ncb) == 0) { const int G = 8 / ncb; blocks = (unsigned)((tbs + G - 1) / G) * 8u; }
+    hipLaunchKernelGGL(conv_winograd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
     return vpho::check_launch("conv_winograd_kernel");
 }

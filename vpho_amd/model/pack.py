@@ -45,11 +45,19 @@ def pack_deconv4x4s2(w):
 
 
 def winograd_weights(w_packed, cin=None):
-    """packed 3x3 weights (Cout, 9*Cin) -> U (16, Cout, Cin) = G g G^T of Winograd F(2x2, 3x3), computed in fp64
-    (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]); frequency f = 4*fy + fx."""
+    """packed 3x3 weights (Cout, 9*Cin) -> U = G g G^T of Winograd F(2x2, 3x3), computed in fp64 (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]),
+    frequency f = 4*fy + fx, stored STAGE-TILED as (Cin/8, 16, Cout, 8): the 8 input channels x 16 frequencies x Cout rows the kernel
+    fills into LDS for one k stage are one contiguous block (a fill instruction reads 1 KB of consecutive bytes instead of 32-byte
+    pieces of 32 different rows).  Which 8 channels a stage holds follows the kernel's 16-byte input loads: stage 2 ss + e takes one
+    channel pair of every 4-channel load of the 16-channel group ss: channels 16 ss + 4 (j >> 1) + 2 e + (j & 1) in slot j."""
     cout = w_packed.shape[0]
     cin = w_packed.shape[1] // 9 if cin is None else cin
-    g = w_packed.double().view(cout, 3, 3, cin)
-    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=w_packed.device)
+    # on the HOST: a one-time weight transform, and a torch contraction on the device would pull rocBLAS kernels into the process
+    g = w_packed.detach().double().cpu().view(cout, 3, 3, cin)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
     U = torch.einsum('ar,orsc,bs->aboc', G, g, G)                     # (4, 4, Cout, Cin)
-    return U.reshape(16, cout, cin).float().contiguous()
+    assert cin % 16 == 0
+    j = torch.arange(8)
+    chan = (16 * torch.arange(cin // 16)[:, None, None] + 2 * torch.arange(2)[None, :, None] + (4 * (j >> 1) + (j & 1))[None, None, :]).reshape(-1)
+    U = U.reshape(16, cout, cin)[:, :, chan].reshape(16, cout, cin // 8, 8).permute(2, 0, 1, 3)          # (Cin/8, 16, Cout, 8)
+    return U.float().contiguous().to(w_packed.device)

@@ -180,13 +180,13 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
 
 def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None):
     """3x3 / stride 1 / pad 1 convolution + bias + LeakyReLU of the inference plan: the Winograd F(2x2,3x3) kernel where its shape
-    conditions hold (even H and W, Cin % 8 == 0, Cout % 64 == 0), else the direct implicit GEMM.  The transformed weights live on the
+    conditions hold (even H and W, Cin % 16 == 0, Cout % 64 == 0), else the direct implicit GEMM.  The transformed weights live on the
     weight tensor object and follow its version.  ``rows`` = a ``RoiWindows``: only the window pixels, as the compact (N*H*W, Cout)
     matrix (see conv2d_nhwc)."""
     N, H, W, x_ld = x.shape
     cout, k9 = w.shape
     cin = k9 // 9
-    if not winograd or H % 2 or W % 2 or cin % 8 or cout % 64 or x_ld != cin or getattr(_conv_split, 'terms', 0):
+    if not winograd or H % 2 or W % 2 or cin % 16 or cout % 64 or x_ld != cin or getattr(_conv_split, 'terms', 0):
         return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, rows=rows)
     c = getattr(w, '_vpho_wino', None)
     if c is None or c[0] != w._version:
@@ -197,9 +197,10 @@ def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None):
 
 
 def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None, rows=None):
-    """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (16, Cout, Cin)"""
+    """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (Cin/8, 16, Cout, 8)"""
     N, H, W, x_ld = x.shape
-    _, cout, cin = u.shape
+    cout, cin = u.shape[2], u.shape[0] * 8
+    assert u.shape[1] == 16 and u.shape[3] == 8
     if rows is not None:
         assert rows.shape == (N, H, W)
         if out is None:
