@@ -55,6 +55,7 @@ def parse():
                    help='weak (default): every rank its own batch of --bs images, like accelerate\'s prepared DataLoader (train_diff_hand_obj.py:121-124); '
                         'strong: ONE global batch of --bs images per step, rank r takes images [r*bs/N, (r+1)*bs/N) (SURVEY 8e); the batch-coupled '
                         'quirks Q3 / Q5 then see the LOCAL batch of bs/N images')
+    p.add_argument('--device_prior', action='store_true', help='opt-in: the sampler prior from the device generator (Philox) instead of the CPU default generator (sde.py:26-28); a different random stream')
     p.add_argument('--no_roi_window', action='store_true', help='compute the full stride-4 FPN maps instead of the pixels the RoIAligns read (same results; A/B aid)')
     return p.parse_args()
 
@@ -113,6 +114,8 @@ def main():
     os.environ['VPHO_SCORE_MFMA'] = score_mfma             # read when an execution plan packs its score networks
     if args.no_winograd:
         os.environ['VPHO_WINOGRAD'] = '0'
+    if args.device_prior:
+        os.environ['VPHO_DEVICE_PRIOR'] = '1'
     conv_mfma = os.environ.get('VPHO_CONV_MFMA', 'f32') if args.conv_mfma == 'f32' else args.conv_mfma
     os.environ['VPHO_CONV_MFMA'] = conv_mfma
     model._engine = Engine(model)
@@ -263,7 +266,8 @@ def main():
                                           'pixel_share_hand_obj_per_batch': roi_frac,
                                           'boxes': 'synth_batch: hand / object half-extent = focal * 0.11 / depth x U(0.75,1.15) / U(0.6,1.1), unchanged since round 1'},
                        'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
-                       'nfev_hand_obj_per_step': nfev[-1], 'prior_draw': 'CPU generator inside the timed step (sde.py:26-28)'},
+                       'nfev_hand_obj_per_step': nfev[-1],
+                       'prior_draw': 'device generator (Philox), opt-in: NOT the reference RNG stream' if eng.device_prior else 'CPU generator inside the timed step (sde.py:26-28)'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2,false> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)' if conv_mfma == 'f32'
                          else f'conv_igemm_split_kernel<128,128,4,2,{conv_mfma[-1]}> (split-bf16 products, opt-in)', 'achieved': conv_tf,
                          'peak': conv_peak, 'unit': 'TFLOP/s', 'frac': conv_tf / conv_peak,

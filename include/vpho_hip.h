@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* vpho_last_error(void);
-int vpho_abi_version(void);
+int vpho_abi_version(void);   /* 6 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -229,6 +229,10 @@ typedef struct {
     const float *posedirs_t;   /* [135][778*3]  */
     const float *J_regressor;  /* [16][778]     */
     const float *weights;      /* [778][16]     */
+    /* ABI version 6, optional (NULL: read the columns from posedirs_t): the 30 pose-blend columns of the 10 finger-tip vertices
+     * (5 manopth tips 745, 317, 444, 556, 673, then 5 HO3D tips 728, 353, 442, 576, 694; column = tip * 3 + c) gathered into one
+     * contiguous [135][30] table -- the joints-only launches of the heat-map cascade read nothing else of the 1.26 MB table */
+    const float *tip_posedirs_t;
 } vpho_mano_tables;
 /* per image: v_shaped (n_img,778,3), J (n_img,16,3) from betas (n_img,10) */
 int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream);

@@ -185,3 +185,30 @@ def test_pipelined_evaluator_equals_sequential_loop(model_cpu, assets):
     for a, b in zip(seq, par):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_device_prior_switch_is_seeded_and_off_by_default(model_cpu, assets):
+    """VPHO_DEVICE_PRIOR: off by default (the CPU generator's draw order is the reference's RNG contract, sde.py:26-28); on, the prior
+    comes from the device generator: reproducible under torch.cuda.manual_seed, finite, and a different stream"""
+    import copy
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.model.engine import Engine
+    from vpho_amd.synth import synth_batch
+    saved = (cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0)
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 6, 5, 6, 3, 0.2
+    try:
+        m = copy.deepcopy(model_cpu).cuda().eval()
+        data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(2, assets, seed=5).items()}
+        eng = Engine(m)
+        assert eng.device_prior is False
+        torch.manual_seed(3)
+        ref = eng.predict(data)['diff_final_hand_mano'].clone()
+        eng.device_prior = True
+        outs = []
+        for _ in range(2):
+            torch.manual_seed(3)
+            torch.cuda.manual_seed(11)
+            outs.append(eng.predict(data)['diff_final_hand_mano'].clone())
+        assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all()) and not torch.equal(outs[0], ref)
+    finally:
+        cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved

@@ -130,18 +130,27 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
     }
     __syncthreads();
 
-    // vp = v_shaped + posedirs . pose_map (k ascending), T = sum_j w_j A_j (j ascending), out = T [vp; 1]
+    // vp = v_shaped + posedirs . pose_map (k ascending), T = sum_j w_j A_j (j ascending), out = T [vp; 1].
+    // The two contractions (135-long pose blend, 16-joint transform blend) are matrix products in the reference (torch.matmul inside
+    // manopth: a BLAS kernel with fused multiply-adds in its own order), so they are written as FUSED multiply-adds here, two lanes of a
+    // packed instruction at a time (v_pk_fma_f32: the fp32 rate of the matrix cores' 16x16x4 instruction, twice that of mul + add --
+    // the build otherwise runs with -ffp-contract=off).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto skin_tail = [&](int h, int v, const float* wv, const float* blend, float* out3) {
         const float* vsh = a.v_shaped + (long long)img_of(h) * NV * 3;
         float vp[3];
         for (int c = 0; c < 3; ++c) vp[c] = vsh[v * 3 + c] + blend[c];
-        float T[12];
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        f32x2 T[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) T[e] = f32x2{0.f, 0.f};
+#pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float w = wv[j];
-            for (int e = 0; e < 12; ++e) T[e] += A[h][j][e] * w;
+            const f32x2 w = {wv[j], wv[j]};
+            const f32x2* Aj = reinterpret_cast<const f32x2*>(A[h][j]);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) T[e] = __builtin_elementwise_fma(Aj[e], w, T[e]);
         }
-        for (int r = 0; r < 3; ++r) out3[r] = T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3];
+        for (int r = 0; r < 3; ++r) out3[r] = fmaf(T[2 * r][0], vp[0], fmaf(T[2 * r][1], vp[1], fmaf(T[2 * r + 1][0], vp[2], T[2 * r + 1][1])));
     };
     // centre on joint 0, mm (*1000) and back to metres (/1000) exactly as manopth + head_mano.py:85-86
     auto fin = [](float v, float c) { return ((v - c) * 1000.f) / 1000.f; };
@@ -153,8 +162,11 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
             float blend[3], wv[16], o[3];
             for (int c = 0; c < 3; ++c) {
                 float s = 0.f;
-                const float* pd = a.t.posedirs_t + v * 3 + c;          // [k][v*3+c]
-                for (int k = 0; k < 135; ++k) s += pd[(long long)k * NV * 3] * pmT[k][h];
+                // the tip columns from their own compact table when the caller supplies it (neighbouring lanes then read neighbouring
+                // words of one 120-byte row instead of 30 different cache lines of the full table); same values, same order
+                const float* pd = a.t.tip_posedirs_t ? a.t.tip_posedirs_t + tip * 3 + c : a.t.posedirs_t + v * 3 + c;
+                const long long ld = a.t.tip_posedirs_t ? 30 : (long long)NV * 3;
+                for (int k = 0; k < 135; ++k) s = fmaf(pd[k * ld], pmT[k][h], s);
                 blend[c] = s;
             }
             for (int j = 0; j < 16; ++j) wv[j] = a.t.weights[v * 16 + j];
@@ -180,16 +192,40 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
         const int v = (blockIdx.y * 4 + (tid >> 6)) * 64 + (tid & 63);
         if (v < NV) {
             float acc[HB][3];
-#pragma unroll
-            for (int h = 0; h < HB; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.f;
             const float* pd = a.t.posedirs_t + v * 3;
-#pragma unroll 3
-            for (int k = 0; k < 135; ++k) {
-                const float p0 = pd[(long long)k * NV * 3], p1 = pd[(long long)k * NV * 3 + 1], p2 = pd[(long long)k * NV * 3 + 2];
+            if constexpr (HB % 2 == 0) {
+                // hands in pairs: one packed FMA advances coordinate c of two hands (their pose-map entries are neighbours in pmT)
+                f32x2 ap[HB / 2][3];
 #pragma unroll
-                for (int h = 0; h < HB; ++h) {
-                    const float m = pmT[k][h];
-                    acc[h][0] += p0 * m; acc[h][1] += p1 * m; acc[h][2] += p2 * m;
+                for (int h = 0; h < HB / 2; ++h) ap[h][0] = ap[h][1] = ap[h][2] = f32x2{0.f, 0.f};
+#pragma unroll 3
+                for (int k = 0; k < 135; ++k) {
+                    const float p0 = pd[(long long)k * NV * 3], p1 = pd[(long long)k * NV * 3 + 1], p2 = pd[(long long)k * NV * 3 + 2];
+                    const f32x2 q0 = {p0, p0}, q1 = {p1, p1}, q2 = {p2, p2};
+                    const f32x2* m2 = reinterpret_cast<const f32x2*>(pmT[k]);
+#pragma unroll
+                    for (int h = 0; h < HB / 2; ++h) {
+                        const f32x2 m = m2[h];
+                        ap[h][0] = __builtin_elementwise_fma(q0, m, ap[h][0]);
+                        ap[h][1] = __builtin_elementwise_fma(q1, m, ap[h][1]);
+                        ap[h][2] = __builtin_elementwise_fma(q2, m, ap[h][2]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[h][c] = ap[h / 2][c][h & 1];
+            } else {
+#pragma unroll
+                for (int h = 0; h < HB; ++h) acc[h][0] = acc[h][1] = acc[h][2] = 0.f;
+#pragma unroll 3
+                for (int k = 0; k < 135; ++k) {
+                    const float p0 = pd[(long long)k * NV * 3], p1 = pd[(long long)k * NV * 3 + 1], p2 = pd[(long long)k * NV * 3 + 2];
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) {
+                        const float m = pmT[k][h];
+                        acc[h][0] = fmaf(p0, m, acc[h][0]); acc[h][1] = fmaf(p1, m, acc[h][1]); acc[h][2] = fmaf(p2, m, acc[h][2]);
+                    }
                 }
             }
             float wv[16];

@@ -124,6 +124,10 @@ class Engine:
         # opt-in split-bf16 convolution products (default: fp32 MFMA); see ops.conv_split
         self.conv_terms = {'f32': 0, 'bf16x6': 6, 'bf16x9': 9}[os.environ.get('VPHO_CONV_MFMA', 'f32')]
         self.serial_samplers = False            # True: object sampler after the hand sampler on one stream (exclusive kernel timings)
+        # VPHO_DEVICE_PRIOR=1: draw the sampler's prior with torch's DEVICE generator (Philox) instead of the CPU default generator.
+        # NOT the default: the order of draws from the CPU generator is part of the reference's RNG contract (sde.py:26-28: hand
+        # (bs*S, 96) first, then object (bs*S, 9)); behind the switch a seeded run is reproducible but is a different random stream
+        self.device_prior = os.environ.get('VPHO_DEVICE_PRIOR', '0') == '1'
         # True: last_info['agg'] also keeps the candidates every cascade level scored (4 copies of (bs, 2S, 48)); what the fp64 referee
         # of the selection chain is given (tests / bench parity block)
         self.keep_states = False
@@ -314,6 +318,8 @@ class Engine:
         step's asynchronous upload is never overwritten).  The sigma(T0) factor is applied on the device after the upload:
         the same fp32 product, but no multi-threaded CPU region on the launch thread (OpenMP workers spin after one and
         eat the host's CPU quota)."""
+        if self.device_prior:
+            return torch.randn((rows, dim), device=self.dev)
         key = (rows, dim)
         slot = self._pin.setdefault(key, dict(bufs=[torch.empty((rows, dim), pin_memory=True) for _ in range(2)], i=0))
         slot['i'] ^= 1

@@ -505,7 +505,7 @@ def append_betas(betas, out, rows_per_image):
 
 # ----------------------------------------------------------------------------------------------- MANO
 class ManoTables(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ('v_template', 'shapedirs', 'posedirs_t', 'J_regressor', 'weights')]
+    _fields_ = [(k, C.c_void_p) for k in ('v_template', 'shapedirs', 'posedirs_t', 'J_regressor', 'weights', 'tip_posedirs_t')]
 
 
 class Mano:
@@ -514,6 +514,9 @@ class Mano:
         self.tensors = dict(v_template=t(mano['v_template']), shapedirs=t(mano['shapedirs']),
                             posedirs_t=t(mano['posedirs']).reshape(778 * 3, 135).t().contiguous(),
                             J_regressor=t(mano['J_regressor']), weights=t(mano['weights']))
+        tips = [745, 317, 444, 556, 673, 728, 353, 442, 576, 694]                   # manopth tips, then the HO3D ones (csrc/mano.hip)
+        cols = torch.tensor([3 * v + c for v in tips for c in range(3)], device=device)
+        self.tensors['tip_posedirs_t'] = self.tensors['posedirs_t'][:, cols].contiguous()     # (135, 30)
         self.c = ManoTables()
         for k, v in self.tensors.items():
             setattr(self.c, k, v.data_ptr())
