@@ -73,7 +73,8 @@ def test_predict_edge_case_matches_oracle(model_cpu, sd, model_contrast_cpu, sd_
             assert np.array_equal(got[~tied], ref_idx[~tied]), (name, lvl)
             gv = ga['hand_val'][lvl].cpu()
             gv = (gv[:, 0] if lvl == 0 else gv.permute(0, 2, 1)).numpy()
-            assert np.abs(gv - ref_val).max() < 5e-6 * max(1.0, np.abs(ref_val).max()), (name, lvl)      # fp32 sums of ~20 looked-up values: a few ulp
+            # fp32 noise of a level score (oracle/referee.py measures it: ~3e-6 of the sum at level 0, ~1e-5 where FK rounding enters)
+            assert np.abs(gv - ref_val).max() < 2e-5 + 3e-6 * np.abs(ref_val).max(), (name, lvl)
         for k in ('transl_topk', 'rot_topk', 'phys_topk', 'heat_topk'):
             assert np.array_equal(ga[k].cpu().view(bs, -1).numpy(), ra[k].numpy()), (name, k)
         for k in ('agg_obj_6d', 'agg_hand_mano', 'agg_hand_vert', 'agg_hand_joint'):
