@@ -383,10 +383,11 @@ int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int
  * gt_vert / gt_joint / gt_rot6d (= mano_aa_to_6D(gt pose)[:96]) / gt_shape (right hands only, is_right [bs]) and the gradient of
  * w_vert*vert_loss + w_joint*joint_loss + w_pose*mano_pose_loss + w_shape*mano_shape_loss w.r.t. rot6d and shape.
  * loss_parts [bs][4]: per-hand sums of squared differences (vert, joint, pose, shape) in fp64 -- the caller applies
- * weight / (bs * 2334 | bs * 63 | bs * 96 | bs * 10).  Hands flagged is_ho3d (joint re-alignment, VPHO.py:150-153) are not supported.
+ * weight / (bs * 2334 | bs * 63 | bs * 96 | bs * 10).  is_ho3d (per hand, optional): the regressed joints of those hands enter the joint
+ * loss in HO3D's convention (get_joint_aligned_with_HO3D, VPHO.py:154-157, hand_fn.py:454-461: joints re-ordered, HO3D's own tip vertices).
  * A batch without any right hand gives a shape loss of 0 here (the reference takes the mean of an empty tensor: NaN). */
 int vpho_mano_train_f32(const vpho_mano_tables* t, const float* rot6d, const float* shape, const float* gt_vert, const float* gt_joint,
-                        const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, int bs,
+                        const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, const unsigned char* is_ho3d, int bs,
                         float w_vert, float w_joint, float w_pose, float w_shape,
                         float* d_rot6d, float* d_shape, double* loss_parts, float* verts, float* joints, void* stream);
 /* JointsMSELoss (lib/model/head_inplane.py:191-203: nn.MSELoss, mean over all elements) times its loss weight

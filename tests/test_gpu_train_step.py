@@ -135,9 +135,11 @@ def test_trainer_full_scope_runs_and_writes_back():
     assert all(np.isfinite(list(h.values())).all() for h in hist) and set(hist[0]) >= {'total_loss', 'diff_hand_loss', 'hm_obj_loss', 'vert_loss', 'mano_shape_loss', 'torque_loss', 'CoM_loss'}
 
 
-def test_mano_head_losses_and_gradients_match_oracle_autograd():
+@pytest.mark.parametrize('ho3d', [None, [True, False, True, False, True]])
+def test_mano_head_losses_and_gradients_match_oracle_autograd(ho3d):
     """vpho_mano_train_f32 (Gram-Schmidt -> MANO -> four losses -> analytic backward) vs fp64 autograd through the oracle's
-    restatement of the reference's chain rot6d -> matrix -> axis-angle -> manopth layer (head_mano.py:60-133)."""
+    restatement of the reference's chain rot6d -> matrix -> axis-angle -> manopth layer (head_mano.py:60-133); with HO3D hands the
+    regressed joints are re-aligned to HO3D's convention before the joint loss (VPHO.py:154-157, hand_fn.py:454-461)."""
     from oracle import mano as OM, rotations as OR
     from vpho_amd import ops
     from vpho_amd.assets import synthetic_assets
@@ -153,13 +155,18 @@ def test_mano_head_losses_and_gradients_match_oracle_autograd():
     Rm = OR.rotation_6d_to_matrix(d6)
     aa = OR.matrix_to_axis_angle(Rm).reshape(bs, 48)
     v, j = OM.get_hand_verts(mano, aa, beta)
+    if ho3d is not None:
+        from oracle.vpho import joints_ho3d
+        hm = torch.tensor(ho3d)
+        j = torch.where(hm[:, None, None], joints_ho3d(v, j), j)
     pd6 = OR.matrix_to_rotation_6d(OR.axis_angle_to_matrix(aa.reshape(bs, 16, 3))).reshape(bs, 96)
     L = dict(vert_loss=W[0] * ((v - gt_v) ** 2).mean(), joint_loss=W[1] * ((j - gt_j) ** 2).mean(), mano_pose_loss=W[2] * ((pd6 - gt6) ** 2).mean(),
              mano_shape_loss=W[3] * ((beta[right] - gtb[right]) ** 2).mean() / bs * int(right.sum()))
     g6, gb = torch.autograd.grad(sum(L.values()), [d6, beta])
     M = ops.Mano(mano, 'cuda')
     c = lambda t: t.float().contiguous().cuda()
-    Lk, k6, kb, kv, kj = M.train(c(d6.detach().reshape(bs, 96)), c(beta.detach()), c(gt_v), c(gt_j), c(gt6), c(gtb), right.to(torch.uint8).cuda(), W, want_outputs=True)
+    Lk, k6, kb, kv, kj = M.train(c(d6.detach().reshape(bs, 96)), c(beta.detach()), c(gt_v), c(gt_j), c(gt6), c(gtb), right.to(torch.uint8).cuda(), W, want_outputs=True,
+                                 is_ho3d=None if ho3d is None else torch.tensor(ho3d).to(torch.uint8).cuda())
     for k in L:
         assert abs(float(Lk[k]) - float(L[k].detach())) <= 2e-5 * abs(float(L[k].detach())), (k, float(Lk[k]), float(L[k].detach()))
     np.testing.assert_allclose(kv.cpu().numpy(), v.detach().numpy(), atol=2e-6)

@@ -17,6 +17,10 @@ namespace {
 
 __constant__ int t_parent[16] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
 __constant__ int t_tips[5] = {745, 317, 444, 556, 673};
+// HO3D joint convention (hand_fn.py:454-461, applied to the regressed joints of HO3D images at VPHO.py:154-157 before the losses):
+// the 21 manopth joints re-ordered by MANOPTH_TO_MANOLAYER, then the five tips replaced by HO3D's own tip vertices
+__constant__ int t_tips_ho3d[5] = {728, 353, 442, 576, 694};
+__constant__ int t_to_manolayer[21] = {0, 5, 6, 7, 9, 10, 11, 17, 18, 19, 13, 14, 15, 1, 2, 3, 4, 8, 12, 16, 20};
 __constant__ int t_order[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
 constexpr int NV = 778, NE = NV * 3;
 
@@ -24,6 +28,7 @@ struct ManoTrainArgs {
     vpho_mano_tables t;
     const float *rot6d, *shape, *gt_vert, *gt_joint, *gt_rot6d, *gt_shape;
     const unsigned char* is_right;
+    const unsigned char* is_ho3d;             // per hand or NULL
     int bs;
     float cv, cj, cp, cs;                     // 2 * weight / element count of each mean
     float *d_rot6d, *d_shape, *verts, *joints;
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(256) void mano_train_kernel(const ManoTrainArgs a) 
     __shared__ float red[4 * 12];
     __shared__ double lsum[4][4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool ho3d = a.is_ho3d && a.is_ho3d[b];
     const vpho_mano_tables& t = a.t;
 
     // ---- 0. rotation_6d_to_matrix (rows b1, b2, b3), intermediates kept for the backward
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void mano_train_kernel(const ManoTrainArgs a) 
         const float* x0 = vp + v * 3;
         float x[3];
         for (int r = 0; r < 3; ++r) x[r] = T[r * 4] * x0[0] + T[r * 4 + 1] * x0[1] + T[r * 4 + 2] * x0[2] + T[r * 4 + 3];
-        for (int q = 0; q < 5; ++q) if (v == t_tips[q]) { xt[q][0] = x[0]; xt[q][1] = x[1]; xt[q][2] = x[2]; }
+        for (int q = 0; q < 5; ++q) if (v == (ho3d ? t_tips_ho3d[q] : t_tips[q])) { xt[q][0] = x[0]; xt[q][1] = x[1]; xt[q][2] = x[2]; }
         for (int r = 0; r < 3; ++r) {
             const float pd = x[r] - cen[r];
             if (a.verts) a.verts[((long long)b * NV + v) * 3 + r] = pd;
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256) void mano_train_kernel(const ManoTrainArgs a) 
         float dc[3] = {-dsum[0], -dsum[1], -dsum[2]};                 // centre = joint 0, subtracted from every vertex and joint
         for (int j = 0; j < 16; ++j) for (int e = 0; e < 12; ++e) dG[j][e] = 0.f;
         for (int i = 0; i < 21; ++i) {
-            const int m = t_order[i];
+            // output joint i: manopth order, or HO3D's (joints 0-15 re-ordered, 16-20 = HO3D's own tip vertices, captured in xt)
+            const int m = !ho3d ? t_order[i] : (i < 16 ? t_order[t_to_manolayer[i]] : i);
             for (int r = 0; r < 3; ++r) {
                 const float raw = m < 16 ? G[m][r * 4 + 3] : xt[m - 16][r];
                 const float pd = raw - cen[r];
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void mano_train_kernel(const ManoTrainArgs a) 
                 const float diff = pd - a.gt_joint[((long long)b * 21 + i) * 3 + r];
                 lj += (double)diff * (double)diff;
                 const float g = a.cj * diff;
-                if (m < 16) dG[m][r * 4 + 3] += g; else dv[t_tips[m - 16] * 3 + r] += g;
+                if (m < 16) dG[m][r * 4 + 3] += g; else dv[(ho3d ? t_tips_ho3d[m - 16] : t_tips[m - 16]) * 3 + r] += g;
                 dc[r] -= g;
             }
         }
@@ -316,14 +323,14 @@ __global__ __launch_bounds__(256) void mano_train_kernel(const ManoTrainArgs a) 
 }  // namespace
 
 extern "C" int vpho_mano_train_f32(const vpho_mano_tables* t, const float* rot6d, const float* shape, const float* gt_vert, const float* gt_joint,
-                                   const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, int bs,
+                                   const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, const unsigned char* is_ho3d, int bs,
                                    float w_vert, float w_joint, float w_pose, float w_shape,
                                    float* d_rot6d, float* d_shape, double* loss_parts, float* verts, float* joints, void* stream) {
     VPHO_REQUIRE(t && rot6d && shape && gt_vert && gt_joint && gt_rot6d && gt_shape && is_right && d_rot6d && d_shape && loss_parts && bs > 0,
                  "vpho_mano_train_f32: bad argument");
     ManoTrainArgs a;
     a.t = *t; a.rot6d = rot6d; a.shape = shape; a.gt_vert = gt_vert; a.gt_joint = gt_joint; a.gt_rot6d = gt_rot6d; a.gt_shape = gt_shape;
-    a.is_right = is_right; a.bs = bs;
+    a.is_right = is_right; a.is_ho3d = is_ho3d; a.bs = bs;
     a.cv = 2.f * w_vert / ((float)bs * NE); a.cj = 2.f * w_joint / ((float)bs * 63.f); a.cp = 2.f * w_pose / ((float)bs * 96.f);
     a.cs = 2.f * w_shape / ((float)bs * 10.f);
     a.d_rot6d = d_rot6d; a.d_shape = d_shape; a.verts = verts; a.joints = joints; a.loss_parts = loss_parts;

@@ -527,7 +527,7 @@ class Mano:
         _call('vpho_mano_shape_f32', C.byref(self.c), _f32(betas), I(n), _f32(vs), _f32(J))
         return vs, J
 
-    def train(self, rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, want_outputs=False):
+    def train(self, rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, want_outputs=False, is_ho3d=None):
         """HeadMano tail in training mode (vpho_mano_train_f32): -> losses dict (0-d fp64 tensors, weighted), d_rot6d (bs,96),
         d_shape (bs,10)[, verts, joints]; weights = (vert, joint, mano_pose, mano_shape)"""
         bs = rot6d.shape[0]
@@ -536,7 +536,7 @@ class Mano:
         verts = _new((bs, 778, 3), rot6d) if want_outputs else None
         joints = _new((bs, 21, 3), rot6d) if want_outputs else None
         _call('vpho_mano_train_f32', C.byref(self.c), _f32(rot6d), _f32(shape), _f32(gt_vert), _f32(gt_joint), _f32(gt_rot6d), _f32(gt_shape),
-              _u8(is_right), I(bs), F(weights[0]), F(weights[1]), F(weights[2]), F(weights[3]), _f32(d6), _f32(ds), _f64(parts),
+              _u8(is_right), _u8(is_ho3d), I(bs), F(weights[0]), F(weights[1]), F(weights[2]), F(weights[3]), _f32(d6), _f32(ds), _f64(parts),
               _f32(verts), _f32(joints))
         tot = parts.sum(0)
         L = dict(vert_loss=tot[0] * (weights[0] / (bs * 2334.0)), joint_loss=tot[1] * (weights[1] / (bs * 63.0)),

@@ -381,7 +381,7 @@ class HeadManoTrain:
         self._pad = torch.zeros((2, self.p['fc_pose.weight'].shape[1]), device=device)
         self.last_outputs = None                         # (verts, joints) of the last forward (pd_dt of VPHO.py:221-222)
 
-    def forward_backward(self, x, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights):
+    def forward_backward(self, x, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, is_ho3d=None):
         """x (bs,1024) encoding.  -> losses dict (weighted, 0-d fp64), d loss / d x (bs,1024), grads"""
         import torch
         from .train_score import _wgrad
@@ -392,7 +392,7 @@ class HeadManoTrain:
         bcat = torch.cat([P['fc_pose.bias'], P['fc_shape.bias'], self._pad[:, 0]], 0).contiguous()
         out = ops.linear(h2, wcat, bcat)
         rot6d, shape = out[:, :96].contiguous(), out[:, 96:106].contiguous()
-        L, d6, ds, v_, j_ = self.mano.train(rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, want_outputs=True)
+        L, d6, ds, v_, j_ = self.mano.train(rot6d, shape, gt_vert, gt_joint, gt_rot6d, gt_shape, is_right, weights, want_outputs=True, is_ho3d=is_ho3d)
         self.last_outputs = (v_, j_)
         dout = torch.cat([d6, ds, torch.zeros_like(d6[:, :2])], 1).contiguous()                               # (bs, 108)
         G = {}

@@ -184,10 +184,12 @@ class DiffusionTrainStep:
             if self.mano_head is not None and 'gt_hand_vert_flip' in data:
                 # head_mano -> MANO -> vert / joint / mano_pose / mano_shape losses (VPHO.py:147-148,197-204); gt_hand is
                 # mano_aa_to_6D(gt_mano)[..., :96], the shape ground truth are the last 10 entries of gt_mano
-                assert not bool(data['is_ho3d'].any()) if 'is_ho3d' in data else True, 'HO3D joint re-alignment is not part of this step'
+                # HO3D images: the regressed joints enter the joint loss in HO3D's convention (get_joint_aligned_with_HO3D, VPHO.py:154-157)
+                ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
                 Lm, d_enc_mano, gm = self.mano_head.forward_backward(
                     enc_h, f32(data['gt_hand_vert_flip']), f32(data['gt_hand_jt3d_flip']), f32(gt_hand), f32(data['gt_mano'][:, 48:]),
-                    data['is_right'].to(torch.uint8).contiguous(), (self.w['vert'], self.w['joint'], self.w['mano_pose'], self.w['mano_shape']))
+                    data['is_right'].to(torch.uint8).contiguous(), (self.w['vert'], self.w['joint'], self.w['mano_pose'], self.w['mano_shape']),
+                    is_ho3d=ho3d)
                 L.update(Lm)
             # physics branch (VPHO.py:164-172,205-212): cross modules on the encoders' second stage maps (8x8), head_physics, 5 losses
             d_stage = dict(h=None, o=None)
