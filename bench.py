@@ -26,6 +26,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 FEATURE_GFLOP_PER_IMAGE = 37.09
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_LIMITS = {'mano_fk': 'vector ALU, not HBM: pose blend [hands x 135] x [135 x 2334] + 16-joint transform blend per vertex as packed fp32 FMAs (6 GFLOP per 6400-hand launch); the table streams from L2',
+              'obj_physics': 'vector ALU: 65 536 squared distances per candidate from an LDS-resident point cloud',
+              'hand_fuse': 'latency: one workgroup per (image, finger) -- ranking by counting, 30 quaternions, a 4x4 Jacobi eigen-solve',
+              'roi_align': 'HBM / L2 gather: window rows read once, pooled output written once',
+              'resize_bilinear': 'HBM: read-modify-write of the finer map (top-down add of the FPN)'}
 HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk_kernel', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
                     'roi_align': 'roi_align_nhwc_kernel', 'resize_bilinear': 'resize_bilinear_nhwc_kernel'}
 
@@ -300,7 +305,7 @@ def main():
                                     'launches_per_step': prof[k]['launches'] / max(args.steps, 1),
                                     'kernel_ms_per_step': prof[k]['total_ms'] / max(args.steps, 1),
                                     'algorithmic_bytes_per_launch': prof[k]['bytes'] / max(prof[k]['launches'], 1),
-                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k])} for k in hbm_classes}},
+                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k]), 'limited_by': HBM_LIMITS[k]} for k in hbm_classes}},
             'metrics_rows_gathered': int(all_rows.shape[0]),
             'host_cpu': host_cpu,
         }

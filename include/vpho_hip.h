@@ -190,7 +190,7 @@ int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, int N, int 
 int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW, float* y, int ldy, int c_off,
                                        int accumulate, const int* row_map, const int* row_count, int rows_hint, void* stream);
 int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
-                                   float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
+                                   float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, int rows_hint,
                                    void* stream);
 /* align_hm_to_bbox_rectangle (VPHO.py:333-346, transposing, quirk Q2) (+ optional W flip, VPHO.py:139) */
 int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,

@@ -623,10 +623,12 @@ extern "C" int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, 
 
 extern "C" int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
                                               float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
-                                              void* stream) {
+                                              int rows_hint, void* stream) {
     VPHO_REQUIRE(feat_rows && wins && boxes && out && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0, "vpho_roi_align_window_nhwc_f32: bad argument");
-    // algorithmic bytes: upper bound as for the full map (the window sizes are device data)
-    vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * N * C * ((double)H * W + (double)out_size * out_size));
+    // algorithmic bytes: the window rows the kernel can touch (device data: the caller's hint in profiling passes; without it the
+    // whole map as an upper bound) read once + the pooled output written once
+    const double rows_read = rows_hint > 0 ? (double)rows_hint : (double)N * H * W;
+    vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * C * (rows_read + (double)N * out_size * out_size));
     if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)feat_rows | (uintptr_t)out) % 16 == 0)
         LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins);
     else

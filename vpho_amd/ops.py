@@ -437,7 +437,7 @@ def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, 
         if out is None:
             out = _new((N, out_size, out_size, Cc), feat)
         _call('vpho_roi_align_window_nhwc_f32', _f32(feat), _ptr(win.wins, torch.int32), I(N), I(H), I(W), I(Cc), _f32(boxes),
-              F(spatial_scale), I(out_size), _u8(flip_w), _f32(out), I(out.shape[-1]), I(c_off))
+              F(spatial_scale), I(out_size), _u8(flip_w), _f32(out), I(out.shape[-1]), I(c_off), I(int(win.count.item()) if _prof_on else 0))
         return out
     N, H, W, Cc = feat.shape
     if out is None:
