@@ -294,6 +294,19 @@ def main():
                                         'samplers_serialised': {'achieved': head_excl_tf, 'frac': head_excl_tf / head_peak,
                                                                 'avg_launch_us': head_excl['total_ms'] * 1e3 / max(head_excl['launches'], 1),
                                                                 'what': 'same kernels, object solve after the hand solve: exclusive durations (hand 32 heads + object 3 heads, averaged over launches by time)'}},
+                         # the convolutions of the step as ONE family, in ALGORITHMIC flops (2 x pixels x Cout x taps x Cin of the direct form,
+                         # whatever algorithm ran): the three direct tile classes + the Winograd launches, whose 2.25 x fewer multiply-adds
+                         # make their algorithmic rate exceed the executed one
+                         'conv_family_algorithmic': (lambda fam, ms: {
+                             'achieved': fam / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, 'frac': (fam / (ms * 1e-3) / 1e12 / conv_peak) if ms > 0 else 0.0,
+                             'kernel_ms_per_step': ms / max(args.steps, 1), 'unit': 'TFLOP/s',
+                             'what': 'direct-form flops of every convolution launch / summed kernel time: conv_igemm 128x128 + 128x64 + 64x64 (executed = algorithmic) '
+                                     '+ conv_winograd (algorithmic = 2.25 x executed)'})(
+                             sum(prof[k]['flops'] for k in ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64')) + 2.25 * prof['conv_winograd']['flops'],
+                             sum(prof[k]['total_ms'] for k in ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'conv_winograd'))),
+                         'note': 'kernel = the direct-convolution tile class with the most kernel time.  Since round 3 its most efficient layers (the 3x3 / stride-1 '
+                                 'convolutions, 113-135 TFLOP/s) run as conv_winograd launches instead, so the class average is lower than in round 2 although no '
+                                 'launch got slower; by summed exclusive time the score head (score_head below, samplers_serialised) is the largest single kernel of the step',
                          'feature_path_gflop_per_image_ref': FEATURE_GFLOP_PER_IMAGE},
             # HBM-bound kernels of the path (north star: MANO skinning, distance kernels, top-k as GB/s against the chip's HBM peak):
             # achieved = ALGORITHMIC bytes (operands read once + results written once, stated at the launch site) / HIP-event kernel time
