@@ -18,7 +18,8 @@ def main():
     import torch.distributed as dist
     world, rank, local = world_from_env(args.gpus)
     if world > 1:
-        dist.init_process_group('gloo')
+        from vpho_amd.launch import init_process_group
+        init_process_group(None)                          # no device: gloo; loud on failure
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)

@@ -61,3 +61,36 @@ def test_entry_points_spawn_before_touching_the_gpu():
         body = src[src.index('def main'):]
         assert 'maybe_spawn(args.gpus)' in body, f
         assert body.index('maybe_spawn(args.gpus)') < body.index('import torch'), f
+
+
+def test_accelerate_launch_starts_the_ranks_like_the_reference_does():
+    """The reference is started with `accelerate launch --config_file lib/configs/ddp01.yaml main.py ...` (README.md:61-72).  accelerate
+    exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like torch.distributed.run; an entry point started that way must NOT spawn again
+    and must form the process group from that environment (CPU / gloo here; `accelerate` is installed in the build container)."""
+    pytest.importorskip('accelerate')
+    port = launch.free_port()
+    cmd = [sys.executable, '-m', 'accelerate.commands.launch', '--cpu', '--multi_gpu', '--num_processes', '2', '--num_machines', '1',
+           '--mixed_precision', 'no', '--dynamo_backend', 'no', '--main_process_ip', '127.0.0.1', '--main_process_port', str(port),
+           os.path.join(HERE, '_launch_probe.py'), '--gpus', '2', '--tag', 'acc']
+    r = subprocess.run(cmd, env=_bare_env(), capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and '--multi_gpu' in r.stderr:                     # accelerate versions differ on how a CPU multi-process job is spelt
+        cmd.remove('--multi_gpu')
+        r = subprocess.run(cmd, env=_bare_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['sum'] == 3.0 and out['tag'] == 'acc'
+
+
+def test_process_group_failure_is_loud_and_quick():
+    """a rank whose peers never arrive: SystemExit naming rank / world / backend / rendezvous address after the bounded timeout,
+    not torch's 10-30 minutes of silence"""
+    env = _bare_env()
+    env.update(WORLD_SIZE='2', RANK='1', LOCAL_RANK='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(launch.free_port()), VPHO_DIST_TIMEOUT_S='5')
+    code = 'import sys; sys.path.insert(0, %r); from vpho_amd.launch import init_process_group; init_process_group(None)' % ROOT
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert 'process-group initialisation FAILED' in r.stderr and 'rank 1/2' in r.stderr and 'backend gloo' in r.stderr, r.stderr[-1500:]
