@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
         const bool in = tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         poff[p] = in ? (int)((((long long)(pn * a.H + iy) * a.W + ix) * a.x_ld + 4 * cp) * 4) : -1;
+        if ((WINO_ABLATE & 128) && p > 0) poff[p] = poff[0];          // every patch load hits the same line: instruction count kept, line requests / 16
+        if ((WINO_ABLATE & 256)) poff[p] = (int)(((long long)(tl * 16 + p) * 4 + cp) * 16);   // dense, conflict-free addresses: 64 lanes x 16 B contiguous
     }
     // A load is 16 bytes = 4 channels of a 16-channel SUPER-STAGE (half the vector-memory instructions of 8-byte loads, and a wave
     // instruction asks for 64 contiguous bytes of a pixel instead of 32).  A k stage takes one channel PAIR of every lane: stage e
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // One wave per SIMD: nothing hides a latency unless the instruction stream does.  A stage is 16 frequency groups of 4 MFMAs (64
     // cycles each); the A / B fragments of a group are requested two groups ahead (register double buffer), and the next stage's work
     // rides in the groups' shadows, ONE memory instruction per MFMA (a burst of vector-memory instructions stalls the wave's issue --
-    // and with it the matrix pipe -- for longer than the MFMAs in flight last): in the EVEN stage of a super-stage the 16 patch loads
-    // of the next super-stage (groups 0-3), in both the 8 U fills (groups 4-5), the row transform (group 11) and one frequency row
+    // and with it the matrix pipe -- for longer than the MFMAs in flight last): in both stages the 8 U fills (groups 0-1), in the EVEN
+    // stage of a super-stage the 16 patch loads of the next super-stage (groups 2-5), the row transform (group 11) and one frequency row
     // of the column transform + its 4 LDS writes (groups 12-15).  Branch-free -- the last stages prefetch the last super-stage once
     // more into registers / the idle buffer -- so that the loop body is ONE basic block the scheduler can interleave.
     auto stage = [&](int kc, int e, int ssn) {
@@ -209,8 +211,11 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
                 av[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(V + (f + 1) * 64 * WK);
                 bv[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(U + (f + 1) * 64 * WK);
             }
-            if (e == 0 && f < 4) load_patch(pnx, ssn, 4 * f, 4 * f + 4);
-            if (f == 4 || f == 5) fill_u(buf ^ 1, kn, 4 * (f - 4), 4 * (f - 4) + 4);
+            // the U fills FIRST, then the patch loads: vector-memory operations complete in order, so the end-of-stage wait can let the 16
+            // patch loads stay in flight (vmcnt(16)) and still know the fills have landed -- the patch has until the row transform of the
+            // NEXT stage to arrive (with vmcnt(0) here it had to beat the barrier of its own stage: 12 % of the kernel's time)
+            if (f < 2) fill_u(buf ^ 1, kn, 4 * f, 4 * f + 4);
+            if (e == 0 && f >= 2 && f < 6) load_patch(pnx, ssn, 4 * (f - 2), 4 * (f - 2) + 4);
             if (f == 11) { if (e == 0) row_transform(pc, 1); else row_transform(pnx, 0); }
             if (f >= 12) store_v_row(buf ^ 1, f - 12);
 #pragma unroll
@@ -226,7 +231,10 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(WINO_ABLATE & 8)) VPHO_SYNC_LDS_DMA();
+        if (!(WINO_ABLATE & 8)) {
+            if (e == 0 && !(WINO_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
+            else VPHO_SYNC_LDS_DMA();
+        }
     };
     for (int ss = 0; ss < nss; ++ss) {
         const int ssn = ss + 1 < nss ? ss + 1 : ss;
