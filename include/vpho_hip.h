@@ -93,6 +93,14 @@ int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* 
  * dilated by one pixel need to hold data.  Device-side lists: the grid is sized for all tiles, blocks past the last live tile exit
  * (no host round trip, replays in a HIP graph with new boxes).  tiles_hint (0 = unknown) only feeds the profiling counters. */
 int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
+/* Training (weights change every step): u on the DEVICE from the packed 3x3 weights (Cout, 9*Cin) -- for the forward convolution
+ * (for_input_gradient = 0: u is (Cin/8, 16, Cout, 8)) or for its input-gradient convolution, the 3x3 convolution of dY with the
+ * spatially flipped, channel-transposed weights (1: u is (Cout/8, 16, Cin, 8)); fp64 arithmetic, rounded once.  The gate variant
+ * of the convolution fuses the backward of the LeakyReLU that produced the convolution's input (torch autograd of nn.LeakyReLU in
+ * Bottleneck / Residual, backbone_FPN_HFL.py:326, encoding.py:21-36): y = gate > 0 ? y : gate_slope * y, gate laid out like y. */
+int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream);
+int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
+                                        int x_ld, int Cout, float* y, int y_ld, void* stream);
 int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                         float out_slope, const int* wins, const int* tile_base, int tiles_hint, float* y_rows, int y_ld,
                                         void* stream);

@@ -297,3 +297,43 @@ def test_align_heatmap_backward_matches_oracle_autograd():
     (y * dy).sum().backward()
     d = ops.align_heatmap_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), bbox.cuda(), rect.cuda(), flip.to(torch.uint8).cuda())
     np.testing.assert_allclose(d.permute(0, 3, 1, 2).cpu().numpy(), hm.grad.numpy(), atol=2e-5 * float(hm.grad.abs().max()), rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,H,W,cin,cout', [(4, 16, 16, 64, 128), (3, 8, 12, 128, 64)])
+def test_training_winograd_forward_and_input_gradient(N, H, W, cin, cout):
+    """Training path of the 3x3 / stride-1 convolutions (weights change every step): u = G g G^T made on the DEVICE
+    (vpho_winograd_weights_f32) equals the host transform of pack.winograd_weights, for the forward convolution and -- on the flipped,
+    channel-transposed weights -- for its input gradient; the Winograd input gradient with the fused LeakyReLU backward (gate) equals
+    torch autograd of conv2d(leaky_relu(x)) to fp32 rounding."""
+    import torch.nn.functional as F
+    from vpho_amd import ops, conv_backward as CB
+    from vpho_amd.model.pack import pack_conv, winograd_weights
+    g = torch.Generator().manual_seed(N * H + cin)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+    wp = pack_conv(w).cuda()
+    u_dev, u_host = ops.winograd_weights_device(wp), winograd_weights(wp)
+    assert u_dev.shape == u_host.shape and float((u_dev - u_host).abs().max()) <= 1e-7 * float(u_host.abs().max())
+    wt = CB._flip_transpose(wp, cout, cin, 3, 3).contiguous()                                  # (Cin, 9*Cout): the input-gradient convolution's weights
+    ut_dev, ut_host = ops.winograd_weights_device(wp, for_input_gradient=True), winograd_weights(wt)
+    assert ut_dev.shape == ut_host.shape and float((ut_dev - ut_host).abs().max()) <= 1e-7 * float(ut_host.abs().max())
+    # in-place weight update -> the cached transform follows the tensor's version
+    before = u_dev.clone()                                                                     # the transform is updated in place
+    wp.mul_(2.0)
+    assert torch.allclose(ops.winograd_weights_device(wp), 2 * before)
+    wp.mul_(0.5)
+    # forward + input gradient through LeakyReLU against autograd (fp64 reference)
+    x = torch.randn(N, cin, H, W, generator=g).double().requires_grad_(True)
+    a = F.leaky_relu(x, 0.01)
+    y = F.conv2d(a, w.double(), None, 1, 1)
+    dy = torch.randn(N, cout, H, W, generator=g).double()
+    dx, = torch.autograd.grad(y, x, dy)
+    a_g = a.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    y_g = ops.conv3x3_train(a_g, wp)
+    assert float((y_g.permute(0, 3, 1, 2).cpu().double() - y.detach()).abs().max()) < 2e-6 * float(y.detach().abs().max())
+    dy_g = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dx_g = CB.conv2d_dgrad(dy_g, wp, (H, W), 3, 3, 1, 1, gate=(a_g, 0.01))
+    assert float((dx_g.permute(0, 3, 1, 2).cpu().double() - dx).abs().max()) < 2e-6 * float(dx.abs().max())
+    da_g = CB.conv2d_dgrad(dy_g, wp, (H, W), 3, 3, 1, 1)                                       # no gate: gradient w.r.t. the convolution's input
+    a2 = a.detach().requires_grad_(True)
+    da, = torch.autograd.grad(F.conv2d(a2, w.double(), None, 1, 1), a2, dy)
+    assert float((da_g.permute(0, 3, 1, 2).cpu().double() - da).abs().max()) < 2e-6 * float(da.abs().max())

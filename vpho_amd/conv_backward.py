@@ -47,6 +47,10 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     N, OH, OW, cout = dy.shape
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
+    if kh == 3 and kw == 3 and stride == 1 and pad == 1 and pad_y is None and pad_x is None and res is None and (OH, OW) == (H, W) and dy.is_contiguous():
+        dx = ops.conv3x3_dgrad_winograd(dy, w_packed, gate)      # Winograd F(2x2,3x3) on the flipped / transposed weights where the shape allows
+        if dx is not None:
+            return dx
     if cout % 4:                                          # the GEMM kernel wants a reduction length that is a multiple of 4
         extra = 4 - cout % 4
         dy = torch.nn.functional.pad(dy, (0, extra)).contiguous()

@@ -32,6 +32,7 @@ struct WinoArgs {
     float out_slope;
     // RoI windows (vpho_roi_windows_i32): only the 2 x 2 tiles -- on the image's even grid, so a pixel is computed from the same 4 x 4
     // patch as in the full map: bit-identical -- that touch an image's window; y = the COMPACT (rows, Cout) matrix of the window pixels
+    const float* gate; float gate_slope;       // optional, laid out like y: y = gate > 0 ? y : gate_slope * y (LeakyReLU backward given its output)
     const int* wins;                           // [N][5] = (first row, y0, x0, w, h) or NULL
     const int* tile_base;                      // [N + 1] first tile of every image; [N] = live tiles (vpho_winograd_window_tiles_i32)
 };
@@ -264,8 +265,13 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             float* yp = a.y + (long long)s_row[trow] * a.y_ld + co;
             const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
             const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
+            const float* gp = a.gate ? a.gate + (long long)s_row[trow] * a.y_ld + co : nullptr;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) { const float v = o[p]; yp[offs[p]] = v > 0.f ? v : v * a.out_slope; }
+            for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
+                float v = o[p];
+                if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
+                yp[offs[p]] = v > 0.f ? v : v * a.out_slope;
+            }
         }
     }
 }
@@ -285,7 +291,38 @@ __global__ void wino_tile_base_kernel(const int* __restrict__ wins, int N, int* 
 }
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
-                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream);
+                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
+                       const float* gate = nullptr, float gate_slope = 1.f);
+
+// U = G g G^T on the DEVICE for weights that change every step (training): one thread per (output channel, input channel) pair of the
+// convolution the result is for.  mode 0: that convolution is the forward one (w packed as [Cout][(r*3+s)*Cin + ci]); mode 1: its
+// input-gradient convolution = a 3x3 convolution of dY with the spatially flipped, channel-transposed weights (Cin outputs, Cout
+// inputs).  Written straight into the stage-tiled layout of pack.winograd_weights (same slots, same channel order).
+__global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ u) {
+    const int OUT = mode ? Cin : Cout, IN = mode ? Cout : Cin;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)OUT * IN) return;
+    // forward: neighbouring threads = neighbouring ci (contiguous reads); transposed: neighbouring threads = neighbouring OUT = ci as well
+    const int o = mode ? (int)(i % OUT) : (int)(i / IN), c = mode ? (int)(i / OUT) : (int)(i % IN);
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            g[r][q] = mode ? (double)w[(long long)c * 9 * Cin + ((2 - r) * 3 + (2 - q)) * Cin + o] : (double)w[(long long)o * 9 * Cin + (r * 3 + q) * Cin + c];
+    double t[4][3];                                             // G g
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        t[0][q] = g[0][q]; t[1][q] = 0.5 * (g[0][q] + g[1][q] + g[2][q]); t[2][q] = 0.5 * (g[0][q] - g[1][q] + g[2][q]); t[3][q] = g[2][q];
+    }
+    const int kc = 2 * (c >> 4) + ((c & 3) >> 1), j = 2 * ((c & 15) >> 2) + (c & 1);
+#pragma unroll
+    for (int fy = 0; fy < 4; ++fy) {
+        const double v[4] = {t[fy][0], 0.5 * (t[fy][0] + t[fy][1] + t[fy][2]), 0.5 * (t[fy][0] - t[fy][1] + t[fy][2]), t[fy][2]};
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) u[(((long long)kc * 16 + fy * 4 + fx) * OUT + o) * 8 + j] = (float)v[fx];
+    }
+}
 
 extern "C" int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream) {
     VPHO_REQUIRE(wins && tile_base && N > 0, "vpho_winograd_window_tiles_i32: bad argument");
@@ -305,8 +342,23 @@ extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, co
     return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, nullptr, nullptr, 0, y, y_ld, stream);
 }
 
+extern "C" int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
+                                                   int x_ld, int Cout, float* y, int y_ld, void* stream) {
+    VPHO_REQUIRE(gate, "vpho_conv3x3_winograd_gate_nhwc_f32: bad argument");
+    return wino_launch(x, u, nullptr, N, H, W, Cin, x_ld, Cout, 1.f, nullptr, nullptr, 0, y, y_ld, stream, gate, gate_slope);
+}
+
+extern "C" int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream) {
+    VPHO_REQUIRE(w_packed && u && Cout > 0 && Cin > 0, "vpho_winograd_weights_f32: bad argument");
+    VPHO_REQUIRE((for_input_gradient ? Cout : Cin) % 16 == 0, "vpho_winograd_weights_f32: the convolution's input channels must be a multiple of 16");
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, Cout, Cin, for_input_gradient ? 1 : 0, u);
+    return vpho::check_launch("wino_weights_kernel");
+}
+
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
-                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream) {
+                       const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
+                       const float* gate, float gate_slope) {
     VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
     VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % (2 * WK) == 0 && Cout % W_CB == 0 && x_ld % 4 == 0 && x_ld >= Cin && y_ld >= Cout,
                  "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 16 == 0, Cout %% 64 == 0, x_ld %% 4 == 0");
@@ -315,7 +367,7 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
-    a.wins = wins; a.tile_base = tile_base;
+    a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {

@@ -215,6 +215,57 @@ def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None, rows=None):
     return out
 
 
+def winograd_weights_device(w, for_input_gradient=False):
+    """u of pack.winograd_weights made on the DEVICE (training: the weights change every step, a host transform would synchronise),
+    for the forward convolution or for its input-gradient convolution; kept on the weight tensor object, follows its version"""
+    key = '_vpho_wino_dev_t' if for_input_gradient else '_vpho_wino_dev'
+    c = getattr(w, key, None)
+    if c is None or c[0] != w._version:
+        cout, k9 = w.shape
+        cin = k9 // 9
+        o, i = (cin, cout) if for_input_gradient else (cout, cin)
+        u = c[1] if c is not None else torch.empty((i // 8, 16, o, 8), device=w.device, dtype=torch.float32)
+        _call('vpho_winograd_weights_f32', _f32(w), I(cout), I(cin), I(1 if for_input_gradient else 0), _f32(u))
+        c = (w._version, u)
+        setattr(w, key, c)
+    return c[1]
+
+
+def winograd_ok(H, W, cin, cout, x_ld):
+    return H % 2 == 0 and W % 2 == 0 and cin % 16 == 0 and cout % 64 == 0 and x_ld == cin and not getattr(_conv_split, 'terms', 0)
+
+
+_TRAIN_WINOGRAD = os.environ.get('VPHO_TRAIN_WINOGRAD', '1') != '0'
+
+
+def conv3x3_train(x, w, bias=None, out_slope=1.0):
+    """3x3 / stride 1 / pad 1 convolution of the TRAINING path: Winograd F(2x2,3x3) with the weight transform on the device where the
+    shape allows, else the direct kernel (VPHO_TRAIN_WINOGRAD=0: always the direct kernel)"""
+    N, H, W, x_ld = x.shape
+    cout, cin = w.shape[0], w.shape[1] // 9
+    if not _TRAIN_WINOGRAD or not winograd_ok(H, W, cin, cout, x_ld) or w.shape[1] != 9 * cin:
+        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope)
+    return conv3x3_winograd(x, winograd_weights_device(w), bias, out_slope)
+
+
+def conv3x3_dgrad_winograd(dy, w, gate=None):
+    """input gradient of a 3x3 / stride 1 / pad 1 convolution with packed weights w (Cout, 9*Cin): dX = conv3x3(dY, flipped / transposed
+    w), optionally through the backward of the LeakyReLU that produced the convolution's input (gate = (that input, slope)).
+    None when the shape is not one the Winograd kernel takes (the caller then uses the direct kernel)."""
+    N, H, W, ld = dy.shape
+    cout, cin = w.shape[0], w.shape[1] // 9
+    if not _TRAIN_WINOGRAD or not winograd_ok(H, W, cout, cin, ld) or w.shape[1] != 9 * cin:
+        return None
+    u = winograd_weights_device(w, for_input_gradient=True)
+    if gate is None:
+        return conv3x3_winograd(dy, u, None, 1.0)
+    g, slope = gate
+    assert g.shape == (N, H, W, cin) and g.is_contiguous()
+    out = torch.empty((N, H, W, cin), device=dy.device, dtype=torch.float32)
+    _call('vpho_conv3x3_winograd_gate_nhwc_f32', _f32(dy), _f32(u), _f32(g), F(slope), I(N), I(H), I(W), I(cout), I(ld), I(cin), _f32(out), I(cin))
+    return out
+
+
 def linear(x, w, bias=None, out_slope=1.0, out=None):
     """x: (rows, cin) fp32, w: (cout, cin) -> (rows, cout).  Same kernel as conv2d_nhwc (1x1)."""
     rows, cin = x.shape

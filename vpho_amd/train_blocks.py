@@ -23,7 +23,7 @@ class BottleneckTrain:
         p, s = self.p, self.stride
         c1 = ops.conv2d_nhwc(x, p['conv1'])
         a1, s1 = self._bn('bn1', c1, SLOPE)
-        c2 = ops.conv2d_nhwc(a1, p['conv2'], kh=3, kw=3, stride=s, pad=1)
+        c2 = ops.conv3x3_train(a1, p['conv2']) if s == 1 else ops.conv2d_nhwc(a1, p['conv2'], kh=3, kw=3, stride=s, pad=1)
         a2, s2 = self._bn('bn2', c2, SLOPE)
         c3 = ops.conv2d_nhwc(a2, p['conv3'])
         if 'down' in p:
@@ -142,7 +142,7 @@ class FPNTrain:
                 q = ops.conv2d_nhwc(c, *self.heads[lat])
                 p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
             self.td[br] = p                                               # p2 before smoothing
-            out[br] = ops.conv2d_nhwc(p, *self.heads[f'smooth3_{br}'], kh=3, kw=3, pad=1)
+            out[br] = ops.conv3x3_train(p, *self.heads[f'smooth3_{br}'])
         self.saved = dict(x=x, c0=c0, a0=a0, s0=s0, c1=c1, feats=feats)
         return out['h'], out['o']
 
@@ -248,7 +248,7 @@ class EncoderTrain:
             a0, s0 = bn(p['bn'], h)
             c1 = ops.conv2d_nhwc(a0, *p['conv1'])
             a1, s1 = bn(p['bn1'], c1)
-            c2 = ops.conv2d_nhwc(a1, *p['conv2'], kh=3, kw=3, pad=1)
+            c2 = ops.conv3x3_train(a1, *p['conv2'])
             a2, s2 = bn(p['bn2'], c2)
             out = ops.conv2d_nhwc(a2, *p['conv3'], res=h)
             self.saved['blocks'].append(dict(h=h, a0=a0, s0=s0, c1=c1, a1=a1, s1=s1, c2=c2, a2=a2, s2=s2))
@@ -321,8 +321,8 @@ class HeatmapHeadTrain:
     def forward(self, x):
         import torch
         bn = lambda p, t, slope: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=slope)
-        c0 = ops.conv2d_nhwc(x, *self.c0, kh=3, kw=3, pad=1)
-        c1 = ops.conv2d_nhwc(c0, *self.c1, kh=3, kw=3, pad=1)
+        c0 = ops.conv3x3_train(x, *self.c0)
+        c1 = ops.conv3x3_train(c0, *self.c1)
         a1, s1 = bn(self.bn1, c1, 1.0)
         N, H, W, _ = a1.shape
         co = self.shapes['deconv_layers.0.weight'][1]
@@ -445,8 +445,8 @@ class CrossTrain:
         import torch
         P, L = self.p, self.L
         bs = st_h.shape[0]
-        ph = ops.conv2d_nhwc(st_h, *self.conv['proj_hand'], kh=3, kw=3, pad=1)
-        po = ops.conv2d_nhwc(st_o, *self.conv['proj_obj'], kh=3, kw=3, pad=1)
+        ph = ops.conv3x3_train(st_h, *self.conv['proj_hand'])
+        po = ops.conv3x3_train(st_o, *self.conv['proj_obj'])
         self._gw64 = torch.nn.functional.pad(P['gravity_proj.weight'], (0, 1)).contiguous()
         ge = ops.linear(grav_emb, self._gw64, P['gravity_proj.bias'])
         x0, m0 = self._drop(ops.cross_tokens(ph, po, ge, self.pe[:bs].contiguous()).view(bs * 65, 512))
