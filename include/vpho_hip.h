@@ -93,6 +93,10 @@ int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* 
  * dilated by one pixel need to hold data.  Device-side lists: the grid is sized for all tiles, blocks past the last live tile exit
  * (no host round trip, replays in a HIP graph with new boxes).  tiles_hint (0 = unknown) only feeds the profiling counters. */
 int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
+/* ... and with the window pixels written IN PLACE into the ordinary (N,H,W,y_ld) map y, every other pixel of y left untouched (the
+ * input gradient of an FPN smoothing convolution: non-zero only in the RoI windows dilated by the 3x3 halo; the caller zeroes y) */
+int vpho_conv3x3_winograd_scatter_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+                                           float out_slope, const int* wins, const int* tile_base, float* y, int y_ld, void* stream);
 /* Training (weights change every step): u on the DEVICE from the packed 3x3 weights (Cout, 9*Cin) -- for the forward convolution
  * (for_input_gradient = 0: u is (Cin/8, 16, Cout, 8)) or for its input-gradient convolution, the 3x3 convolution of dY with the
  * spatially flipped, channel-transposed weights (1: u is (Cout/8, 16, Cin, 8)); fp64 arithmetic, rounded once.  The gate variant
@@ -385,6 +389,14 @@ int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows,
 long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
                                int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream);
+/* The same weight gradient when dY is known to be zero outside RoI windows (the gradient of a map that is only read through RoIAlign:
+ * the FPN smoothing convolutions, VPHO.py:126-129): the reduction runs over the ascending list of live 32-pixel groups that
+ * vpho_window_groups_i32 builds on the device from the window table of vpho_roi_windows_i32 (a group is live when one of its pixels
+ * lies in its image's window); the pixel slices cut the list instead of the pixel range.  Needs OW % 32 == 0.  Same workspace. */
+int vpho_window_groups_i32(const int* wins, int N, int H, int W, int* group_list, int* group_count, void* stream);
+int vpho_conv2d_wgrad_groups_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout,
+                                      int dy_ld, int KH, int KW, int stride, int pad_y, int pad_x, const int* group_list,
+                                      const int* group_count, float* dw, void* workspace, void* stream);
 /* Training-mode tail of HeadMano for one batch of hands (lib/model/head_mano.py:60-87 forward + get_hand_verts, :89-133 get_loss,
  * weights applied as lib/model/VPHO.py:214-219): rot6d [bs][96] (fc_pose output) -> rotation_6d_to_matrix -> ManoLayer -> root-centred
  * vertices / joints in metres (optional outputs verts [bs][778][3], joints [bs][21][3], may be NULL); the four losses against

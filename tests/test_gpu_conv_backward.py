@@ -337,3 +337,32 @@ def test_training_winograd_forward_and_input_gradient(N, H, W, cin, cout):
     a2 = a.detach().requires_grad_(True)
     da, = torch.autograd.grad(F.conv2d(a2, w.double(), None, 1, 1), a2, dy)
     assert float((da_g.permute(0, 3, 1, 2).cpu().double() - da).abs().max()) < 2e-6 * float(da.abs().max())
+
+
+def test_weight_gradient_over_roi_window_groups():
+    """vpho_conv2d_wgrad_groups_nhwc_f32: a gradient that came back through RoIAlign is zero outside the RoI windows; reducing over the
+    live 32-pixel groups only (vpho_window_groups_i32) gives the full reduction's weight gradient (to fp32 summation order), and the
+    group list is exactly the groups that touch a window, ascending."""
+    from vpho_amd import ops, conv_backward as CB
+    g = torch.Generator().manual_seed(5)
+    N, H, W, cin, cout = 6, 64, 64, 64, 128
+    boxes = torch.tensor([[20.0, 30.0, 200.0, 180.0], [0.0, 0.0, 256.0, 256.0], [100.0, 10.0, 130.0, 250.0], [-20.0, 40.0, 90.0, 300.0],
+                          [200.0, 200.0, 255.0, 255.0], [64.0, 64.0, 192.0, 96.0]]).cuda()
+    win = ops.roi_windows(boxes, None, N, H, W, 0.25)
+    lst, cnt = ops.window_groups(win)
+    _, mask = win.to_map(torch.zeros(N * H * W, 1).cuda())
+    live = mask.reshape(-1, 32).any(1).nonzero().flatten().int()
+    n = int(cnt)
+    assert n == live.numel() and torch.equal(lst[:n], live) and 0 < n < N * H * W // 32
+    x = torch.randn(N, H, W, cin, generator=g).cuda()
+    dy = torch.randn(N, H, W, cout, generator=g).cuda() * mask[..., None]
+    # input gradient of a 3x3 convolution on the windows dilated by the halo only: equals the full map's, zeros included
+    w3 = (torch.randn(cout, 9 * cin, generator=g) * 0.05).cuda()
+    halo = ops.roi_windows(boxes, None, N, H, W, 0.25, dilate=1)
+    dfull, dwin = CB.conv2d_dgrad(dy, w3, (H, W), 3, 3, 1, 1), CB.conv2d_dgrad(dy, w3, (H, W), 3, 3, 1, 1, rows=halo)
+    _, hmask = halo.to_map(torch.zeros(N * H * W, 1).cuda())
+    assert torch.equal(dwin[hmask], dfull[hmask]) and bool((dwin[~hmask] == 0).all()) and float(dfull[~hmask].abs().max()) == 0.0
+    for k, pad in ((3, 1), (1, 0)):
+        full = CB.conv2d_wgrad(x, dy, k, k, 1, pad)
+        part = CB.conv2d_wgrad(x, dy, k, k, 1, pad, groups=(lst, cnt))
+        assert float((full - part).abs().max()) < 2e-5 * float(full.abs().max()), k

@@ -39,7 +39,7 @@ def _flip_transpose(w_packed, cout, cin, kh, kw):
     return w_packed.view(cout, kh * kw, cin).permute(2, 1, 0).index_select(1, rev).reshape(cin, kh * kw * cout)
 
 
-def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None):
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None, rows=None):
     """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
     asymmetric top/left paddings of the transposed-convolution phases, stride 1 only).  ``gate`` = (y, slope): the result is
     additionally passed through the backward of the LeakyReLU that produced y = lrelu(x) (fused into the kernel's epilogue).
@@ -48,7 +48,9 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
     if kh == 3 and kw == 3 and stride == 1 and pad == 1 and pad_y is None and pad_x is None and res is None and (OH, OW) == (H, W) and dy.is_contiguous():
-        dx = ops.conv3x3_dgrad_winograd(dy, w_packed, gate)      # Winograd F(2x2,3x3) on the flipped / transposed weights where the shape allows
+        # Winograd F(2x2,3x3) on the flipped / transposed weights where the shape allows; rows (RoiWindows dilated by the halo): dy is
+        # zero outside the windows, so only their pixels are computed (the rest of dx is zero)
+        dx = ops.conv3x3_dgrad_winograd(dy, w_packed, gate, rows=rows)
         if dx is not None:
             return dx
     if cout % 4:                                          # the GEMM kernel wants a reduction length that is a multiple of 4
@@ -89,13 +91,15 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     return dx
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None):
-    """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights."""
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None, groups=None):
+    """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights.
+    ``groups`` (ops.window_groups of the output map): dy is zero outside those 32-pixel groups -- only they are reduced."""
     N, OH, OW, cout = dy.shape
     c_in = x.shape[-1] if cin is None else cin
     small = x.numel() * 4 < 3.9e9 and dy.numel() * 4 < 3.9e9          # the TN kernel addresses its operands by 32-bit byte offsets
     if USE_TN_WGRAD and small and c_in % 4 == 0 and cout % 4 == 0 and x.shape[-1] % 4 == 0:
-        return ops.conv2d_wgrad_nhwc(x, dy.contiguous(), kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, cin=cin)
+        return ops.conv2d_wgrad_nhwc(x, dy.contiguous(), kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, cin=cin,
+                                     groups=groups)
     xg_t = ops.im2col_t(x, kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, OH, OW, cin=cin)   # (kh*kw*cin, P4)
     dy_t = ops.transpose(dy.reshape(N * OH * OW, cout))                          # (Cout, P4), zero-padded columns
     kc, P4 = xg_t.shape

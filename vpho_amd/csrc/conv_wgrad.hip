@@ -25,6 +25,10 @@ struct WgArgs {
     const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
     int N, H, W, Cin, x_ld, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x;
     int M, K, tiles_n, ntiles, m_chunk;
+    // optional: the reduction runs over the LISTED groups of BK consecutive pixels only (ascending; vpho_window_groups_i32) -- dY is
+    // known to be zero everywhere else (the gradient of a map that is read through RoIAlign lives in the RoI windows).  Needs
+    // OW % BK == 0 (a group never leaves its pixel row).  The slices of blockIdx.y then cut the LIST, m_chunk / BK entries each.
+    const int* glist; const int* gcount;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -44,8 +48,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     if (lb >= a.ntiles) return;
     const int tile_n = lb % a.tiles_n, tile_m = lb / a.tiles_n;
     const int co0 = tile_m * BM, c0 = tile_n * BN;                          // c0: column of the flattened (tap, ci) axis
-    const int m_begin = blockIdx.y * a.m_chunk;
-    const int m_end = m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M;
+    const bool listed = a.glist != nullptr;
+    const int s_per = a.m_chunk / BK;                                       // listed: list entries per slice
+    const int s_begin = blockIdx.y * s_per;
+    int s_end = 0;
+    if (listed) { const int total = *a.gcount; s_end = s_begin + s_per < total ? s_begin + s_per : total; }
+    const int m_begin = listed ? 0 : blockIdx.y * a.m_chunk;
+    const int m_end = listed ? a.M : (m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -79,7 +88,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     auto fill = [&](int buf, int kt) {
         float* As = smem + buf * TILE;
         float* Bs = As + BM * BK;
-        const int mb = m_begin + kt * BK;
+        const int mb = listed ? a.glist[s_begin + kt] * BK : m_begin + kt * BK;
+        if (listed) {                                      // the group's pixel row from its first pixel (uniform: scalar divisions)
+            const int q = mb / a.OW, ox0 = mb - q * a.OW, n = q / a.OH, oy = q - n * a.OH;
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) { b_n[j] = n; b_oy[j] = oy; b_ox[j] = ox0 + b_row[j]; }
+        }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const int m = mb + a_row[j];
@@ -96,6 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(Bs + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
             // this row's pixel for the next stage: BK pixels further, (n, oy, ox) advanced without a division
+            if (listed) continue;
             if (a.OW >= 8) {
                 b_ox[j] += BK;
                 while (b_ox[j] >= a.OW) { b_ox[j] -= a.OW; if (++b_oy[j] == a.OH) { b_oy[j] = 0; ++b_n[j]; } }
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (m_end - m_begin + BK - 1) / BK;
+    const int nk = listed ? (s_end > s_begin ? s_end - s_begin : 0) : (m_end - m_begin + BK - 1) / BK;
     if (nk > 0) {
         fill(0, 0);
         VPHO_SYNC_LDS_DMA();
@@ -178,6 +193,37 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
+// ordered list of the live groups of BK consecutive pixels of an (N, H, W) map: group g is live when one of its pixels lies in the
+// window (y0, x0, w, h) of its image (vpho_roi_windows_i32's table).  One workgroup: every thread counts its run of consecutive
+// groups, an exclusive scan of the counts gives each run its place -- ascending order, no atomics.
+__global__ __launch_bounds__(1024) void window_groups_kernel(const int* __restrict__ wins, int N, int H, int W, int* __restrict__ list,
+                                                              int* __restrict__ count) {
+    __shared__ int s_cnt[1024];
+    const int G = N * H * W / BK, per = (G + 1023) / 1024, g0 = threadIdx.x * per;
+    auto live = [&](int g) {
+        const int m = g * BK, n = m / (H * W), rem = m - n * H * W;
+        const int* w = wins + 5 * n;
+        for (int k = 0; k < BK; ++k) {
+            const int y = (rem + k) / W, x = (rem + k) - y * W;
+            if (y >= w[1] && y < w[1] + w[4] && x >= w[2] && x < w[2] + w[3]) return true;
+        }
+        return false;
+    };
+    int c = 0;
+    for (int g = g0; g < g0 + per && g < G; ++g) c += live(g) ? 1 : 0;
+    s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                  // inclusive scan
+        const int v = threadIdx.x >= o ? s_cnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = s_cnt[threadIdx.x] - c;
+    for (int g = g0; g < g0 + per && g < G; ++g) if (live(g)) list[pos++] = g;
+    if (threadIdx.x == 1023) *count = s_cnt[1023];
+}
+
 struct WgPlan { int bm, bn, tiles_m, tiles_n, splits, m_chunk; };
 
 WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
@@ -212,8 +258,30 @@ extern "C" long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, in
     return p.splits > 1 ? (long long)p.splits * Cout * KH * KW * Cin * 4 : 0;
 }
 
+extern "C" int vpho_window_groups_i32(const int* wins, int N, int H, int W, int* group_list, int* group_count, void* stream) {
+    VPHO_REQUIRE(wins && group_list && group_count && N > 0 && H > 0 && W > 0, "vpho_window_groups_i32: bad argument");
+    VPHO_REQUIRE(W % BK == 0 && (long long)N * H * W < (1ll << 31), "vpho_window_groups_i32: the map width must be a multiple of %d", BK);
+    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, wins, N, H, W, group_list, group_count);
+    return vpho::check_launch("window_groups_kernel");
+}
+
+static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
+                        int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream, const int* glist, const int* gcount);
+
 extern "C" int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
                                           int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream) {
+    return wgrad_launch(x, N, H, W, Cin, x_ld, dy, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x, dw, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" int vpho_conv2d_wgrad_groups_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout,
+                                                 int dy_ld, int KH, int KW, int stride, int pad_y, int pad_x, const int* group_list,
+                                                 const int* group_count, float* dw, void* workspace, void* stream) {
+    VPHO_REQUIRE(group_list && group_count && OW % BK == 0, "vpho_conv2d_wgrad_groups_nhwc_f32: needs the group list and an output width that is a multiple of %d", BK);
+    return wgrad_launch(x, N, H, W, Cin, x_ld, dy, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x, dw, workspace, stream, group_list, group_count);
+}
+
+static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
+                        int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream, const int* glist, const int* gcount) {
     VPHO_REQUIRE(x && dy && dw, "vpho_conv2d_wgrad_nhwc_f32: null tensor");
     VPHO_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && OH > 0 && OW > 0, "vpho_conv2d_wgrad_nhwc_f32: non-positive dimension");
     VPHO_REQUIRE(Cin % 4 == 0 && x_ld % 4 == 0 && x_ld >= Cin && Cout % 4 == 0 && dy_ld % 4 == 0 && dy_ld >= Cout,
@@ -231,6 +299,7 @@ extern "C" int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, i
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_ld = dy_ld;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (int)M; a.K = taps * Cin; a.tiles_n = p.tiles_n; a.ntiles = p.tiles_m * p.tiles_n; a.m_chunk = p.m_chunk;
+    a.glist = glist; a.gcount = gcount;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((a.ntiles + 7) / 8 * 8, p.splits);
     if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);

@@ -35,6 +35,7 @@ struct WinoArgs {
     const float* gate; float gate_slope;       // optional, laid out like y: y = gate > 0 ? y : gate_slope * y (LeakyReLU backward given its output)
     const int* wins;                           // [N][5] = (first row, y0, x0, w, h) or NULL
     const int* tile_base;                      // [N + 1] first tile of every image; [N] = live tiles (vpho_winograd_window_tiles_i32)
+    int scatter;                               // with wins: 1 = y is the ordinary (N,H,W,y_ld) map, window pixels written in place, the rest untouched
 };
 
 // tile t -> image n, tile coordinates (ty, tx) on the image's even grid; false past the last live tile
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
                 const int* w = a.wins + 5 * n;
                 const int y = 2 * ty - w[1], x = 2 * tx - w[2];              // window coordinates of the tile's top-left pixel (may be -1)
                 const int my = (y >= 0 ? 1 : 0) | (y + 1 < w[4] ? 2 : 0), mx = (x >= 0 ? 1 : 0) | (x + 1 < w[3] ? 2 : 0);
-                row = w[0] + y * w[3] + x;
-                pitch = (w[3] << 4) | ((my & 1) && (mx & 1) ? 1 : 0) | ((my & 1) && (mx & 2) ? 2 : 0) | ((my & 2) && (mx & 1) ? 4 : 0) | ((my & 2) && (mx & 2) ? 8 : 0);
+                row = a.scatter ? (n * a.H + 2 * ty) * a.W + 2 * tx : w[0] + y * w[3] + x;
+                pitch = ((a.scatter ? a.W : w[3]) << 4) | ((my & 1) && (mx & 1) ? 1 : 0) | ((my & 1) && (mx & 2) ? 2 : 0) | ((my & 2) && (mx & 1) ? 4 : 0) | ((my & 2) && (mx & 2) ? 8 : 0);
             }
         }
         s_row[tid] = row; s_pitch[tid] = pitch;
@@ -292,7 +293,7 @@ __global__ void wino_tile_base_kernel(const int* __restrict__ wins, int N, int* 
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
                        const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
-                       const float* gate = nullptr, float gate_slope = 1.f);
+                       const float* gate = nullptr, float gate_slope = 1.f, int scatter = 0);
 
 // U = G g G^T on the DEVICE for weights that change every step (training): one thread per (output channel, input channel) pair of the
 // convolution the result is for.  mode 0: that convolution is the forward one (w packed as [Cout][(r*3+s)*Cin + ci]); mode 1: its
@@ -337,6 +338,12 @@ extern "C" int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* 
     return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, wins, tile_base, tiles_hint, y_rows, y_ld, stream);
 }
 
+extern "C" int vpho_conv3x3_winograd_scatter_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld,
+                                                      int Cout, float out_slope, const int* wins, const int* tile_base, float* y, int y_ld, void* stream) {
+    VPHO_REQUIRE(wins && tile_base, "vpho_conv3x3_winograd_scatter_nhwc_f32: bad argument");
+    return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, wins, tile_base, 0, y, y_ld, stream, nullptr, 1.f, 1);
+}
+
 extern "C" int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                               float out_slope, float* y, int y_ld, void* stream) {
     return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, nullptr, nullptr, 0, y, y_ld, stream);
@@ -358,7 +365,7 @@ extern "C" int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Ci
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
                        const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
-                       const float* gate, float gate_slope) {
+                       const float* gate, float gate_slope, int scatter) {
     VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
     VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % (2 * WK) == 0 && Cout % W_CB == 0 && x_ld % 4 == 0 && x_ld >= Cin && y_ld >= Cout,
                  "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 16 == 0, Cout %% 64 == 0, x_ld %% 4 == 0");
@@ -367,7 +374,7 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
-    a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope;
+    a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope; a.scatter = scatter;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {

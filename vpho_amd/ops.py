@@ -238,25 +238,41 @@ def winograd_ok(H, W, cin, cout, x_ld):
 _TRAIN_WINOGRAD = os.environ.get('VPHO_TRAIN_WINOGRAD', '1') != '0'
 
 
-def conv3x3_train(x, w, bias=None, out_slope=1.0):
+def conv3x3_train(x, w, bias=None, out_slope=1.0, rows=None):
     """3x3 / stride 1 / pad 1 convolution of the TRAINING path: Winograd F(2x2,3x3) with the weight transform on the device where the
-    shape allows, else the direct kernel (VPHO_TRAIN_WINOGRAD=0: always the direct kernel)"""
+    shape allows, else the direct kernel (VPHO_TRAIN_WINOGRAD=0: always the direct kernel).  ``rows`` (a RoiWindows): the output is
+    only ever read inside these windows (RoIAlign), so only their pixels are computed -- in place in the ordinary (N,H,W,Cout) map,
+    zeros elsewhere; same values as the full convolution on every window pixel."""
     N, H, W, x_ld = x.shape
     cout, cin = w.shape[0], w.shape[1] // 9
     if not _TRAIN_WINOGRAD or not winograd_ok(H, W, cin, cout, x_ld) or w.shape[1] != 9 * cin:
         return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope)
-    return conv3x3_winograd(x, winograd_weights_device(w), bias, out_slope)
+    u = winograd_weights_device(w)
+    if rows is not None:
+        assert rows.shape == (N, H, W)
+        out = torch.zeros((N, H, W, cout), device=x.device, dtype=torch.float32)
+        _call('vpho_conv3x3_winograd_scatter_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope),
+              _i32(rows.wins), _i32(rows.tiles()), _f32(out), I(cout))
+        return out
+    return conv3x3_winograd(x, u, bias, out_slope)
 
 
-def conv3x3_dgrad_winograd(dy, w, gate=None):
+def conv3x3_dgrad_winograd(dy, w, gate=None, rows=None):
     """input gradient of a 3x3 / stride 1 / pad 1 convolution with packed weights w (Cout, 9*Cin): dX = conv3x3(dY, flipped / transposed
     w), optionally through the backward of the LeakyReLU that produced the convolution's input (gate = (that input, slope)).
-    None when the shape is not one the Winograd kernel takes (the caller then uses the direct kernel)."""
+    ``rows`` (a RoiWindows, no gate): dY is zero outside the windows' interior, so dX is computed on the window pixels only and is
+    zero elsewhere.  None when the shape is not one the Winograd kernel takes (the caller then uses the direct kernel)."""
     N, H, W, ld = dy.shape
     cout, cin = w.shape[0], w.shape[1] // 9
     if not _TRAIN_WINOGRAD or not winograd_ok(H, W, cout, cin, ld) or w.shape[1] != 9 * cin:
         return None
     u = winograd_weights_device(w, for_input_gradient=True)
+    if rows is not None and gate is None:
+        assert rows.shape == (N, H, W)
+        out = torch.zeros((N, H, W, cin), device=dy.device, dtype=torch.float32)
+        _call('vpho_conv3x3_winograd_scatter_nhwc_f32', _f32(dy), _f32(u), None, I(N), I(H), I(W), I(cout), I(ld), I(cin), F(1.0),
+              _i32(rows.wins), _i32(rows.tiles()), _f32(out), I(cin))
+        return out
     if gate is None:
         return conv3x3_winograd(dy, u, None, 1.0)
     g, slope = gate
@@ -937,14 +953,29 @@ def im2col_t(x, kh, kw, stride, pad_y, pad_x, OH, OW, cin=None):
     return out
 
 
-def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None):
-    """x (N,H,W,ld), dy (N,OH,OW,Cout) contiguous -> dW (Cout, kh*kw*cin) packed; implicit TN GEMM (csrc/conv_wgrad.hip)"""
+def window_groups(win):
+    """live 32-pixel groups of the (N,H,W) map of a ``RoiWindows`` (ascending list + count, device tensors): where a gradient that
+    came back through RoIAlign can be non-zero (vpho_window_groups_i32)"""
+    N, H, W = win.shape
+    lst = torch.empty((N * H * W // 32,), device=win.wins.device, dtype=torch.int32)
+    cnt = torch.empty((1,), device=win.wins.device, dtype=torch.int32)
+    _call('vpho_window_groups_i32', _i32(win.wins), I(N), I(H), I(W), _i32(lst), _i32(cnt))
+    return lst, cnt
+
+
+def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None, groups=None):
+    """x (N,H,W,ld), dy (N,OH,OW,Cout) contiguous -> dW (Cout, kh*kw*cin) packed; implicit TN GEMM (csrc/conv_wgrad.hip).
+    ``groups`` = window_groups(...) of the OUTPUT map: dy is zero outside them, the reduction skips everything else."""
     N, H, W, ld = x.shape
     _, OH, OW, cout = dy.shape
     cin = ld if cin is None else cin
     dw = _new((cout, kh * kw * cin), x)
     nbytes = lib.vpho_conv2d_wgrad_workspace_bytes(I(N), I(OH), I(OW), I(cin), I(cout), I(kh), I(kw))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes > 0 else None
+    if groups is not None and OW % 32 == 0:
+        _call('vpho_conv2d_wgrad_groups_nhwc_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), _f32(dy), I(OH), I(OW), I(cout), I(cout),
+              I(kh), I(kw), I(stride), I(pad_y), I(pad_x), _i32(groups[0]), _i32(groups[1]), _f32(dw), _ptr(ws))
+        return dw
     _call('vpho_conv2d_wgrad_nhwc_f32', _f32(x), I(N), I(H), I(W), I(cin), I(ld), _f32(dy), I(OH), I(OW), I(cout), I(cout),
           I(kh), I(kw), I(stride), I(pad_y), I(pad_x), _f32(dw), _ptr(ws))
     return dw

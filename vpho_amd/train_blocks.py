@@ -120,8 +120,9 @@ class FPNTrain:
         self.calls[(name, tag)] = seq
         return x
 
-    def forward(self, rgb_nchw):
-        """rgb (N,3,H,W) -> p2_h, p2_o (N,H/4,W/4,256) NHWC"""
+    def forward(self, rgb_nchw, windows=None):
+        """rgb (N,3,H,W) -> p2_h, p2_o (N,H/4,W/4,256) NHWC.  windows = {'h': RoiWindows, 'o': RoiWindows} (optional): the only readers
+        of the two outputs are RoIAligns over these windows, so the smoothing convolutions compute the window pixels only"""
         self.calls = {}
         x = ops.nchw_to_nhwc(rgb_nchw.float().contiguous(), 4)
         c0 = ops.conv2d_nhwc(x, self.stem['conv'], kh=7, kw=7, stride=2, pad=3)
@@ -142,7 +143,7 @@ class FPNTrain:
                 q = ops.conv2d_nhwc(c, *self.heads[lat])
                 p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
             self.td[br] = p                                               # p2 before smoothing
-            out[br] = ops.conv3x3_train(p, *self.heads[f'smooth3_{br}'])
+            out[br] = ops.conv3x3_train(p, *self.heads[f'smooth3_{br}'], rows=None if windows is None else windows[br])
         self.saved = dict(x=x, c0=c0, a0=a0, s0=s0, c1=c1, feats=feats)
         return out['h'], out['o']
 
@@ -161,8 +162,11 @@ class FPNTrain:
                 grads[key] = grads[key] + val if key in grads else val    # layer4 is called twice: its gradients add up
         return dy
 
-    def backward(self, dp2_h, dp2_o, on_ready=None):
-        """on_ready(part, milestone): called with the gradients that have become final at 'fpn_top' (smoothing / lateral / top layers),
+    def backward(self, dp2_h, dp2_o, on_ready=None, groups=None, halo=None):
+        """groups = {'h': ops.window_groups(...), 'o': ...} (optional): where dp2_h / dp2_o can be non-zero (they come back through
+        RoIAligns) -- the smoothing convolutions' weight gradients then skip the rest of the map; halo = {'h': RoiWindows dilated by one
+        pixel, 'o': ...}: where their INPUT gradients can be non-zero (computed there only).
+        on_ready(part, milestone): called with the gradients that have become final at 'fpn_top' (smoothing / lateral / top layers),
         'fpn_mid' (layers 4-2 of both branches) and 'fpn_end' (layer1 + stem) -- grad_buckets.py"""
         S, grads = self.saved, {}
         reported = set()
@@ -177,9 +181,10 @@ class FPNTrain:
         for br, dp in (('h', dp2_h), ('o', dp2_o)):
             c5, c4, c3, c2 = S['feats'][br]
             wS = self.heads[f'smooth3_{br}'][0]
-            grads[f'smooth3_{br}.weight'] = _unpack_grad(CB.conv2d_wgrad(self.td[br], dp, 3, 3, 1, 1), *self.shapes[f'smooth3_{br}.weight'])
+            grads[f'smooth3_{br}.weight'] = _unpack_grad(CB.conv2d_wgrad(self.td[br], dp, 3, 3, 1, 1, groups=None if groups is None else groups[br]),
+                                                         *self.shapes[f'smooth3_{br}.weight'])
             grads[f'smooth3_{br}.bias'] = CB.conv2d_bias_grad(dp)
-            d = CB.conv2d_dgrad(dp, wS, self.td[br].shape[1:3], 3, 3, 1, 1)                 # d p2 (pre-smoothing)
+            d = CB.conv2d_dgrad(dp, wS, self.td[br].shape[1:3], 3, 3, 1, 1, rows=None if halo is None else halo[br])     # d p2 (pre-smoothing)
             for lat, c, slot in ((f'latlayer3_{br}', c2, None), (f'latlayer2_{br}', c3, 2), (f'latlayer1_{br}', c4, 1)):
                 wl = self.heads[lat][0]
                 grads[lat + '.weight'] = _unpack_grad(CB.conv2d_wgrad(c, d, 1, 1), *self.shapes[lat + '.weight'])

@@ -158,8 +158,13 @@ class DiffusionTrainStep:
         eh, eo = self.enc['h'], self.enc['o']
         with torch.cuda.device(self.dev):
             # ---- forward (VPHO.py:115-150)
-            ph, po = self.fpn.forward(data['rgb'])
-            bs, H, W = ph.shape[:3]
+            # The FPN outputs are read only through the RoIAligns below (VPHO.py:126-129), so the two smoothing convolutions -- forward,
+            # input gradient and weight gradient, the largest launches of the step -- work on the RoI windows only (window = every pixel
+            # a bilinear sample of the image's boxes can weigh, vpho_roi_windows_i32; same values on those pixels, zeros elsewhere)
+            bs, H, W = data['rgb'].shape[0], data['rgb'].shape[2] // 4, data['rgb'].shape[3] // 4
+            fwin = dict(h=ops.roi_windows(bb_h, bb_hr, bs, H, W, 0.25), o=ops.roi_windows(bb_or, None, bs, H, W, 0.25)) if W % 32 == 0 else None
+            ph, po = self.fpn.forward(data['rgb'], windows=fwin)
+            assert ph.shape[:3] == (bs, H, W)
             in_h = torch.zeros((bs, R, R, eh.cin_pad), device=self.dev)
             in_o = torch.zeros((bs, R, R, eo.cin_pad), device=self.dev)
             hf_hr = ops.roi_align_nhwc(ph, bb_h, R, 0.25)                          # tight box: the hand heat-map head's input
@@ -239,7 +244,14 @@ class DiffusionTrainStep:
                 if sink is not None:
                     sink.put({f'feature_extractor.{k}': v for k, v in part.items()})
                     sink.flush(milestone)
-            G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o'], on_ready=fpn_ready).items()})
+            # the FPN outputs are read only through the RoIAligns above, so their gradients live in the RoI windows: the weight gradients
+            # of the two smoothing convolutions (the largest of the step) reduce over those pixels only
+            # ... and their input gradients are computed on the windows dilated by the 3x3 halo only
+            groups = halo = None
+            if W % 32 == 0:
+                groups = dict(h=ops.window_groups(fwin['h']), o=ops.window_groups(fwin['o']))
+                halo = dict(h=ops.roi_windows(bb_h, bb_hr, bs, H, W, 0.25, dilate=1), o=ops.roi_windows(bb_or, None, bs, H, W, 0.25, dilate=1))
+            G.update({f'feature_extractor.{k}': v for k, v in self.fpn.backward(dfeat['h'], dfeat['o'], on_ready=fpn_ready, groups=groups, halo=halo).items()})
             L['total_loss'] = sum(L.values())
             if want_outputs:                                   # pd_dt of VPHO.py:221-225
                 pd = dict(hand_heatmap=ops.nhwc_to_nchw(hm_h), obj_heatmap=ops.nhwc_to_nchw(hm_o))
