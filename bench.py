@@ -48,6 +48,7 @@ def parse():
     p.add_argument('--sample_T0', type=float, default=0.65)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
+    p.add_argument('--no_opt_in', action='store_true', help='skip the secondary measurement of the opt-in split-bf16 product path (N=1 only)')
     p.add_argument('--cpu_images', type=int, default=64, help='images of the oracle / parity leg (one batch)')
     p.add_argument('--weights', choices=('conditioned', 'random'), default='conditioned', help='synthetic weight set (vpho_amd.synth)')
     p.add_argument('--pipeline', type=int, default=3, help='evaluation batches kept in flight (1 = sequential loop)')
@@ -322,6 +323,8 @@ def main():
             'metrics_rows_gathered': int(all_rows.shape[0]),
             'host_cpu': host_cpu,
         }
+        if world == 1 and not args.no_opt_in and (score_mfma, conv_mfma) == ('f32', 'f32'):
+            result['opt_in'] = opt_in_leg(args, model, batches, E, lambda out, batch, engine: E.metric_rows(out, batch, gt_joint, gt_vert, 0, assets))
         if world == 1 and not args.no_cpu_baseline:
             result.update(cpu_baseline_leg(args, cfg, model, sd, assets, ANCHOR_SKELETON, dev))
         print(json.dumps(result), flush=True)
@@ -329,6 +332,36 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def opt_in_leg(args, model, batches, E, post):
+    """Secondary, clearly separate from `value`: the same step with every fp32 product of the score head and of the direct convolutions
+    assembled from six exact bf16 x bf16 products on the bf16 matrix cores (fp32 storage and accumulation; error against fp64 at the
+    fp32 kernels' level: DESIGN 4b, tests/test_gpu_split_head.py).  NOT the default and NOT the headline: `value` is the fp32-MFMA path."""
+    import torch
+    saved = {k: os.environ.get(k) for k in ('VPHO_SCORE_MFMA', 'VPHO_CONV_MFMA')}
+    os.environ['VPHO_SCORE_MFMA'] = os.environ['VPHO_CONV_MFMA'] = 'bf16x6'      # read when an execution plan is built
+    try:
+        pipe = E.PipelinedPredictor(model, max(args.pipeline, 1))
+        for f in [pipe.submit(batches[i % 2], post) for i in range(2 * max(args.pipeline, 1) + 1)]:
+            f.result()
+        torch.cuda.synchronize()
+        k = max(4, min(args.steps, 12))
+        t0 = time.perf_counter()
+        for f in [pipe.submit(batches[i % 2], post) for i in range(k)]:
+            f.result()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pipe.close()
+    finally:
+        for key, v in saved.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
+    return {'split_bf16x6': {'value': k * args.bs / dt, 'unit': 'images/s', 'ms_per_step': dt / k * 1e3, 'steps': k,
+                             'what': 'same step, same evaluator; fp32 products of the score head and of the direct convolutions as 6 exact bf16 products each '
+                                     '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`'}}
 
 
 def pmc_traffic(kernel):
