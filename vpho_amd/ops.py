@@ -186,7 +186,7 @@ def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None):
     N, H, W, x_ld = x.shape
     cout, k9 = w.shape
     cin = k9 // 9
-    if not winograd or H % 2 or W % 2 or cin % 16 or cout % 64 or x_ld != cin or getattr(_conv_split, 'terms', 0):
+    if not winograd or H % 2 or W % 2 or cin % 16 or cout % 64 or x_ld != cin:
         return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, rows=rows)
     c = getattr(w, '_vpho_wino', None)
     if c is None or c[0] != w._version:
