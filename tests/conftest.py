@@ -5,6 +5,10 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = sys.argv[:1]          # vpho_amd.configs.args parses sys.argv at import, like the reference's lib/configs/args.py
+# libgomp reads this when torch loads it.  With the default policy the OpenMP workers spin between parallel regions; on a small VM the
+# scheduler can leave two spinning threads on one vCPU for minutes (another vCPU idle), and every barrier of the CPU oracle then
+# costs a time slice: the suite went from 80 s to 220 s that way.  Sleeping workers are woken onto idle CPUs instead.
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
 
 
 def pytest_configure(config):
