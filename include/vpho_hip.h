@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* vpho_last_error(void);
-int vpho_abi_version(void);   /* 6 */
+int vpho_abi_version(void);   /* 7 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -245,6 +245,11 @@ typedef struct {
      * (5 manopth tips 745, 317, 444, 556, 673, then 5 HO3D tips 728, 353, 442, 576, 694; column = tip * 3 + c) gathered into one
      * contiguous [135][30] table -- the joints-only launches of the heat-map cascade read nothing else of the 1.26 MB table */
     const float *tip_posedirs_t;
+    /* ABI version 7, optional (NULL: big launches with vertices take the packed-FMA kernel): the pose-blend table in the operand order
+     * of the fp32 matrix-core kernel, zero padded to 136 rows and 800 vertices: [25 vertex tiles][17 groups of 4 k steps][3][2][32][4],
+     * element (t, g, j, lh, li, e) = posedirs_t[k][(32 t + li) * 3 + c] with f = 4 j + e, k = 2 (4 g + f / 3) + lh, c = f % 3 --
+     * a lane's B fragments of four k steps are three aligned 16-byte loads, consecutive lanes read consecutive 16 bytes */
+    const float *posedirs_mfma;
 } vpho_mano_tables;
 /* per image: v_shaped (n_img,778,3), J (n_img,16,3) from betas (n_img,10) */
 int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream);

@@ -26,8 +26,16 @@ def timed(x, w, bias=None, **kw):
     rec.append((e0, e1, (N, H, W, kw.get('cin', ld), w.shape[0], kw.get('kh', 1), kw.get('stride', 1), 'win' if rows is not None else ''), ys))
     return y
 ops.conv2d_nhwc = timed
-import vpho_amd.model.engine as EM
-EM.ops.conv2d_nhwc = timed
+orig_w = ops.conv3x3_winograd
+def timed_w(x, u, bias=None, out_slope=1.0, out=None, rows=None):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); y = orig_w(x, u, bias, out_slope, out, rows); e1.record()
+    N, H, W, ld = x.shape
+    cout, cin = u.shape[2], u.shape[0] * 8
+    ys = (N, H, W, cout) if rows is None else (int(rows.count), 1, 1, cout)
+    rec.append((e0, e1, (N, H, W, cin, cout, 3, 1, 'wino-win' if rows is not None else 'wino'), ys))
+    return y
+ops.conv3x3_winograd = timed_w
 eng.features(data); torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for e0, e1, key, ys in rec:

@@ -1,0 +1,54 @@
+"""What the pipelined step pays beyond its chip-filling kernels: the time in which NO convolution / score-head kernel is executing,
+split by the kernels that run there (or idle), from a rocprofv3 rocpd database (steady state = the last MS ms).
+usage: rocpd_exposed.py DB [--last-ms MS] [--big 'conv_igemm,conv_winograd,score_head']"""
+import collections, sqlite3, sys
+a = sys.argv
+last_ms = float(a[a.index('--last-ms') + 1]) if '--last-ms' in a else 300.0
+big = (a[a.index('--big') + 1] if '--big' in a else 'conv_igemm,conv_winograd,score_head').split(',')
+cur = sqlite3.connect(a[1]).cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+nm = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
+t_end = cur.execute("select max(end) from kernels").fetchone()[0]
+t0 = t_end - int(last_ms * 1e6)
+rows = list(cur.execute(f"select start, end, {nm} from kernels where end >= {t0} order by start"))
+
+
+def short(n):
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    return n.split('(')[0][:48]
+
+
+# sweep over the event points: at each elementary interval know which kernels are live
+ev = []
+for i, (s, e, n) in enumerate(rows):
+    ev.append((max(s, t0), 1, i)); ev.append((e, 0, i))
+ev.sort()
+live, live_big = set(), 0
+prev = t0
+tot = collections.Counter()
+excl = collections.Counter()            # exposed time by the set of (small) kernels live in it
+isbig = [any(b in n for b in big) for _, _, n in rows]
+for t, kind, i in ev:
+    dt = t - prev
+    if dt > 0:
+        if live_big:
+            tot['big kernel live'] += dt
+        elif not live:
+            tot['idle'] += dt
+        else:
+            tot['only small kernels'] += dt
+            names = sorted({short(rows[j][2]) for j in live})
+            for k in names:
+                excl[k] += dt / len(names)
+        prev = t
+    if kind:
+        live.add(i); live_big += isbig[i]
+    else:
+        live.discard(i); live_big -= isbig[i]
+span = t_end - t0
+print(f'window {span/1e6:.1f} ms, {len(rows)} dispatches; big = {big}')
+for k, v in tot.most_common():
+    print(f'  {k:22s} {v/1e6:8.2f} ms  {100*v/span:5.1f} %')
+print('exposed time (no big kernel live), shared equally among the small kernels live at that moment:')
+for k, v in excl.most_common(25):
+    print(f'  {v/1e6:7.3f} ms  {100*v/span:5.2f} %  {k}')

@@ -246,6 +246,233 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- vertices on the matrix cores
+// The big launches with vertices (6 400 final hypotheses, the physics candidates): 32 hands per workgroup = the rows of a 32x32
+// fp32 MFMA tile, 8 waves; both contractions are matrix products
+//   blend[hand][v*3+c] = sum_k pose_map[hand][k] . posedirs[k][v*3+c]        K = 135 (+1 zero row), 3 accumulator tiles per 32 vertices
+//   T_e[hand][v]       = sum_j A_e[hand][j] . w[j][v]   e = 0..11              K = 16, 12 accumulator tiles per 32 vertices
+// so an operand is fetched once per 2 048 multiply-adds instead of once per multiply-add (the packed-FMA kernel above is bound by
+// its LDS broadcasts of the transforms and by the latency of its table loads, not by arithmetic).  A lane ends up with the three
+// blend coordinates and the twelve transform entries of ONE vertex for 16 hands: the 3x4 transform is applied in registers.
+// The kinematic part and the finger tips are the code of mano_fk_kernel, so the joints are bit-identical to a joints-only launch.
+#ifndef FK_ABLATE
+#define FK_ABLATE 0                     // timing ablations (scripts/kernel_ablate.sh): 1 no vertex stores, 2 no table loads, 4 no blend MFMAs, 8 no skin MFMAs
+#endif
+constexpr int MH = 32;
+struct FkMfmaLds {
+    float R[MH][16][9];
+    float G[MH][16][12];
+    float AT[12][16][MH];        // skinning transforms, element-major / hand-minor: the A operand of the transform blend
+    float pmT[136][MH];          // pose map R_j - I, hand-minor; row 135 = 0 (K padded to the MFMA's k step of 2)
+    float jt[MH][21][3];
+    float tipv[MH][10][3];
+    float tipblend[MH][10][3];
+    float tippd[135][30];        // the compact tip columns of the pose-blend table
+    int img[MH];
+};
+
+__global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fk_smem[];
+    FkMfmaLds& L = *reinterpret_cast<FkMfmaLds*>(fk_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const long long h0 = (long long)blockIdx.x * MH;
+    auto hand_of = [&](int h) { const long long g = h0 + h; return g < a.n_hands ? g : a.n_hands - 1; };
+    const int hj_h = tid >> 4, hj_j = tid & 15;                      // (hand, joint) role of all 512 threads
+    {
+        float r[9];
+        if (FK_ABLATE & 128) { for (int k = 0; k < 9; ++k) r[k] = (float)k; }
+        else vpho::mano_rodrigues(a.pose + hand_of(hj_h) * a.ld_pose + 3 * hj_j, r);
+        for (int k = 0; k < 9; ++k) L.R[hj_h][hj_j][k] = r[k];
+        if (hj_j == 0) L.img[hj_h] = (int)(hand_of(hj_h) / a.hands_per_image);
+    }
+    if (a.t.tip_posedirs_t) for (int i = tid; i < 135 * 30; i += 512) (&L.tippd[0][0])[i] = a.t.tip_posedirs_t[i];
+    __syncthreads();
+    for (int i = tid; i < MH * 136; i += 512) {
+        const int k = i / MH, h = i - k * MH;
+        float v = 0.f;
+        if (k < 135) { const int e = k % 9; v = L.R[h][k / 9 + 1][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
+        L.pmT[k][h] = v;
+    }
+    const float* Jr = a.J + L.img[hj_h] * 48;
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        if ((hj_j == 0 ? 0 : (hj_j - 1) % 3 + 1) == lvl) {
+            const int i = hj_j;
+            float (*Gh)[12] = L.G[hj_h];
+            const float* Ri = L.R[hj_h][i];
+            if (i == 0) {
+                for (int k = 0; k < 3; ++k) { for (int c = 0; c < 3; ++c) Gh[0][k * 4 + c] = Ri[k * 3 + c]; Gh[0][k * 4 + 3] = Jr[k]; }
+            } else {
+                const int p = c_parent[i];
+                const float rel[3] = {Jr[i * 3 + 0] - Jr[p * 3 + 0], Jr[i * 3 + 1] - Jr[p * 3 + 1], Jr[i * 3 + 2] - Jr[p * 3 + 2]};
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) {
+                        float s = 0.f;
+                        for (int k = 0; k < 3; ++k) s += Gh[p][r * 4 + k] * Ri[k * 3 + c];
+                        Gh[i][r * 4 + c] = s;
+                    }
+                    float s = 0.f;
+                    for (int k = 0; k < 3; ++k) s += Gh[p][r * 4 + k] * rel[k];
+                    Gh[i][r * 4 + 3] = s + Gh[p][r * 4 + 3];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const int i = hj_j;
+        for (int r = 0; r < 3; ++r) {
+            float s = 0.f;
+            for (int k = 0; k < 3; ++k) s += L.G[hj_h][i][r * 4 + k] * Jr[i * 3 + k];
+            for (int c = 0; c < 3; ++c) L.AT[r * 4 + c][i][hj_h] = L.G[hj_h][i][r * 4 + c];
+            L.AT[r * 4 + 3][i][hj_h] = L.G[hj_h][i][r * 4 + 3] - s;
+            L.jt[hj_h][i][r] = L.G[hj_h][i][r * 4 + 3];
+        }
+    }
+    __syncthreads();
+    auto fin = [](float v, float c) { return ((v - c) * 1000.f) / 1000.f; };
+    // finger tips: the arithmetic of mano_fk_kernel's tip path, operation for operation (one thread per blend coordinate first)
+    for (int t = tid; t < ((FK_ABLATE & 32) ? 0 : MH * 30); t += 512) {
+        const int h = t / 30, tc = t - h * 30, tip = tc / 3, c = tc - tip * 3;
+        const int v = tip < 5 ? c_tips[tip] : c_tips_ho3d[tip - 5];
+        float s = 0.f;
+        if (a.t.tip_posedirs_t) {
+#pragma unroll 15
+            for (int k = 0; k < 135; ++k) s = fmaf(L.tippd[k][tc], L.pmT[k][h], s);
+        } else {
+            const float* pd = a.t.posedirs_t + v * 3 + c;
+            for (int k = 0; k < 135; ++k) s = fmaf(pd[(long long)k * NV * 3], L.pmT[k][h], s);
+        }
+        L.tipblend[h][tip][c] = s;
+    }
+    __syncthreads();
+    for (int t = tid; t < ((FK_ABLATE & 64) ? 0 : MH * 10); t += 512) {
+        const int h = t / 10, tip = t - h * 10;
+        const int v = tip < 5 ? c_tips[tip] : c_tips_ho3d[tip - 5];
+        const float* vsh = a.v_shaped + (long long)L.img[h] * NV * 3;
+        float vp[3], T[12], o[3];
+        for (int c = 0; c < 3; ++c) vp[c] = vsh[v * 3 + c] + L.tipblend[h][tip][c];
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            const float w = a.t.weights[v * 16 + j];
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(L.AT[e][j][h], w, T[e]);
+        }
+        for (int r = 0; r < 3; ++r) o[r] = fmaf(T[4 * r], vp[0], fmaf(T[4 * r + 1], vp[1], fmaf(T[4 * r + 2], vp[2], T[4 * r + 3])));
+        for (int c = 0; c < 3; ++c) L.tipv[h][tip][c] = o[c];
+        if (tip < 5) for (int c = 0; c < 3; ++c) L.jt[h][16 + tip][c] = o[c];
+    }
+    __syncthreads();
+    for (int t = tid; t < MH * 21; t += 512) {
+        const int h = t / 21, q = t - h * 21;
+        if (h0 + h >= a.n_hands) continue;
+        const bool ho = a.ho3d && a.ho3d[L.img[h]];
+        const float cx = L.jt[h][0][0], cy = L.jt[h][0][1], cz = L.jt[h][0][2];
+        const float* src;
+        if (!ho) src = L.jt[h][c_order[q]];
+        else if (q >= 16) src = L.tipv[h][5 + q - 16];
+        else src = L.jt[h][c_order[c_to_manolayer[q]]];
+        float* jo = a.joints + ((h0 + h) * 21 + q) * 3;
+        jo[0] = fin(src[0], cx); jo[1] = fin(src[1], cy); jo[2] = fin(src[2], cz);
+    }
+
+    // ---- vertices: wave w takes the 32-vertex tiles w, w + 8, ...
+    const int img_lo = L.img[0], img_hi = L.img[MH - 1];             // hands_per_image >= 32: a block spans at most two images
+    constexpr int GS = 4, NG = 68 / GS, NB = 3;     static_assert(GS == 4, "the tiled table holds groups of four k steps");                      // B fragments are requested NB - 1 groups of k steps ahead (L2 latency > one group's MFMAs)
+    // gfx9 counts loads and stores in ONE in-order counter: a table load issued behind a tile's vertex stores cannot be waited for without
+    // waiting for those stores, so the first fragments of the NEXT tile are requested before the current tile's stores are issued
+    constexpr int NT = (NV + 31) / 32;
+    float bq[NB][GS][3];
+    auto load_group = [&](int tile, int g, float (*dst)[3]) {
+        // [t][g][j][lh][li][4]: three aligned 16-byte loads bring the fragments of four k steps (f = 4 j + e <-> step f / 3, coordinate f % 3)
+        const f32x4* p = reinterpret_cast<const f32x4*>(a.t.posedirs_mfma) + ((long long)(tile * NG + g) * 3) * 64 + lane;
+        float f[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 x = (FK_ABLATE & 2) ? f32x4{1.f, 2.f, 3.f, 4.f} : p[j * 64];
+            f[4 * j] = x[0]; f[4 * j + 1] = x[1]; f[4 * j + 2] = x[2]; f[4 * j + 3] = x[3];
+        }
+#pragma unroll
+        for (int q = 0; q < GS; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[q][c] = f[3 * q + c];
+    };
+    if (wave < NT) {
+#pragma unroll
+        for (int g = 0; g < NB - 1; ++g) load_group(wave, g, bq[g]);
+    }
+    for (int t = wave; t < NT; t += 8) {
+        const int v = t * 32 + li, vc = v < NV ? v : NV - 1;
+        float wv[8], vlo[3], vhi[3];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wv[s] = a.t.weights[vc * 16 + 2 * s + lh];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vlo[c] = a.v_shaped[(long long)img_lo * NV * 3 + vc * 3 + c];
+            vhi[c] = a.v_shaped[(long long)img_hi * NV * 3 + vc * 3 + c];
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + NB - 1 < NG) load_group(t, g + NB - 1, bq[(g + NB - 1) % NB]);
+#pragma unroll
+            for (int q = 0; q < GS; ++q) {
+                const float af = L.pmT[2 * (g * GS + q) + lh][li];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (FK_ABLATE & 4) { acc[c][q & 15] += af * bq[g % NB][q][c]; continue; }
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bq[g % NB][q][c], acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 8 < NT) {
+#pragma unroll
+            for (int g = 0; g < NB - 1; ++g) load_group(t + 8, g, bq[g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // vp = v_shaped + blend, in place
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int h = (i >> 2) * 8 + lh * 4 + (i & 3);
+            const bool lo = L.img[h] == img_lo;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c][i] = (lo ? vlo[c] : vhi[c]) + acc[c][i];
+        }
+        float cen[16];                                                // per hand of this lane: the root coordinate of row r
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x16 T[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[q][i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cen[i] = L.jt[(i >> 2) * 8 + lh * 4 + (i & 3)][0][r];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (FK_ABLATE & 8) { T[q][s] += L.AT[r * 4 + q][2 * s + lh][li] * wv[s]; continue; }
+                    T[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.AT[r * 4 + q][2 * s + lh][li], wv[s], T[q], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (v < NV) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int h = (i >> 2) * 8 + lh * 4 + (i & 3);
+                    const float o = fmaf(T[0][i], acc[0][i], fmaf(T[1][i], acc[1][i], fmaf(T[2][i], acc[2][i], T[3][i])));
+                    if ((FK_ABLATE & 1) && o != 1.2345e-30f) continue;
+                    if (h0 + h < a.n_hands) a.verts[((h0 + h) * NV + v) * 3 + r] = fin(o, cen[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream) {
@@ -268,6 +495,16 @@ extern "C" int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, in
     // algorithmic bytes: 48 pose floats read + 21 joints (+ 778 vertices) written per hand; v_shaped + J read once per image
     vpho::ProfScope prof(vpho::PROF_MANO_FK, (hipStream_t)stream, 0.0,
                          (double)n_hands * (48 * 4 + 21 * 12 + (verts ? 778 * 12 : 0)) + (double)((n_hands + hands_per_image - 1) / hands_per_image) * (778 + 16) * 12);
+    static const bool no_mfma = getenv("VPHO_MANO_MFMA") && atoi(getenv("VPHO_MANO_MFMA")) == 0;      // A/B aid: the packed-FMA kernel for every launch
+    if (verts && t->posedirs_mfma && n_hands >= 1024 && hands_per_image >= MH && !no_mfma) {
+        static bool opt_in = false;
+        if (!opt_in) {
+            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mano_fk_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FkMfmaLds)));
+            opt_in = true;
+        }
+        hipLaunchKernelGGL(mano_fk_mfma_kernel, dim3((unsigned)((n_hands + MH - 1) / MH)), dim3(512), sizeof(FkMfmaLds), (hipStream_t)stream, a);
+        return vpho::check_launch("mano_fk_mfma_kernel");
+    }
     if (n_hands >= 1024) hipLaunchKernelGGL(mano_fk_kernel<16>, dim3((unsigned)((n_hands + 15) / 16), gy), dim3(256), 0, (hipStream_t)stream, a);
     else if (n_hands >= 128) hipLaunchKernelGGL(mano_fk_kernel<4>, dim3((unsigned)((n_hands + 3) / 4), gy), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mano_fk_kernel<1>, dim3((unsigned)n_hands, gy), dim3(256), 0, (hipStream_t)stream, a);

@@ -572,7 +572,7 @@ def append_betas(betas, out, rows_per_image):
 
 # ----------------------------------------------------------------------------------------------- MANO
 class ManoTables(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ('v_template', 'shapedirs', 'posedirs_t', 'J_regressor', 'weights', 'tip_posedirs_t')]
+    _fields_ = [(k, C.c_void_p) for k in ('v_template', 'shapedirs', 'posedirs_t', 'J_regressor', 'weights', 'tip_posedirs_t', 'posedirs_mfma')]
 
 
 class Mano:
@@ -584,6 +584,11 @@ class Mano:
         tips = [745, 317, 444, 556, 673, 728, 353, 442, 576, 694]                   # manopth tips, then the HO3D ones (csrc/mano.hip)
         cols = torch.tensor([3 * v + c for v in tips for c in range(3)], device=device)
         self.tensors['tip_posedirs_t'] = self.tensors['posedirs_t'][:, cols].contiguous()     # (135, 30)
+        # the table in the operand order of the matrix-core kernel (include/vpho_hip.h): k = 2 (4 g + sl) + lh, vertex = 32 t + li
+        pad = torch.zeros((136, 800, 3), device=device, dtype=torch.float32)
+        pad[:135, :778] = self.tensors['posedirs_t'].view(135, 778, 3)
+        frag = pad.view(17, 4, 2, 25, 32, 3).permute(3, 0, 2, 4, 1, 5).reshape(25, 17, 2, 32, 3, 4)        # [t][g][lh][li][j][e]
+        self.tensors['posedirs_mfma'] = frag.permute(0, 1, 4, 2, 3, 5).contiguous()                            # [t][g][j][lh][li][e]
         self.c = ManoTables()
         for k, v in self.tensors.items():
             setattr(self.c, k, v.data_ptr())
