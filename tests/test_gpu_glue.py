@@ -55,7 +55,8 @@ def test_mano_fk_batched_matches_oracle(assets, n_img, per_img):
         M2.c.posedirs_mfma = None
         v2, j2 = M2.fk(pose.cuda(), ctx, per_img, True)
         assert torch.equal(j2, joints)
-        assert float((v2 - verts).abs().max()) < 3e-7 and not torch.equal(v2, verts)      # fp32 sums in a different order
+        # observed bit-identical: the fp32 MFMA accumulates its k steps as the same chain of fused multiply-adds; not relied upon
+        assert float((v2 - verts).abs().max()) < 3e-7
 
 
 @pytest.mark.parametrize('n,F,k', [(5, 1, 5), (200, 5, 30), (512, 1, 30), (513, 5, 64), (1024, 1, 30)])

@@ -260,14 +260,13 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
 #endif
 constexpr int MH = 32;
 struct FkMfmaLds {
-    float R[MH][16][9];
-    float G[MH][16][12];
+    union {                      // 91 KB in all: one of these workgroups and one 64 KB convolution workgroup fit a CU together
+        struct { float R[MH][16][9]; float G[MH][16][12]; } kin;                  // rotations and global transforms: dead once AT is made
+        struct { float tippd[135][30]; float tipblend[MH][10][3]; float tipv[MH][10][3]; } tip;   // tip columns of the table, tip results
+    } u;
     float AT[12][16][MH];        // skinning transforms, element-major / hand-minor: the A operand of the transform blend
     float pmT[136][MH];          // pose map R_j - I, hand-minor; row 135 = 0 (K padded to the MFMA's k step of 2)
     float jt[MH][21][3];
-    float tipv[MH][10][3];
-    float tipblend[MH][10][3];
-    float tippd[135][30];        // the compact tip columns of the pose-blend table
     int img[MH];
 };
 
@@ -282,23 +281,22 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
         float r[9];
         if (FK_ABLATE & 128) { for (int k = 0; k < 9; ++k) r[k] = (float)k; }
         else vpho::mano_rodrigues(a.pose + hand_of(hj_h) * a.ld_pose + 3 * hj_j, r);
-        for (int k = 0; k < 9; ++k) L.R[hj_h][hj_j][k] = r[k];
+        for (int k = 0; k < 9; ++k) L.u.kin.R[hj_h][hj_j][k] = r[k];
         if (hj_j == 0) L.img[hj_h] = (int)(hand_of(hj_h) / a.hands_per_image);
     }
-    if (a.t.tip_posedirs_t) for (int i = tid; i < 135 * 30; i += 512) (&L.tippd[0][0])[i] = a.t.tip_posedirs_t[i];
     __syncthreads();
     for (int i = tid; i < MH * 136; i += 512) {
         const int k = i / MH, h = i - k * MH;
         float v = 0.f;
-        if (k < 135) { const int e = k % 9; v = L.R[h][k / 9 + 1][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
+        if (k < 135) { const int e = k % 9; v = L.u.kin.R[h][k / 9 + 1][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
         L.pmT[k][h] = v;
     }
     const float* Jr = a.J + L.img[hj_h] * 48;
     for (int lvl = 0; lvl < 4; ++lvl) {
         if ((hj_j == 0 ? 0 : (hj_j - 1) % 3 + 1) == lvl) {
             const int i = hj_j;
-            float (*Gh)[12] = L.G[hj_h];
-            const float* Ri = L.R[hj_h][i];
+            float (*Gh)[12] = L.u.kin.G[hj_h];
+            const float* Ri = L.u.kin.R[hj_h][i];
             if (i == 0) {
                 for (int k = 0; k < 3; ++k) { for (int c = 0; c < 3; ++c) Gh[0][k * 4 + c] = Ri[k * 3 + c]; Gh[0][k * 4 + 3] = Jr[k]; }
             } else {
@@ -322,13 +320,17 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
         const int i = hj_j;
         for (int r = 0; r < 3; ++r) {
             float s = 0.f;
-            for (int k = 0; k < 3; ++k) s += L.G[hj_h][i][r * 4 + k] * Jr[i * 3 + k];
-            for (int c = 0; c < 3; ++c) L.AT[r * 4 + c][i][hj_h] = L.G[hj_h][i][r * 4 + c];
-            L.AT[r * 4 + 3][i][hj_h] = L.G[hj_h][i][r * 4 + 3] - s;
-            L.jt[hj_h][i][r] = L.G[hj_h][i][r * 4 + 3];
+            for (int k = 0; k < 3; ++k) s += L.u.kin.G[hj_h][i][r * 4 + k] * Jr[i * 3 + k];
+            for (int c = 0; c < 3; ++c) L.AT[r * 4 + c][i][hj_h] = L.u.kin.G[hj_h][i][r * 4 + c];
+            L.AT[r * 4 + 3][i][hj_h] = L.u.kin.G[hj_h][i][r * 4 + 3] - s;
+            L.jt[hj_h][i][r] = L.u.kin.G[hj_h][i][r * 4 + 3];
         }
     }
-    __syncthreads();
+    __syncthreads();                                                 // R and G are dead: their space takes the tip table
+    if (a.t.tip_posedirs_t) {
+        for (int i = tid; i < 135 * 30; i += 512) (&L.u.tip.tippd[0][0])[i] = a.t.tip_posedirs_t[i];
+        __syncthreads();
+    }
     auto fin = [](float v, float c) { return ((v - c) * 1000.f) / 1000.f; };
     // finger tips: the arithmetic of mano_fk_kernel's tip path, operation for operation (one thread per blend coordinate first)
     for (int t = tid; t < ((FK_ABLATE & 32) ? 0 : MH * 30); t += 512) {
@@ -337,12 +339,12 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
         float s = 0.f;
         if (a.t.tip_posedirs_t) {
 #pragma unroll 15
-            for (int k = 0; k < 135; ++k) s = fmaf(L.tippd[k][tc], L.pmT[k][h], s);
+            for (int k = 0; k < 135; ++k) s = fmaf(L.u.tip.tippd[k][tc], L.pmT[k][h], s);
         } else {
             const float* pd = a.t.posedirs_t + v * 3 + c;
             for (int k = 0; k < 135; ++k) s = fmaf(pd[(long long)k * NV * 3], L.pmT[k][h], s);
         }
-        L.tipblend[h][tip][c] = s;
+        L.u.tip.tipblend[h][tip][c] = s;
     }
     __syncthreads();
     for (int t = tid; t < ((FK_ABLATE & 64) ? 0 : MH * 10); t += 512) {
@@ -350,14 +352,14 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
         const int v = tip < 5 ? c_tips[tip] : c_tips_ho3d[tip - 5];
         const float* vsh = a.v_shaped + (long long)L.img[h] * NV * 3;
         float vp[3], T[12], o[3];
-        for (int c = 0; c < 3; ++c) vp[c] = vsh[v * 3 + c] + L.tipblend[h][tip][c];
+        for (int c = 0; c < 3; ++c) vp[c] = vsh[v * 3 + c] + L.u.tip.tipblend[h][tip][c];
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
         for (int j = 0; j < 16; ++j) {
             const float w = a.t.weights[v * 16 + j];
             for (int e = 0; e < 12; ++e) T[e] = fmaf(L.AT[e][j][h], w, T[e]);
         }
         for (int r = 0; r < 3; ++r) o[r] = fmaf(T[4 * r], vp[0], fmaf(T[4 * r + 1], vp[1], fmaf(T[4 * r + 2], vp[2], T[4 * r + 3])));
-        for (int c = 0; c < 3; ++c) L.tipv[h][tip][c] = o[c];
+        for (int c = 0; c < 3; ++c) L.u.tip.tipv[h][tip][c] = o[c];
         if (tip < 5) for (int c = 0; c < 3; ++c) L.jt[h][16 + tip][c] = o[c];
     }
     __syncthreads();
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
         const float cx = L.jt[h][0][0], cy = L.jt[h][0][1], cz = L.jt[h][0][2];
         const float* src;
         if (!ho) src = L.jt[h][c_order[q]];
-        else if (q >= 16) src = L.tipv[h][5 + q - 16];
+        else if (q >= 16) src = L.u.tip.tipv[h][5 + q - 16];
         else src = L.jt[h][c_order[c_to_manolayer[q]]];
         float* jo = a.joints + ((h0 + h) * 21 + q) * 3;
         jo[0] = fin(src[0], cx); jo[1] = fin(src[1], cy); jo[2] = fin(src[2], cz);
