@@ -6,14 +6,14 @@ g = 'gpurun_out/'
 seq, pipe = json.load(open(g + tag + '_seq.json')), json.load(open(g + tag + '_pipe.json'))
 A, As, B = open(g + tag + '_seq_all.txt').read(), open(g + tag + '_seq_ss.txt').read(), open(g + tag + '_pipe_ss.txt').read()
 r = seq['roofline']
-txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --pipeline 1 --steps 10   (MI355X, {rnd}, default plan: Winograd F(2x2,3x3) for the 3x3 / stride-1 convolutions incl. the RoI-windowed FPN ones, score-head tail tiles; sequential steps: 3 warm-up + 10 timed + the instrumented repeats that feed the roofline / hbm blocks; README config bs=64, sample_num=100, sampling_steps=50, T0=0.65; weights = vpho_amd.synth.bench_state_dict: nfev 51/51)
+txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_opt_in --pipeline 1 --steps 10   (MI355X, {rnd}, default plan: Winograd F(2x2,3x3) for the 3x3 / stride-1 convolutions incl. the RoI-windowed FPN ones, score-head tail tiles; sequential steps: 3 warm-up + 10 timed + the instrumented repeats that feed the roofline / hbm blocks; README config bs=64, sample_num=100, sampling_steps=50, T0=0.65; weights = vpho_amd.synth.bench_state_dict: nfev 51/51)
 # this run's bench line:
 #   value {seq['value']:.1f} images/s (sequential, under the profiler), roofline.avg_launch_us {r['avg_launch_us']:.2f} -> {r['achieved']:.1f} TFLOP/s, frac {r['frac']:.3f}; score_head {r['score_head']['achieved']:.1f} TFLOP/s in-run, {r['score_head']['samplers_serialised']['achieved']:.1f} with the samplers serialised
 # summary produced from the rocpd database by scripts/rocpd_stats.py (whole trace); recipe: scripts/profile_round.sh + scripts/install_profiles.py
 {A}
 # (A') same trace, steady state only (--last-ms 600)
 {As}
-# (B) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_kernel_timing --steps 10   (the DEFAULT evaluator: three batches in flight; kernels of different batches and of the two samplers overlap, so per-kernel durations are NOT exclusive times and their sum exceeds the wall time); steady state (--last-ms 300)
+# (B) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing --steps 10   (the DEFAULT evaluator: three batches in flight; kernels of different batches and of the two samplers overlap, so per-kernel durations are NOT exclusive times and their sum exceeds the wall time); steady state (--last-ms 300)
 #   this run's bench line: {pipe['value']:.1f} images/s, {pipe['ms_per_step']:.2f} ms/step under the profiler
 {B}"""
 open(f'profiles/{rnd}_kernel_stats_bench_cfg2.txt', 'w').write(txt)
@@ -21,6 +21,9 @@ hdr = f"# HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE; WR
 open(f'profiles/{rnd}_pmc_hbm_traffic.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_hbm.txt').read())
 hdr = f"# MFMA pipe utilisation from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT) of the same command ({rnd}; summary by scripts/pmc_mfma_summary.py)"
 open(f'profiles/{rnd}_pmc_mfma_busy.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_mfma.txt').read())
+import os
+if os.path.exists(g + tag + '_exposed.txt'):
+    open(f'profiles/{rnd}_exposed_time.txt', 'w').write(f"# time of the pipelined step (trace B above) in which no convolution / score-head kernel executes, by the kernels that run there ({rnd}; scripts/rocpd_exposed.py)\n" + open(g + tag + '_exposed.txt').read())
 shutil.copy(g + tag + '_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic.json')
 shutil.copy(g + tag + '_bench_default.json', f'profiles/{rnd}_bench_default.json')
 d = json.load(open(g + tag + '_bench_default.json'))
