@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void mano_fk_kernel(const FkArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- vertices on the matrix cores
-// The big launches with vertices (6 400 final hypotheses, the physics candidates): 32 hands per workgroup = the rows of a 32x32
+// The big launches with vertices (4 096 hands and more: the 6 400 final hypotheses): 32 hands per workgroup = the rows of a 32x32
 // fp32 MFMA tile, 8 waves; both contractions are matrix products
 //   blend[hand][v*3+c] = sum_k pose_map[hand][k] . posedirs[k][v*3+c]        K = 135 (+1 zero row), 3 accumulator tiles per 32 vertices
 //   T_e[hand][v]       = sum_j A_e[hand][j] . w[j][v]   e = 0..11              K = 16, 12 accumulator tiles per 32 vertices
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
     }
 
     // ---- vertices: wave w takes the 32-vertex tiles w, w + 8, ...
-    const int img_lo = L.img[0], img_hi = L.img[MH - 1];             // hands_per_image >= 32: a block spans at most two images
+    // hands_per_image >= 16: a block of 32 hands spans at most three images (the middle one is lo + 1, or hi again)
+    const int img_lo = L.img[0], img_hi = L.img[MH - 1], img_mid = img_lo + 1 < img_hi ? img_lo + 1 : img_hi;
     constexpr int GS = 4, NG = 68 / GS, NB = 3;     static_assert(GS == 4, "the tiled table holds groups of four k steps");                      // B fragments are requested NB - 1 groups of k steps ahead (L2 latency > one group's MFMAs)
     // gfx9 counts loads and stores in ONE in-order counter: a table load issued behind a tile's vertex stores cannot be waited for without
     // waiting for those stores, so the first fragments of the NEXT tile are requested before the current tile's stores are issued
@@ -403,12 +404,13 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
     }
     for (int t = wave; t < NT; t += 8) {
         const int v = t * 32 + li, vc = v < NV ? v : NV - 1;
-        float wv[8], vlo[3], vhi[3];
+        float wv[8], vlo[3], vmid[3], vhi[3];
 #pragma unroll
         for (int s = 0; s < 8; ++s) wv[s] = a.t.weights[vc * 16 + 2 * s + lh];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             vlo[c] = a.v_shaped[(long long)img_lo * NV * 3 + vc * 3 + c];
+            vmid[c] = a.v_shaped[(long long)img_mid * NV * 3 + vc * 3 + c];
             vhi[c] = a.v_shaped[(long long)img_hi * NV * 3 + vc * 3 + c];
         }
         f32x16 acc[3];
@@ -439,9 +441,9 @@ __global__ __launch_bounds__(512) void mano_fk_mfma_kernel(const FkArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int h = (i >> 2) * 8 + lh * 4 + (i & 3);
-            const bool lo = L.img[h] == img_lo;
+            const int im = L.img[h];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c][i] = (lo ? vlo[c] : vhi[c]) + acc[c][i];
+            for (int c = 0; c < 3; ++c) acc[c][i] = (im == img_lo ? vlo[c] : im == img_hi ? vhi[c] : vmid[c]) + acc[c][i];
         }
         float cen[16];                                                // per hand of this lane: the root coordinate of row r
 #pragma unroll
@@ -498,7 +500,9 @@ extern "C" int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, in
     vpho::ProfScope prof(vpho::PROF_MANO_FK, (hipStream_t)stream, 0.0,
                          (double)n_hands * (48 * 4 + 21 * 12 + (verts ? 778 * 12 : 0)) + (double)((n_hands + hands_per_image - 1) / hands_per_image) * (778 + 16) * 12);
     static const bool no_mfma = getenv("VPHO_MANO_MFMA") && atoi(getenv("VPHO_MANO_MFMA")) == 0;      // A/B aid: the packed-FMA kernel for every launch
-    if (verts && t->posedirs_mfma && n_hands >= 1024 && hands_per_image >= MH && !no_mfma) {
+    // one 32-hand workgroup per CU takes ~95 us whatever the launch size: it pays from ~4 000 hands on (the packed-FMA kernel needs 61 us for
+    // 1 920 hands, 166 us for 6 400)
+    if (verts && t->posedirs_mfma && n_hands >= 4096 && hands_per_image >= MH / 2 && !no_mfma) {
         static bool opt_in = false;
         if (!opt_in) {
             VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mano_fk_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FkMfmaLds)));
