@@ -642,6 +642,7 @@ class Aggregation:
         ycb = assets['ycb']
         self.names = list(ycb.keys())
         self.name_to_id = {n: i for i, n in enumerate(self.names)}
+        self._ids = {}
         f = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
         stack = lambda key: torch.stack([torch.as_tensor(ycb[n][key], dtype=torch.float32).reshape(-1, 3) for n in self.names]).to(device).contiguous()
         self.kpt, self.vert = stack('kpt3d'), stack('verts_sampled')
@@ -656,7 +657,15 @@ class Aggregation:
         self.device = device
 
     def obj_ids(self, names):
-        return torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+        """class indices of a batch as a device tensor; kept per name tuple: building it is a synchronous host-to-device copy, which in the
+        middle of a step would park the calling thread behind everything already queued on its stream"""
+        key = tuple(names)
+        ids = self._ids.get(key)
+        if ids is None:
+            if len(self._ids) > 256:
+                self._ids.clear()
+            ids = self._ids[key] = torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+        return ids
 
     def hand_candidates(self, diff_pose, reg_pose, bs, S):
         pose = _new((bs, 2 * S, 48), diff_pose)
@@ -827,6 +836,7 @@ class ObjectMetrics:
         import numpy as np
         self.names = list(ycb.keys())
         self.name_to_id = {n: i for i, n in enumerate(self.names)}
+        self._ids = {}
         d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
         self.bbox3d = d(np.stack([np.asarray(ycb[n]['bbox3d']).reshape(8, 3) for n in self.names]))
         self.verts_sampled = d(np.stack([np.asarray(ycb[n]['verts_sampled']).reshape(-1, 3) for n in self.names]))
@@ -838,10 +848,17 @@ class ObjectMetrics:
         self.c = ObjMetricTables(self.bbox3d.data_ptr(), self.verts_sampled.data_ptr(), self.verts.data_ptr(),
                                  self.vert_offset.data_ptr(), self.diameter.data_ptr(), len(self.names), self.verts_sampled.shape[1])
         self.device = device
-        self._ws = None
 
     def obj_ids(self, names):
-        return torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+        """class indices of a batch as a device tensor; kept per name tuple: building it is a synchronous host-to-device copy, which in the
+        middle of a step would park the calling thread behind everything already queued on its stream"""
+        key = tuple(names)
+        ids = self._ids.get(key)
+        if ids is None:
+            if len(self._ids) > 256:
+                self._ids.clear()
+            ids = self._ids[key] = torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
+        return ids
 
     def __call__(self, pd_rt, gt_rt, cam_intr, obj_id):
         """pd_rt, gt_rt (n,3,4), cam_intr (n,3,3) fp64, obj_id (n,) int32 -> (n,16) fp64 in the order of OBJ_METRIC_NAMES."""
@@ -850,11 +867,12 @@ class ObjectMetrics:
         need = lib.vpho_obj_metrics_workspace_bytes(C.byref(self.c), I(n), I(self.max_verts))
         if need < 0:
             raise VphoError('vpho_obj_metrics_workspace_bytes: bad argument')
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        # a fresh block from torch's caching allocator per call (stream-ordered reuse): one object serves the evaluator's slots, whose
+        # streams run concurrently -- a workspace kept on the object would be shared by kernels of different streams
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = _new((n, 16), pd_rt, torch.float64)
         _call('vpho_obj_metrics_f64', C.byref(self.c), _f64(pd_rt), _f64(gt_rt), _f64(cam_intr), _i32(obj_id), I(n), I(self.max_verts),
-              _f64(out), _ptr(self._ws), LL(self._ws.numel()))
+              _f64(out), _ptr(ws), LL(ws.numel()))
         return out
 
 
