@@ -39,8 +39,14 @@ class GraphedCall:
                 return self.fn(tensors)
             self.entries[key] = e
         static, graph, out = e
+        dev_in = [k for k, v in tensors.items() if v.is_cuda]
+        if len(dev_in) > 1:                                   # one multi-tensor copy instead of a launch per input
+            torch._foreach_copy_([static[k] for k in dev_in], [tensors[k] for k in dev_in], non_blocking=True)
+        else:
+            dev_in = []
         for k, v in tensors.items():
-            static[k].copy_(v, non_blocking=True)
+            if k not in set(dev_in):
+                static[k].copy_(v, non_blocking=True)
         graph.replay()
         return out
 
