@@ -146,3 +146,32 @@ def test_object_metric_block_of_the_evaluation_rows(assets):
                     for i, n in enumerate(data['obj_name'])])
     _check_obj(got, orc, nn_atol=1e-7, f_atol=1e-3)
     assert got[0, col['ADD']] < 1e-3 < got[-1, col['ADD']]          # the sweep really goes from near-exact to far off
+
+
+def test_one_object_metrics_instance_serves_concurrent_streams(assets):
+    """The evaluator's slots share one ObjectMetrics object and call it on their own streams: every call must own its workspace
+    (a workspace kept on the object was shared by kernels of different streams)."""
+    from vpho_amd import ops
+    from oracle import rotations as R
+    M = ops.ObjectMetrics(assets['ycb'], 'cuda')
+    rng = np.random.default_rng(5)
+    n, sets = 64, []
+    for s in range(6):
+        Rm = R.axis_angle_to_matrix(torch.from_numpy(rng.normal(size=(n, 3)))).numpy()
+        t = rng.normal(size=(n, 3)) * 0.05 + np.array([0, 0, 0.7])
+        gt = np.concatenate([Rm, t[:, :, None]], -1)
+        pd = gt.copy(); pd[:, :, 3] += rng.normal(size=(n, 3)) * 0.01 * (s + 1)
+        cam = np.tile(np.array([[500.0, 0, 128], [0, 500.0, 128], [0, 0, 1]]), (n, 1, 1))
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        sets.append((d(pd), d(gt), d(cam), torch.from_numpy(rng.integers(0, len(M.names), n).astype(np.int32)).cuda()))
+    want = [M(*a).clone() for a in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in sets]
+    for rep in range(5):
+        got = []
+        for st, a in zip(streams, sets):
+            with torch.cuda.stream(st):
+                got.append(M(*a))
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
