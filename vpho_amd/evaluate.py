@@ -109,7 +109,9 @@ class PipelinedPredictor:
         self.dev = self.engines[0].dev
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)]
         self.locks = [threading.Lock() for _ in range(depth)]
-        self.pool = ThreadPoolExecutor(max_workers=depth, thread_name_prefix='vpho-predict')
+        # ONE worker thread and queue per slot: with a shared pool a thread that has finished its slot's batch takes the next task in line,
+        # which may belong to ANOTHER slot, and sleeps on that slot's lock while its own slot sits idle
+        self.pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f'vpho-predict-{i}') for i in range(depth)]
         self.n = 0
         import os
         self.sync_in_worker = os.environ.get('VPHO_PIPE_SYNC_IN_WORKER', '0') == '1'      # A/B aid: the round-1 behaviour
@@ -139,10 +141,11 @@ class PipelinedPredictor:
                     done.synchronize()
                 return res, done
 
-        return _Pending(self.pool.submit(work))
+        return _Pending(self.pools[slot].submit(work))
 
     def close(self):
-        self.pool.shutdown(wait=True)
+        for p in self.pools:
+            p.shutdown(wait=True)
 
 
 def gather_rows(rows):
