@@ -13,7 +13,7 @@ txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_ba
 {A}
 # (A') same trace, steady state only (--last-ms 600)
 {As}
-# (B) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing --steps 10   (the DEFAULT evaluator: three batches in flight; kernels of different batches and of the two samplers overlap, so per-kernel durations are NOT exclusive times and their sum exceeds the wall time); steady state (--last-ms 300)
+# (B) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing --steps 10   (the DEFAULT evaluator: three batches in flight; kernels of different batches and of the two samplers overlap, so per-kernel durations are NOT exclusive times and their sum exceeds the wall time); steady state of the PIPELINED steps only (scripts/_rocpd.py: the end of a bench trace is its sequential legs)
 #   this run's bench line: {pipe['value']:.1f} images/s, {pipe['ms_per_step']:.2f} ms/step under the profiler
 {B}"""
 open(f'profiles/{rnd}_kernel_stats_bench_cfg2.txt', 'w').write(txt)
@@ -23,7 +23,7 @@ hdr = f"# MFMA pipe utilisation from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY
 open(f'profiles/{rnd}_pmc_mfma_busy.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_mfma.txt').read())
 import os
 if os.path.exists(g + tag + '_exposed.txt'):
-    open(f'profiles/{rnd}_exposed_time.txt', 'w').write(f"# time of the pipelined step (trace B above) in which no convolution / score-head kernel executes, by the kernels that run there ({rnd}; scripts/rocpd_exposed.py)\n" + open(g + tag + '_exposed.txt').read())
+    open(f'profiles/{rnd}_exposed_time.txt', 'w').write(f"# time of the pipelined steps (trace B of the kernel-stats file, same window) in which no convolution / score-head kernel executes, by the kernels that run there ({rnd}; scripts/rocpd_exposed.py)\n" + open(g + tag + '_exposed.txt').read())
 shutil.copy(g + tag + '_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic.json')
 shutil.copy(g + tag + '_bench_default.json', f'profiles/{rnd}_bench_default.json')
 d = json.load(open(g + tag + '_bench_default.json'))

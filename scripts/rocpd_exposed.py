@@ -1,6 +1,7 @@
 """What the pipelined step pays beyond its chip-filling kernels: the time in which NO convolution / score-head kernel is executing,
 split by the kernels that run there (or idle), from a rocprofv3 rocpd database (steady state = the last MS ms).
-usage: rocpd_exposed.py DB [--last-ms MS] [--big 'conv_igemm,conv_winograd,score_head']"""
+usage: rocpd_exposed.py DB [--last-ms MS | --pipelined] [--big 'conv_igemm,conv_winograd,score_head']
+(--pipelined: the steady state of bench.py's pipelined steps, scripts/_rocpd.py; the END of a bench trace is its sequential legs)"""
 import collections, sqlite3, sys
 a = sys.argv
 last_ms = float(a[a.index('--last-ms') + 1]) if '--last-ms' in a else 300.0
@@ -10,7 +11,15 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 nm = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
 t_end = cur.execute("select max(end) from kernels").fetchone()[0]
 t0 = t_end - int(last_ms * 1e6)
-rows = list(cur.execute(f"select start, end, {nm} from kernels where end >= {t0} order by start"))
+if '--pipelined' in a:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _rocpd import pipelined_window
+    w = pipelined_window(cur)
+    if w is None:
+        raise SystemExit('no pipelined region in this trace')
+    t0, t_end = w
+rows = list(cur.execute(f"select start, end, {nm} from kernels where end >= {t0} and start <= {t_end} order by start"))
 
 
 def short(n):
@@ -21,7 +30,7 @@ def short(n):
 # sweep over the event points: at each elementary interval know which kernels are live
 ev = []
 for i, (s, e, n) in enumerate(rows):
-    ev.append((max(s, t0), 1, i)); ev.append((e, 0, i))
+    ev.append((max(s, t0), 1, i)); ev.append((min(e, t_end), 0, i))
 ev.sort()
 live, live_big = set(), 0
 prev = t0
