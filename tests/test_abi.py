@@ -64,3 +64,44 @@ def test_bn_folding_on_cpu(sd):
                        sd[p + '.bn1.weight'], sd[p + '.bn1.bias'], False, 0.0, 1e-5)
     got = F.conv2d(x, w.view(64, 1, 1, 64).permute(0, 3, 1, 2), b)
     assert torch.allclose(got, ref, atol=1e-5)
+
+
+def _header_structs():
+    """{struct name: [(field name, 'ptr' | 'int' | 'float' | 'double' | 'longlong'), ...]} from include/vpho_hip.h"""
+    import re
+    txt = open(os.path.join(ROOT, 'include', 'vpho_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', ' ', txt, flags=re.S)
+    out = {}
+    for body, name in re.findall(r'typedef\s+struct(?:\s+\w+)?\s*\{(.*?)\}\s*(\w+)\s*;', txt, flags=re.S):
+        fields = []
+        for decl in body.split(';'):
+            decl = ' '.join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r'^(const\s+)?(unsigned\s+char|long\s+long|\w+)\s*(.*)$', decl)
+            base, rest = m.group(2), m.group(3)
+            for item in rest.split(','):
+                item = item.strip()
+                ptr = item.startswith('*') or base.endswith('*')
+                fields.append((item.lstrip('* '), 'ptr' if ptr else {'int': 'int', 'float': 'float', 'double': 'double', 'long long': 'longlong'}[base]))
+        out[name] = fields
+    return out
+
+
+def test_ctypes_structures_mirror_the_header_field_for_field():
+    """A binding whose Structure is one field short makes the C side read past it (found in INTEGRATION.md's example): names, order and
+    kind of every field of every struct the ABI passes by pointer, header against vpho_amd/ops.py."""
+    from vpho_amd import ops
+    hs = _header_structs()
+    pairs = {'vpho_conv_desc': ops.ConvDesc, 'vpho_score_weights': ops.ScoreWeights, 'vpho_ode_stats': ops.OdeStats,
+             'vpho_mano_tables': ops.ManoTables, 'vpho_obj_tables': ops.ObjTables, 'vpho_anchor_tables': ops.AnchorTables,
+             'vpho_obj_metric_tables': ops.ObjMetricTables}
+    kind = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_float: 'float', ctypes.c_double: 'double', ctypes.c_longlong: 'longlong'}
+    for name, cls in pairs.items():
+        assert name in hs, name
+        got = [(f[0], kind[f[1]]) for f in cls._fields_]
+        assert got == hs[name], f'{name}: header {hs[name]} vs ctypes {got}'
+    # the example a maintainer would copy out of INTEGRATION.md names the same fields of the sampler's weight struct
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    for f, _ in hs['vpho_score_weights']:
+        assert f"'{f}'" in doc, f'INTEGRATION.md example lacks vpho_score_weights.{f}'
