@@ -105,3 +105,71 @@ def test_ctypes_structures_mirror_the_header_field_for_field():
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     for f, _ in hs['vpho_score_weights']:
         assert f"'{f}'" in doc, f'INTEGRATION.md example lacks vpho_score_weights.{f}'
+
+
+def _header_prototypes():
+    """{function: [kind of every parameter]} with kind in ptr / int / float / double / longlong"""
+    import re
+    txt = open(os.path.join(ROOT, 'include', 'vpho_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', ' ', txt, flags=re.S)
+    txt = re.sub(r'typedef\s+struct(?:\s+\w+)?\s*\{.*?\}\s*\w+\s*;', ' ', txt, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r'\b(int|long long|const char\s*\*|void)\s+(vpho_\w+)\s*\(([^)]*)\)\s*;', txt):
+        kinds = []
+        for a in args.split(','):
+            a = ' '.join(a.split())
+            if not a or a == 'void':
+                continue
+            if '*' in a:
+                kinds.append('ptr')
+            elif a.startswith('long long'):
+                kinds.append('longlong')
+            else:
+                kinds.append({'int': 'int', 'float': 'float', 'double': 'double', 'unsigned': 'int'}[a.replace('const ', '').split()[0]])
+        protos[name] = kinds
+    return protos
+
+
+def test_every_ctypes_call_site_passes_what_the_header_declares():
+    """Static check of vpho_amd/ops.py against include/vpho_hip.h: each `_call('vpho_x', ...)` passes as many arguments as the prototype
+    has before its trailing stream, and every argument built by a typed wrapper (I / F / LL / c_double / tensor pointer / byref) has the
+    declared kind -- a swapped or missing argument would otherwise only show on the GPU, as a wrong result."""
+    import ast
+    protos = _header_prototypes()
+    assert len(protos) >= 80
+    src = open(os.path.join(ROOT, 'vpho_amd', 'ops.py')).read()
+    wrap = {'I': 'int', 'F': 'float', 'LL': 'longlong', '_f32': 'ptr', '_f64': 'ptr', '_i32': 'ptr', '_u8': 'ptr', '_ptr': 'ptr', '_at': 'ptr'}
+
+    def kind(node):
+        if isinstance(node, ast.Call):
+            f = node.func
+            if isinstance(f, ast.Name) and f.id in wrap:
+                return wrap[f.id]
+            if isinstance(f, ast.Attribute) and f.attr in ('byref', 'c_void_p'):
+                return 'ptr'
+            if isinstance(f, ast.Attribute) and f.attr == 'c_double':
+                return 'double'
+            if isinstance(f, ast.Attribute) and f.attr == 'c_longlong':
+                return 'longlong'
+        if isinstance(node, ast.Constant) and node.value is None:
+            return 'ptr'
+        return None                      # built elsewhere (a ctypes array, a local): not judged
+
+    seen, judged = set(), 0
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == '_call':
+            name = node.args[0].value
+            assert name in protos, f'{name} is called but not declared in include/vpho_hip.h'
+            want = protos[name]
+            assert want and want[-1] == 'ptr', f'{name}: the last parameter must be the stream'
+            got = node.args[1:]
+            if any(isinstance(a, ast.Starred) for a in got):
+                continue
+            assert len(got) == len(want) - 1, f'{name}: {len(got)} arguments at line {node.lineno}, header has {len(want) - 1} before the stream'
+            for i, (a, w) in enumerate(zip(got, want)):
+                k = kind(a)
+                if k is not None:
+                    judged += 1
+                    assert k == w, f'{name} argument {i} at line {node.lineno}: passes {k}, header declares {w}'
+            seen.add(name)
+    assert len(seen) >= 60 and judged >= 600, (len(seen), judged)
