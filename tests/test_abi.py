@@ -173,3 +173,24 @@ def test_every_ctypes_call_site_passes_what_the_header_declares():
                     assert k == w, f'{name} argument {i} at line {node.lineno}: passes {k}, header declares {w}'
             seen.add(name)
     assert len(seen) >= 60 and judged >= 600, (len(seen), judged)
+    # entry points called directly (not through _call) declare argtypes: those must spell the prototype
+    from vpho_amd import ops
+    kinds = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_float: 'float', ctypes.c_double: 'double', ctypes.c_longlong: 'longlong'}
+    typed = 0
+    for name, want in protos.items():
+        at = getattr(ops.lib, name).argtypes
+        if at is None:
+            continue
+        got = [kinds.get(t, 'ptr' if hasattr(t, 'contents') or hasattr(t, '_type_') and isinstance(t._type_, type) else None) for t in at]
+        assert got == want, f'{name}.argtypes {got} vs header {want}'
+        typed += 1
+    assert typed >= 4
+    for node in ast.walk(ast.parse(src)):                 # ... and every direct call has argtypes behind it or typed wrappers only
+        if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name)
+                and node.func.value.id == 'lib' and node.func.attr.startswith('vpho_') and node.func.attr in protos):
+            name = node.func.attr
+            if getattr(ops.lib, name).argtypes is None:
+                assert len(node.args) == len(protos[name]), f'{name}: {len(node.args)} arguments at line {node.lineno}, header has {len(protos[name])}'
+                for i, (a, w) in enumerate(zip(node.args, protos[name])):
+                    k = kind(a) or ('ptr' if isinstance(a, ast.Call) and isinstance(a.func, ast.Name) and a.func.id == '_stream' else None)
+                    assert k == w, f'{name} argument {i} at line {node.lineno}: passes {k} without argtypes, header declares {w}'
