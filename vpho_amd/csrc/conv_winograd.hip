@@ -1,5 +1,5 @@
-// Winograd F(2x2, 3x3) convolution (stride 1, padding 1) on the gfx950 fp32 matrix cores -- EXPERIMENT, see the launch condition in
-// vpho_conv3x3_winograd_nhwc_f32 and DESIGN.md for where (if anywhere) the plan uses it.
+// Winograd F(2x2, 3x3) convolution (stride 1, padding 1) on the gfx950 fp32 matrix cores: the default for the stride-1 3x3 convolutions of
+// the inference plan and of the training step (VPHO_WINOGRAD=0 / VPHO_TRAIN_WINOGRAD=0 select the direct kernels).
 //
 // Y(2x2) = A^T [ sum_c (G g_c G^T) o (B^T d_c B) ] A: the 16 element-wise products are 16 independent GEMMs
 //   M_f[tile][cout] = sum_cin V_f[tile][cin] * U_f[cout][cin]      (f = 4*fy + fx)
