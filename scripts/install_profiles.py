@@ -17,7 +17,7 @@ txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_ba
 #   this run's bench line: {pipe['value']:.1f} images/s, {pipe['ms_per_step']:.2f} ms/step under the profiler
 {B}"""
 open(f'profiles/{rnd}_kernel_stats_bench_cfg2.txt', 'w').write(txt)
-hdr = f"# HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of  VPHO_GRAPHS=0 python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing --pipeline 1  ({rnd}; scripts/profile_round.sh, summary by scripts/pmc_summary.py)\n# per-launch averages over all launches of each kernel; HBM column = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (counters in KB; gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md)"
+hdr = f"# HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of  VPHO_GRAPHS=0 python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_opt_in --no_kernel_timing --pipeline 1  ({rnd}; scripts/profile_round.sh, summary by scripts/pmc_summary.py)\n# per-launch averages over all launches of each kernel; HBM column = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (counters in KB; gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md)"
 open(f'profiles/{rnd}_pmc_hbm_traffic.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_hbm.txt').read())
 hdr = f"# MFMA pipe utilisation from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT) of the same command ({rnd}; summary by scripts/pmc_mfma_summary.py)"
 open(f'profiles/{rnd}_pmc_mfma_busy.txt', 'w').write(hdr + '\n' + open(g + tag + '_pmc_mfma.txt').read())
