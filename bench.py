@@ -430,6 +430,11 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     # the judge of the top-k chain: every list of the HIP path re-scored in fp64 on the HIP path's own candidates (oracle/referee.py)
     from oracle import referee as RFE
     ref_sum = RFE.summary(RFE.referee(assets, skeleton, RFE.record_from_hip(out, eng_info, data)))
+    # how well the REFERENCE reproduces itself (committed fixture written by the reference's own forward under other thread counts /
+    # oneDNN off, tests/golden/make_golden_readme.py --variant): the yardstick for end_to_end_vs_oracle's list counts
+    from oracle.compare import reference_self_agreement
+    selfcheck = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'golden_predict_readme64_selfcheck.npz')
+    self_rep = reference_self_agreement(selfcheck) if os.path.exists(selfcheck) else None
     return {'cpu_baseline': {'value': n / t_cpu, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
                              'sample': f'one batch of {n} images at the same config (S={args.sample_num}, steps={args.sampling_steps}), oracle '
                                        f'(torch-CPU + host RK45, {cores} threads = this process\'s CPU quota), {t_cpu:.1f} s; nfev hand/obj {info["hand_ode"]["nfev"]}/{info["obj_ode"]["nfev"]}'},
@@ -445,6 +450,7 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                                       eng_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
                        'upstream_max_abs': upstream,
                        'fp64_referee': ref_sum,
+                       'reference_self_agreement': self_rep,
                        'end_to_end_vs_oracle': end_to_end,
                        'aggregation_given_identical_candidates': given_same}}
 

@@ -14,20 +14,28 @@
 #ifndef VPHO_HIP_H
 #define VPHO_HIP_H
 
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols
+ * (tests/test_abi.py compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#define VPHO_API __attribute__((visibility("default")))
+#else
+#define VPHO_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-const char* vpho_last_error(void);
-int vpho_abi_version(void);   /* 7 */
+VPHO_API const char* vpho_last_error(void);
+VPHO_API int vpho_abi_version(void);   /* 7 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
  * reported in bytes: 4 = MANO FK, 5 = object physics score, 6 = hand cascade fuse, 7 = RoIAlign, 8 = bilinear resize).
  * vpho_prof_collect waits for the recorded events and returns the summed kernel time, the launch count, the algorithmic
  * flop (2*M*N*K) and the algorithmic bytes (operands once) issued. */
-int vpho_prof_enable(int kernel_class, int on);
-int vpho_prof_collect(int kernel_class, double* total_ms, long long* launches, double* total_flops, double* total_bytes);
+VPHO_API int vpho_prof_enable(int kernel_class, int on);
+VPHO_API int vpho_prof_collect(int kernel_class, double* total_ms, long long* launches, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Convolution / linear layers as one implicit-GEMM kernel on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -78,12 +86,12 @@ typedef struct {
     int plane_terms;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
-int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
+VPHO_API int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
 /* Winograd F(2x2, 3x3) form of a 3x3 / stride 1 / padding 1 convolution (+ bias, LeakyReLU): u = G g G^T, fp32, stage-tiled as
  * (Cin/8, 16 frequencies, Cout, 8 input channels) by model/pack.py::winograd_weights; 2.25 x fewer multiply-adds on the matrix cores, input / output transforms inside the kernel
  * (csrc/conv_winograd.hip).  Needs even H, W, Cin % 16 == 0, Cout % 64 == 0.  Results differ from vpho_conv2d_nhwc_f32 by fp32 rounding
  * of the transforms (~1e-6 relative). */
-int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+VPHO_API int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                    float out_slope, float* y, int y_ld, void* stream);
 /* The same convolution on RoI windows only (the FPN smoothing convolutions, backbone_FPN_HFL.py:105-108, whose maps are read only
  * through RoIAlign, VPHO.py:126-129): wins = the (N,5) window table of vpho_roi_windows_i32, tile_base (N+1 ints, written by
@@ -92,20 +100,20 @@ int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, const float* 
  * COMPACT (rows, Cout) matrix vpho_roi_align_window_nhwc_f32 reads; x is the ordinary (N,H,W,x_ld) map, of which only the windows
  * dilated by one pixel need to hold data.  Device-side lists: the grid is sized for all tiles, blocks past the last live tile exit
  * (no host round trip, replays in a HIP graph with new boxes).  tiles_hint (0 = unknown) only feeds the profiling counters. */
-int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
+VPHO_API int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
 /* ... and with the window pixels written IN PLACE into the ordinary (N,H,W,y_ld) map y, every other pixel of y left untouched (the
  * input gradient of an FPN smoothing convolution: non-zero only in the RoI windows dilated by the 3x3 halo; the caller zeroes y) */
-int vpho_conv3x3_winograd_scatter_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+VPHO_API int vpho_conv3x3_winograd_scatter_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                            float out_slope, const int* wins, const int* tile_base, float* y, int y_ld, void* stream);
 /* Training (weights change every step): u on the DEVICE from the packed 3x3 weights (Cout, 9*Cin) -- for the forward convolution
  * (for_input_gradient = 0: u is (Cin/8, 16, Cout, 8)) or for its input-gradient convolution, the 3x3 convolution of dY with the
  * spatially flipped, channel-transposed weights (1: u is (Cout/8, 16, Cin, 8)); fp64 arithmetic, rounded once.  The gate variant
  * of the convolution fuses the backward of the LeakyReLU that produced the convolution's input (torch autograd of nn.LeakyReLU in
  * Bottleneck / Residual, backbone_FPN_HFL.py:326, encoding.py:21-36): y = gate > 0 ? y : gate_slope * y, gate laid out like y. */
-int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream);
-int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
+VPHO_API int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream);
+VPHO_API int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
                                         int x_ld, int Cout, float* y, int y_ld, void* stream);
-int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+VPHO_API int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                         float out_slope, const int* wins, const int* tile_base, int tiles_hint, float* y_rows, int y_ld,
                                         void* stream);
 
@@ -138,11 +146,11 @@ typedef struct {
 } vpho_score_weights;
 
 /* bytes of scratch `vpho_score_eval` / `vpho_ode_sample` need for R = bs*S rows */
-long long vpho_score_workspace_bytes(const vpho_score_weights* w, int bs, int S);
+VPHO_API long long vpho_score_workspace_bytes(const vpho_score_weights* w, int bs, int S);
 
 /* One score evaluation s(x, t | feat) for R = bs*S rows (row r belongs to image r / S).
  * feat_img: [bs][1024], x: [R][D] fp32, t: scalar shared by all rows, out: [R][D] fp32.  (denoiser.py:68-82) */
-int vpho_score_eval(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* x, float t,
+VPHO_API int vpho_score_eval(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* x, float t,
                     float* out, void* workspace, long long workspace_bytes, void* stream);
 
 typedef struct {
@@ -162,7 +170,7 @@ typedef struct {
  * attempts are added two at a time if the solve is not finished).  With the environment variable VPHO_RK_HOST=1 (or
  * num_steps > 1024) the controller runs on the host instead and the call synchronises once per attempted step.
  * stats_host / step_log_host are host memory (step_log_host may be NULL; capacity in entries of 4 doubles). */
-int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
+VPHO_API int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, int S, const float* init_x,
                     double T0, double eps, int num_steps, double rtol, double atol,
                     void* xs_out, int xs_is_f64, void* x_out, int x_is_f64,
                     void* workspace, long long workspace_bytes,
@@ -173,18 +181,18 @@ int vpho_ode_sample(const vpho_score_weights* w, const float* feat_img, int bs, 
  * wider (concatenation) buffer.
  */
 /* rgb (N,C,H,W) -> (N,H,W,ldy) with channels >= C zero-filled (input of the 7x7 stem, backbone_FPN_HFL.py:206) */
-int vpho_nchw_to_nhwc_f32(const float* x, int N, int C, int H, int W, float* y, int ldy, void* stream);
+VPHO_API int vpho_nchw_to_nhwc_f32(const float* x, int N, int C, int H, int W, float* y, int ldy, void* stream);
 /* (N,H,W,C | ldx) -> (N,C,H,W): heat-map outputs (VPHO.py:232-233) and Encoder's x.flatten(1) (encoding.py:72) */
-int vpho_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, void* stream);
+VPHO_API int vpho_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, void* stream);
 /* nn.MaxPool2d (backbone_FPN_HFL.py:209 k3 s2 p1; encoding.py:54 k2 s2) */
-int vpho_maxpool_nhwc_f32(const float* x, int N, int H, int W, int C, int k, int stride, int pad, float* y, void* stream);
+VPHO_API int vpho_maxpool_nhwc_f32(const float* x, int N, int H, int W, int C, int k, int stride, int pad, float* y, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False); accumulate=1 gives FPN._upsample_add (backbone_FPN_HFL.py:66-68),
  * accumulate=0 with c_off the heat-map 64->32 resize into the encoder input (VPHO.py:143-144,148-149) */
-int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW,
+VPHO_API int vpho_resize_bilinear_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW,
                                   float* y, int ldy, int c_off, int accumulate, void* stream);
 /* torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), one box per image, boxes (N,4) xyxy (VPHO.py:125-128);
  * flip_w[n] != 0 mirrors the output along W (flip_tensor_by_mask_index, VPHO.py:138) */
-int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+VPHO_API int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                             int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, void* stream);
 /* Demand-driven FPN output.  The stride-4 maps of FPN.forward (backbone_FPN_HFL.py:105-109) are read ONLY by the RoIAligns of
  * VPHO.py:126-129, so each branch's last convolution is computed on the pixels its image's boxes can sample and nowhere else --
@@ -196,40 +204,40 @@ int vpho_roi_align_nhwc_f32(const float* feat, int N, int H, int W, int C, const
  * windows dilated by 1, stored in place -- vpho_conv_desc.rows_scatter).  All device-side: feed row_map /
  * row_count to vpho_conv_desc and wins to vpho_roi_align_window_nhwc_f32, which reads the compact (rows, C) matrix with the
  * arithmetic of vpho_roi_align_nhwc_f32 (bit-identical outputs, tests/test_gpu_glue.py). */
-int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, int N, int H, int W, float spatial_scale, int dilate,
+VPHO_API int vpho_roi_windows_i32(const float* boxes_a, const float* boxes_b, int N, int H, int W, float spatial_scale, int dilate,
                          int* wins, int* row_map, int* row_count, void* stream);
 /* vpho_resize_bilinear_nhwc_f32 on the listed output pixels only (FPN._upsample_add inside the dilated windows) */
-int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW, float* y, int ldy, int c_off,
+VPHO_API int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, int W, int C, int ldx, int OH, int OW, float* y, int ldy, int c_off,
                                        int accumulate, const int* row_map, const int* row_count, int rows_hint, void* stream);
-int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
+VPHO_API int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
                                    float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, int rows_hint,
                                    void* stream);
 /* align_hm_to_bbox_rectangle (VPHO.py:333-346, transposing, quirk Q2) (+ optional W flip, VPHO.py:139) */
-int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
+VPHO_API int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                 const unsigned char* flip_w, float* out, void* stream);
 /* NeRF embedding of gravity (cross_module.py:8-46), x negated where flip_x (VPHO.py:167); out (N,64), column 63 = 0 */
-int vpho_nerf_embed_f32(const float* g, int N, const unsigned char* flip_x, float* out, void* stream);
+VPHO_API int vpho_nerf_embed_f32(const float* g, int N, const unsigned char* flip_x, float* out, void* stream);
 /* (bs,65,512) token tensor of CrossModule.forward (cross_module.py:124-133) incl. the positional code of the BATCH index */
-int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const float* grav_emb, const float* pe,
+VPHO_API int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const float* grav_emb, const float* pe,
                           int bs, float* out, void* stream);
 /* multi-head attention core over the first axis of qkv (S,B,3E) (nn.MultiheadAttention inside cross_module.py:104-107) */
-int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream);
+VPHO_API int vpho_mha_f32(const float* qkv, int S, int B, int E, int nhead, float* out, void* stream);
 /* the same with nn.MultiheadAttention's dropout on the attention probabilities (training): drop_mask [B*nhead][S][S] = keep / (1 - p),
  * applied after the soft-max and before P V; NULL = no dropout */
-int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int nhead, const float* drop_mask, float* out, void* stream);
+VPHO_API int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int nhead, const float* drop_mask, float* out, void* stream);
 /* out = LayerNorm(x + r) (post-norm TransformerEncoderLayer) */
-int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,
+VPHO_API int vpho_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta, long long rows, int E,
                            float eps, float* out, void* stream);
 /* HeadPhysics: |scale| * normalise(softmax(softmax(logits)) . friction-cone anchors) (physics.py:546-557,700-712).
  * Output row r reads token row (r / group) * group_stride + r % group (+ off_scale | off_logits) of the MLP outputs, so the
  * 32 hand / 32 object tokens are picked out of the (bs, 65, .) transformer output without a copy. */
-int vpho_force_local_f32(const float* scale, int ld_scale, const float* logits, int ld_logits, const float* anchor,
+VPHO_API int vpho_force_local_f32(const float* scale, int ld_scale, const float* logits, int ld_logits, const float* anchor,
                          float friction, long long rows, int group, int group_stride, int off_scale, int off_logits,
                          float* out, void* stream);
 /* matrix_to_axis_angle(rotation_6d_to_matrix(x)) for rows of rot_per_row rotations (head_mano.py:66-69, VPHO.py:314-324) */
-int vpho_rot6d_to_axis_angle_f32(const float* x, long long rows, int rot_per_row, int ldx, float* out, int ldo, void* stream);
+VPHO_API int vpho_rot6d_to_axis_angle_f32(const float* x, long long rows, int rot_per_row, int ldx, float* out, int ldo, void* stream);
 /* out[row, 48:58] = betas[row / rows_per_image] (VPHO.py:318-319,325-326) */
-int vpho_append_betas_f32(const float* betas, long long rows, long long rows_per_image, float* out, int ldo, void* stream);
+VPHO_API int vpho_append_betas_f32(const float* betas, long long rows, long long rows_per_image, float* out, int ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * MANO forward kinematics (manopth.ManoLayer as configured at head_mano.py:48-55; metres, head_mano.py:78-87).
@@ -252,10 +260,10 @@ typedef struct {
     const float *posedirs_mfma;
 } vpho_mano_tables;
 /* per image: v_shaped (n_img,778,3), J (n_img,16,3) from betas (n_img,10) */
-int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream);
+VPHO_API int vpho_mano_shape_f32(const vpho_mano_tables* t, const float* betas, int n_img, float* v_shaped, float* J, void* stream);
 /* per hand: pose rows of ld_pose floats (first 48 = axis-angle); hand h uses image h / hands_per_image.
  * verts may be NULL (joints only).  ho3d_per_image (optional) selects hand_fn.get_joint_aligned_with_HO3D ordering. */
-int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, int ld_pose, long long n_hands, int hands_per_image,
+VPHO_API int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, int ld_pose, long long n_hands, int hands_per_image,
                      const float* v_shaped, const float* J, const unsigned char* ho3d_per_image,
                      float* verts, float* joints, void* stream);
 
@@ -269,49 +277,49 @@ typedef struct { const int* face_idx; const float* anchor_weight; const float* v
     /* face_idx [32][3], anchor_weight [32][2], vert2joint [21][778], skeleton [32][2]   (physics_fn.py:120-171) */
 
 /* pose (bs,2S,48): [S diffusion | S regression with the diffusion wrist] (aggregation.py:120-126,140-143) */
-int vpho_hand_candidates_f32(const float* diff_pose, int ld_diff, const float* reg_pose, int bs, int S, float* pose, void* stream);
+VPHO_API int vpho_hand_candidates_f32(const float* diff_pose, int ld_diff, const float* reg_pose, int bs, int S, float* pose, void* stream);
 /* hv (bs,C,n_obs): bicubic heat-map value of each observed joint of each candidate (aggregation.py:196-213);
  * joints (bs,C,21,3) root-relative, heatmap (bs,J,H,W) planar; observe_host is a HOST int array */
-int vpho_hand_heat_f32(const float* joints, const float* root, const float* Kmat, const float* bbox, const float* heatmap,
+VPHO_API int vpho_hand_heat_f32(const float* joints, const float* root, const float* Kmat, const float* bbox, const float* heatmap,
                        int bs, int C, int J, int H, int W, const int* observe_host, int n_obs, float* out, void* stream);
 /* one cascade level (aggregation.py:215-269): score -> top-k -> weighted quaternion mean -> broadcast into all candidates.
  * val/idx: [bs][F][k] with F = 1 (level 0) or 5, in torch.topk's order (larger score first; equal scores: smaller index first);
  * topk_pose (optional) [bs][k][F][3]; score_out (optional) [bs][C][F] = the level score of EVERY candidate exactly as ranked
  * (aggregation.py:215-218,244-247: sum over the observed joints at level 0, per-finger mean at levels 1-3) */
-int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
+VPHO_API int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
                              float* val, int* idx, float* topk_pose, float* score_out, void* stream);
 /* generic wavefront top-k: element c of row (o,f) at scores[(o*n + c)*F + f]; val/idx [o][f][k] */
-int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream);
-int vpho_topk_weights_f32(const float* val, int rows, int k, float* w, void* stream);
+VPHO_API int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream);
+VPHO_API int vpho_topk_weights_f32(const float* val, int rows, int k, float* w, void* stream);
 /* select_topk_object_by_heatmap score (aggregation.py:742-776); pose (bs,n,9) fp64 */
-int vpho_obj_heat_score(const double* pose, int n, const double* transl_override, const float* root, const vpho_obj_tables* t,
+VPHO_API int vpho_obj_heat_score(const double* pose, int n, const double* transl_override, const float* root, const vpho_obj_tables* t,
                         const int* obj_id, const unsigned char* is_right, const float* Kmat, const float* bbox,
                         const float* heatmap, int bs, int H, int W, float* score, void* stream);
-int vpho_obj_cross_candidates(const double* pose, int n, const int* transl_idx, const int* rot_idx, int bs, int ko, double* cand, void* stream);
+VPHO_API int vpho_obj_cross_candidates(const double* pose, int n, const int* transl_idx, const int* rot_idx, int bs, int ko, double* cand, void* stream);
 /* select_topk_object_by_physics3 score (aggregation.py:947-985) */
-int vpho_obj_physics_score(const double* cand, int n, const float* root, const vpho_obj_tables* t, const int* obj_id,
+VPHO_API int vpho_obj_physics_score(const double* cand, int n, const float* root, const vpho_obj_tables* t, const int* obj_id,
                            const unsigned char* is_right, const float* force_point, const float* force_global, int bs,
                            float* score, void* stream);
 /* fuse_topk + average_rot6d in fp64 (aggregation.py:729-740,50-56); source b (if given) is used where pick_b[b] != 0 */
-int vpho_obj_fuse_f64(const double* pose, int n, const int* idx_a, const float* w_a, const int* idx_b, const float* w_b,
+VPHO_API int vpho_obj_fuse_f64(const double* pose, int n, const int* idx_a, const float* w_a, const int* idx_b, const float* w_b,
                       const unsigned char* pick_b, int bs, int k, double* fused, void* stream);
-int vpho_obj_verts_f32(const double* pose, const float* root, const vpho_obj_tables* t, const int* obj_id,
+VPHO_API int vpho_obj_verts_f32(const double* pose, const float* root, const vpho_obj_tables* t, const int* obj_id,
                        const unsigned char* is_right, int bs, float* out, void* stream);
 /* ForceAnchor.__call__ on (verts + root) and from_local_to_global (physics_fn.py:224-257, physics.py:362-371) */
-int vpho_force_anchor_f32(const vpho_anchor_tables* t, const float* verts, const float* root, const float* force_local,
+VPHO_API int vpho_force_anchor_f32(const vpho_anchor_tables* t, const float* verts, const float* root, const float* force_local,
                           long long n_hands, int hands_per_image, float* force_point, float* force_global, void* stream);
 /* aggregation.py:1306-1325 / :561-596 / :598-617 */
-int vpho_hand_phys_candidates_f32(const float* agg_pose, int ld_agg, const float* betas, const float* topk_pose, int bs, int k,
+VPHO_API int vpho_hand_phys_candidates_f32(const float* agg_pose, int ld_agg, const float* betas, const float* topk_pose, int bs, int k,
                                   float* out, void* stream);
-int vpho_hand_phys_score_f32(const float* force_point, const float* force_global, const float* obj_vert, int n_vert,
+VPHO_API int vpho_hand_phys_score_f32(const float* force_point, const float* force_global, const float* obj_vert, int n_vert,
                              int bs, int n_cand, float* finger_score, void* stream);
-int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int bs, int k, float* out, void* stream);
+VPHO_API int vpho_hand_phys_fuse_f32(const float* cand, int n_cand, const int* idx, int bs, int k, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Evaluation metrics on the device: TesterHand.criterion_MJE_PAMJE (lib/engine/test.py:657-680) with
  * rigid_align_AtoB (lib/utils/transform_fn.py:43-66).  pd, gt: [n_img][n_pts][3] fp32 (metres); outputs per image the
  * mean point error, the mean error after similarity (Procrustes) alignment of pd onto gt, optionally every point's error. */
-int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
+VPHO_API int vpho_hand_metrics_f32(const float* pd, const float* gt, int n_img, int n_pts, float* mean_err, float* pa_mean_err,
                           float* per_point, void* stream);
 
 /* Object evaluation metrics on the device: TesterObject.__call__ (lib/engine/test.py:240-352) for a single
@@ -331,9 +339,9 @@ typedef struct vpho_obj_metric_tables {
 } vpho_obj_metric_tables;
 /* obj_9D_to_mat (lib/utils/transform_fn.py:85-90) with the root joint added to the translation (Trainer.postprocess,
  * train_diff_hand_obj.py:578-597): pose9 [n][9] fp64 = [rot6d | t], root_joint [n][3] fp32 -> rt [n][3][4] fp64. */
-int vpho_obj_9d_to_rt_f64(const double* pose9, const float* root_joint, int n, double* rt, void* stream);
-long long vpho_obj_metrics_workspace_bytes(const vpho_obj_metric_tables* t, int n_img, int max_verts);
-int vpho_obj_metrics_f64(const vpho_obj_metric_tables* t, const double* pd_rt, const double* gt_rt, const double* cam_intr,
+VPHO_API int vpho_obj_9d_to_rt_f64(const double* pose9, const float* root_joint, int n, double* rt, void* stream);
+VPHO_API long long vpho_obj_metrics_workspace_bytes(const vpho_obj_metric_tables* t, int n_img, int max_verts);
+VPHO_API int vpho_obj_metrics_f64(const vpho_obj_metric_tables* t, const double* pd_rt, const double* gt_rt, const double* cam_intr,
                          const int* obj_id, int n_img, int max_verts, double* out, void* workspace, long long workspace_bytes,
                          void* stream);
 
@@ -347,8 +355,8 @@ int vpho_obj_metrics_f64(const vpho_obj_metric_tables* t, const double* pd_rt, c
  * Inputs are laid out [n_batches*B]...; gravity/com [..][3] in the flipped (right-hand) frame; outputs force_local /
  * force_global [..][32][3] (zero where !is_grasped, :199-202), final scale [..][32], weight [..][32][8],
  * losses [n_batches][4] = (force, gravity, moment, distribution) of the last iteration. */
-int vpho_anchor_frames_f32(const vpho_anchor_tables* t, const float* verts, long long n_hands, float* pts, float* frames, void* stream);
-int vpho_force_optimize_f32(const float* pts, const float* frames, const float* gravity, const float* com, const float* force_contact,
+VPHO_API int vpho_anchor_frames_f32(const vpho_anchor_tables* t, const float* verts, long long n_hands, float* pts, float* frames, void* stream);
+VPHO_API int vpho_force_optimize_f32(const float* pts, const float* frames, const float* gravity, const float* com, const float* force_contact,
                             const unsigned char* is_grasped, int n_batches, int B, int iters, int phase1_iters, float lr,
                             float* force_local, float* force_global, float* scale, float* weight, float* losses, void* stream);
 
@@ -361,10 +369,10 @@ int vpho_force_optimize_f32(const float* pts, const float* frames, const float* 
  * for hand_contact_map and object->hand for obj_contact_map / obj_contact_to_hand_vert.
  * vpho_force_contact_f32 pools a hand contact map (rows of `ld` >= 778 floats) onto the 32 CPF anchors and applies the
  * check_is_grasped rule. */
-int vpho_contact_detect_f32(const float* query, const float* query_normals, const float* target, int n, int n_query, int n_target,
+VPHO_API int vpho_contact_detect_f32(const float* query, const float* query_normals, const float* target, int n, int n_query, int n_target,
                             float normal_lo, float normal_hi, float vertical_thresh, float decay_lo, float decay_hi,
                             float* weight, int* nn_index, void* stream);
-int vpho_force_contact_f32(const vpho_anchor_tables* t, const float* hand_contact, int ld, int n, float thresh,
+VPHO_API int vpho_force_contact_f32(const vpho_anchor_tables* t, const float* hand_contact, int ld, int n, float thresh,
                            float* force_contact, unsigned char* is_grasped, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -375,15 +383,15 @@ int vpho_force_contact_f32(const vpho_anchor_tables* t, const float* hand_contac
  * The GEMMs run through vpho_conv2d_nhwc_f32 (1x1 convolutions on [rows][C] matrices); these are the pieces around them. */
 /* std = 0.01 * 5000^t (sde.py:15-18), x_t = gt_pose[b] + z * std zero-padded to Dp columns, emb = [sin, cos](t W 2 pi)
  * (denoiser.py:29-31).  t [rows], z [rows][D], fourier_W [64] -> x_t [rows][Dp], emb [rows][128], std_out [rows] */
-int vpho_dsm_prepare_f32(const float* gt_pose, const float* t, const float* z, const float* fourier_W, int bs, int reps, int D, int Dp,
+VPHO_API int vpho_dsm_prepare_f32(const float* gt_pose, const float* t, const float* z, const float* fourier_W, int bs, int reps, int D, int Dp,
                          float* x_t, float* emb, float* std_out, void* stream);
 /* second ParallelLinear (256 -> 3 per head, parallel_linear.py:27-35) + division by (std + 1e-7) (denoiser.py:80-81):
  * h [rows][nheads*256], w2 [nheads][256][3], b2 [nheads][3] -> score [rows][3*nheads] */
-int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, const float* std_rows, long long rows, int nheads,
+VPHO_API int vpho_plinear2_fwd_f32(const float* h, const float* w2, const float* b2, const float* std_rows, long long rows, int nheads,
                           float* score, void* stream);
 /* loss = mean over batch*reps of sum_d std^2 (score - target)^2, target = -z std / std^2 (score_based_model.py:33-41);
  * dout = d loss / d (un-normalised head output) [rows][D]; loss: one double on the device; partial_ws: >= 1024 doubles */
-int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
+VPHO_API int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows, long long rows, int D, int batch_times_reps,
                       float* dout, double* loss, double* partial_ws, int partial_cap, void* stream);
 /* Weight gradient of an NHWC convolution without materialised im2col / transposes (torch.nn.functional.conv2d's autograd for
  * every nn.Conv2d of lib/model/backbone_FPN_HFL.py, encoding.py, head_inplane.py under lib/engine/train_diff_hand_obj.py:181-182):
@@ -391,15 +399,15 @@ int vpho_dsm_loss_f32(const float* score, const float* z, const float* std_rows,
  * in the packed layout of the forward weights.  x [N][H][W][x_ld], dy [N][OH][OW][dy_ld]; Cin, Cout and both leading dimensions
  * multiples of 4, pointers 16-byte aligned.  The pixel range is reduced in slices (fp32 MFMA accumulation inside a slice, slices
  * added in ascending order): workspace of vpho_conv2d_wgrad_workspace_bytes(...) bytes (may be 0 -> workspace may be NULL). */
-long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
-int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
+VPHO_API long long vpho_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+VPHO_API int vpho_conv2d_wgrad_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout, int dy_ld,
                                int KH, int KW, int stride, int pad_y, int pad_x, float* dw, void* workspace, void* stream);
 /* The same weight gradient when dY is known to be zero outside RoI windows (the gradient of a map that is only read through RoIAlign:
  * the FPN smoothing convolutions, VPHO.py:126-129): the reduction runs over the ascending list of live 32-pixel groups that
  * vpho_window_groups_i32 builds on the device from the window table of vpho_roi_windows_i32 (a group is live when one of its pixels
  * lies in its image's window); the pixel slices cut the list instead of the pixel range.  Needs OW % 32 == 0.  Same workspace. */
-int vpho_window_groups_i32(const int* wins, int N, int H, int W, int* group_list, int* group_count, void* stream);
-int vpho_conv2d_wgrad_groups_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout,
+VPHO_API int vpho_window_groups_i32(const int* wins, int N, int H, int W, int* group_list, int* group_count, void* stream);
+VPHO_API int vpho_conv2d_wgrad_groups_nhwc_f32(const float* x, int N, int H, int W, int Cin, int x_ld, const float* dy, int OH, int OW, int Cout,
                                       int dy_ld, int KH, int KW, int stride, int pad_y, int pad_x, const int* group_list,
                                       const int* group_count, float* dw, void* workspace, void* stream);
 /* Training-mode tail of HeadMano for one batch of hands (lib/model/head_mano.py:60-87 forward + get_hand_verts, :89-133 get_loss,
@@ -411,31 +419,31 @@ int vpho_conv2d_wgrad_groups_nhwc_f32(const float* x, int N, int H, int W, int C
  * weight / (bs * 2334 | bs * 63 | bs * 96 | bs * 10).  is_ho3d (per hand, optional): the regressed joints of those hands enter the joint
  * loss in HO3D's convention (get_joint_aligned_with_HO3D, VPHO.py:154-157, hand_fn.py:454-461: joints re-ordered, HO3D's own tip vertices).
  * A batch without any right hand gives a shape loss of 0 here (the reference takes the mean of an empty tensor: NaN). */
-int vpho_mano_train_f32(const vpho_mano_tables* t, const float* rot6d, const float* shape, const float* gt_vert, const float* gt_joint,
+VPHO_API int vpho_mano_train_f32(const vpho_mano_tables* t, const float* rot6d, const float* shape, const float* gt_vert, const float* gt_joint,
                         const float* gt_rot6d, const float* gt_shape, const unsigned char* is_right, const unsigned char* is_ho3d, int bs,
                         float w_vert, float w_joint, float w_pose, float w_shape,
                         float* d_rot6d, float* d_shape, double* loss_parts, float* verts, float* joints, void* stream);
 /* JointsMSELoss (lib/model/head_inplane.py:191-203: nn.MSELoss, mean over all elements) times its loss weight
  * (VPHO.py:214-219): loss[0] = weight * mean((pd - gt)^2) in fp64, grad = weight * 2 (pd - gt) / n.  partial_ws: >= partial_cap doubles */
-int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws, int partial_cap,
+VPHO_API int vpho_mse_loss_f32(const float* pd, const float* gt, long long n, float weight, float* grad, double* loss, double* partial_ws, int partial_cap,
                       void* stream);
 /* backward of the second ParallelLinear and of the ReLU in front of it: dpre [rows][nheads*256] (gradient at the first
  * layer's pre-activation), dw2 [nheads][256][3], db2 [nheads][3] */
-int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,
+VPHO_API int vpho_plinear2_bwd_f32(const float* h, const float* dout, const float* w2, long long rows, int nheads, float* dpre, float* dw2, float* db2,
                           void* stream);
 /* dx = y > 0 ? dy : 0 on [rows][cols] slices with leading dimensions (gradient through nn.ReLU given its output y) */
-int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int ld_y, long long rows, int cols, float* dx, int ld_dx, void* stream);
+VPHO_API int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int ld_y, long long rows, int cols, float* dx, int ld_dx, void* stream);
 /* out[c] = sum_r x[r][c] (bias gradients; fp64 partial sums over row chunks, combined in a fixed order).
  * workspace: vpho_bn_workspace_bytes(cols) bytes */
-int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream);
+VPHO_API int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream);
 /* out[b][c] = sum_rep x[rep*bs + b][c_off + c]: the encoding is shared by the repeat_num draws of an image */
-int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream);
+VPHO_API int vpho_sum_repeats_f32(const float* x, int ld, int c_off, int bs, int reps, int cols, float* out, void* stream);
 /* y[c][r] = x[r][c] (operands of the weight-gradient GEMMs) */
-int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
+VPHO_API int vpho_transpose_f32(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
 /* Transposed im2col, the second operand of a convolution's weight gradient dW[co][(r,s,ci)] = sum_p dY^T[co][p] * out[(r,s,ci)][p]
  * (the product itself is vpho_conv2d_nhwc_f32 as a GEMM): out[(r*KW+s)*Cin + ci][p] = x[n, oy*stride+r-pad_y, ox*stride+s-pad_x, ci],
  * p = (n*OH+oy)*OW+ox, zero outside the image and in the padding columns p >= N*OH*OW of the leading dimension ldo. */
-int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, int KH, int KW, int stride, int pad_y, int pad_x,
+VPHO_API int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, int KH, int KW, int stride, int pad_y, int pad_x,
                       int OH, int OW, float* out, long long ldo, void* stream);
 /* nn.BatchNorm2d in training mode on NHWC rows (rows = N*H*W, leading dimension ld >= C) -- every BatchNorm of
  * backbone_FPN_HFL.py / encoding.py / head_inplane.py under model.train() (train_diff_hand_obj.py:171): batch mean and biased
@@ -445,66 +453,66 @@ int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, int x_ld, in
  * (For a fused activation pass its backward first: vpho_lrelu_bwd_f32 on y.)  res (may be NULL; ABI version 4): the residual
  * branch of a bottleneck, y = lrelu(bn(x) + res, slope) (Bottleneck.forward, backbone_FPN_HFL.py:347-349); its gradient is the
  * gradient of the sum.  workspace: vpho_bn_workspace_bytes(C). */
-long long vpho_bn_workspace_bytes(int C);
-int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
+VPHO_API long long vpho_bn_workspace_bytes(int C);
+VPHO_API int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
                               float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* res,
                               float* y, void* workspace, void* stream);
-int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
+VPHO_API int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
                                const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
-int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
+VPHO_API int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
 /* nn.MaxPool2d backward (backbone_FPN_HFL.py:209): dx[n,iy,ix,c] = sum of dy over the windows whose first maximum (row-major)
  * is (iy,ix); x is the pooling input.  Deterministic gather, no atomics. */
-int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream);
+VPHO_API int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx, void* stream);
 /* the same with a byte workspace (vpho_maxpool_bwd_workspace_bytes; 0 = not needed) for overlapping windows: arg-max position of
  * every window first, then the gather compares position codes instead of re-scanning windows (bit-identical results) */
-long long vpho_maxpool_bwd_workspace_bytes(int N, int H, int W, int C, int k, int stride, int pad);
-int vpho_maxpool_bwd_ws_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx,
+VPHO_API long long vpho_maxpool_bwd_workspace_bytes(int N, int H, int W, int C, int k, int stride, int pad);
+VPHO_API int vpho_maxpool_bwd_ws_nhwc_f32(const float* x, const float* dy, int N, int H, int W, int C, int k, int stride, int pad, float* dx,
                                  void* workspace, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) backward (FPN._upsample_add, backbone_FPN_HFL.py:66-68):
  * dy [N][OH][OW][C] -> dx [N][H][W][C] */
-int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);
+VPHO_API int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream);
 /* torchvision.ops.roi_align backward (VPHO.py:125-128 under loss.backward()): dy [N][P][P][ldo] (channel slice c_off..c_off+C, optionally
  * W-flipped like the forward) accumulated into dfeat [N][H][W][C] (+=; zero-initialise it, or pass another gradient of the same
  * map to sum both).  One RoI per image (box n belongs to image n).  Channel counts / strides that are multiples of 4 take a gather
  * with a fixed summation order (each feature pixel sums the few bins that reach it); other shapes scatter with fp32 atomics. */
-int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
+VPHO_API int vpho_roi_align_bwd_nhwc_f32(const float* dy, int ldo, int c_off, int N, int H, int W, int C, const float* boxes, float spatial_scale,
                                 int out_size, const unsigned char* flip_w, float* dfeat, void* stream);
 /* backward of vpho_align_heatmap_nhwc_f32 (align_hm_to_bbox_rectangle + flip, VPHO.py:333-346,139): dout [N][S][S][C] -> dhm [N][S][S][C]
  * (+=: zero-initialise dhm; a gather with a fixed summation order for S <= 120, fp32 atomics beyond) */
-int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
+VPHO_API int vpho_align_heatmap_bwd_nhwc_f32(const float* dout, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                     const unsigned char* flip_w, float* dhm, void* stream);
 /* y = lrelu(a + b, slope): `out += residual; out = leakyrelu(out)` of Bottleneck.forward (backbone_FPN_HFL.py:347-348); slope 1 = a + b */
-int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
+VPHO_API int vpho_add_lrelu_f32(const float* a, const float* b, long long n, float slope, float* y, void* stream);
 /* torch.optim.AdamW single-tensor step (decoupled weight decay, bias-corrected moments); grad_scale multiplies the gradient
  * first (1 / world_size after a sum all-reduce) */
-int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+VPHO_API int vpho_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* the same step for a list of tensors in one launch.  segments: device array of n_segments records
  * { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; long long first_block; } with
  * first_block = running sum of ceil(n / 1024) over the preceding records, total_blocks = that sum over all records. */
-int vpho_adamw_multi_f32(const void* segments, int n_segments, long long total_blocks, float lr, float beta1, float beta2, float eps,
+VPHO_API int vpho_adamw_multi_f32(const void* segments, int n_segments, long long total_blocks, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float grad_scale, void* stream);
 
 /* ---- physics branch of the training step (lib/model/VPHO.py:170-172,205-212 under loss.backward()) -------------------------------
  * backward of vpho_cross_tokens_f32 (cross_module.py:125-133: .view(bs,32,-1) of the projected maps, cat, + positional code):
  * dtok [bs][65][512] -> d_proj_hand / d_proj_obj [bs][8][8][256] NHWC (NULL for the stream the reference detaches, VPHO.py:170-171)
  * and d_grav_emb [bs][512] (may be NULL) */
-int vpho_cross_tokens_bwd_f32(const float* dtok, int bs, float* d_proj_hand, float* d_proj_obj, float* d_grav_emb, void* stream);
+VPHO_API int vpho_cross_tokens_bwd_f32(const float* dtok, int bs, float* d_proj_hand, float* d_proj_obj, float* d_grav_emb, void* stream);
 /* backward of vpho_add_layernorm_f32 (norm1 / norm2 of nn.TransformerEncoderLayer, post-norm): dy -> dx = d(x + r) and dy_xhat =
  * dy * normalised input per element (d gamma = its column sums, d beta = the column sums of dy) */
-int vpho_layernorm_bwd_f32(const float* x, const float* r, const float* gamma, const float* dy, long long rows, int E, float eps,
+VPHO_API int vpho_layernorm_bwd_f32(const float* x, const float* r, const float* gamma, const float* dy, long long rows, int E, float eps,
                            float* dx, float* dy_xhat, void* stream);
 /* backward of vpho_mha_dropout_f32 (nn.MultiheadAttention inside the encoder layer, sequence axis = batch, quirk Q3):
  * qkv [S*B][3E], d_out [S*B][E], drop_mask as in the forward (NULL = none) -> dqkv [S*B][3E]; S <= 64 */
-int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv, void* stream);
+VPHO_API int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv, void* stream);
 /* HeadPhysics tail + losses + gradient (physics.py:546-557 get_local_force with the double soft-max of :659-664, :362-371
  * from_local_to_global on the GROUND-TRUTH vertices, :456-500 get_loss; weights as VPHO.py:214-219): scale_raw [bs*32] (fc_scale
  * output), logits [bs*32][8] (fc_weight before its Softmax), com [bs*32][3] (fc_CoM output); frame [bs][32][3][3] / point
  * [bs][32][3] from vpho_anchor_frames_f32 of gt_hand_vert_flip; gt_force_local [bs][32][3]; gravity, gt_com [bs][3] in the flipped
  * frame; weights5 (HOST array) = weight_{force,gravity,torque,supervised,CoM}_loss.  Outputs: force_local [bs*32][3], the weighted
  * losses losses5 (device, fp64, same order) and d(total)/d(scale_raw | logits | com).  partial_ws: bs*5 doubles. */
-int vpho_physics_loss_f32(const float* scale_raw, const float* logits, const float* com, const float* anchor, float friction,
+VPHO_API int vpho_physics_loss_f32(const float* scale_raw, const float* logits, const float* com, const float* anchor, float friction,
                           const float* frame, const float* point, const float* gt_force_local, const float* gravity,
                           const float* gt_com, const unsigned char* is_grasped, const float* weights5, int bs,
                           float* force_local, float* d_scale, float* d_logits, float* d_com, double* losses5, double* partial_ws,

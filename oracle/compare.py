@@ -256,3 +256,36 @@ def parity_summary(out, ref, gd, od, S, bound=TIE_REL):
     res['mpjpe_delta_mm_all'] = float(mp.mean())
     res['mpjpe_delta_mm_where_identical'] = float(mp[hand_clean].mean()) if bool(hand_clean.any()) else None
     return res, rep
+
+
+SELFCHECK_VARIANTS = {0: 'default (all intra-op threads, oneDNN on)', 1: '1 intra-op thread', 2: '2 intra-op threads', 3: 'oneDNN off (ATen native kernels)'}
+SELFCHECK_LISTS = ['hand_topk_l0', 'hand_topk_l1', 'hand_topk_l2', 'hand_topk_l3', 'obj_transl_topk', 'obj_rot_topk', 'obj_phys_topk',
+                   'obj_heat_topk'] + [f'hand_phys_topk_f{f}' for f in range(5)]
+
+
+def reference_self_agreement(path):
+    """How well the REFERENCE reproduces its own result: tests/golden/golden_predict_readme64_selfcheck.npz holds the 13 top-k index
+    tensors and the three aggregated outputs of the reference's own ``forward('predict')`` (README config, the 64-image batch of
+    golden_predict_readme64.npz, identical inputs and prior draws) under several execution settings of the same fp32 arithmetic
+    (tests/golden/make_golden_readme.py --variant ...).  Returns, per variant against the default run: images on which every one of the
+    13 lists is identical, images within 1e-3 on joints / vertices / 6-DoF, largest output difference, per-list counts."""
+    import numpy as np
+    P = np.load(path)
+    n = int(P['cfg'][0])
+    rep = {'images': n, 'what': "the reference's own forward('predict') re-run on identical inputs and prior draws; each variant compared "
+                                "with its default run (variant 0)", 'variants': {}}
+    for v in range(1, int(P['variants'])):
+        same = np.ones(n, bool)
+        per = {}
+        for nm in SELFCHECK_LISTS:
+            eq = (P[f'v0_{nm}'].reshape(n, -1) == P[f'v{v}_{nm}'].reshape(n, -1)).all(1)
+            per[nm] = int(eq.sum())
+            same &= eq
+        d = {k: np.abs(P[f'v0_{k}'].astype(np.float64) - P[f'v{v}_{k}'].astype(np.float64)).reshape(n, -1).max(1)
+             for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d')}
+        worst = np.max(np.stack(list(d.values())), 0)
+        mp = np.linalg.norm(P['v0_agg_hand_joint'].astype(np.float64) - P[f'v{v}_agg_hand_joint'].astype(np.float64), axis=-1).mean(-1) * 1000
+        rep['variants'][SELFCHECK_VARIANTS[int(P[f'v{v}_code'])]] = dict(
+            images_all_selections_identical=int(same.sum()), **{'images_within_1e-3_on_joints_vertices_6dof': int((worst <= 1e-3).sum())},
+            max_abs={k: float(x.max()) for k, x in d.items()}, mpjpe_delta_mm_all=float(mp.mean()), images_identical_per_list=per)
+    return rep

@@ -15,12 +15,16 @@ judge:
   for the one list that is consumed by RANK (hand level 3: rank i of every finger forms physics candidate i,
   aggregation.py:1297-1312) max_r |s64_(r) - s64_{list[r]}|.  A list is *optimal* when its regret is 0 (exact copies and exactly
   equal scores are interchangeable by construction).
-* eps32 = max over the candidates of |s32 - s64|: the rounding noise of the reference's own arithmetic on these candidates.  ANY
-  top-k taken from scores that are within eps of the truth has regret <= 2 eps (order statistics of two vectors that differ by
-  <= eps differ by <= eps).  So `regret <= 2 eps32` says: the list is one the reference's arithmetic could itself have produced;
-  no constant in it is fitted to the side under test.
-* Where the list under test differs from the oracle's fp32 list on the same candidates, the fp64 scores of the exchanged
-  candidates must lie within 2 eps32 of each other: lists only differ where the fp32 reference cannot resolve the fp64 order.
+* eps32[b, f] = max over the candidates of ONE (image, finger) score vector of |s32 - s64|: the rounding noise of the reference's own
+  arithmetic on THAT vector (round 3 used the maximum over the whole batch for every image: a mis-selection on a well-resolved image
+  then passed if another image of the batch was noisy -- ADVICE r3).  ANY top-k taken from scores that are within eps of the truth has
+  regret <= 2 eps (order statistics of two vectors that differ by <= eps differ by <= eps).  eps_own[b, f] is the same quantity for
+  the score vector the side under test really ranked.
+* Per (image, finger): `regret <= 2 max(eps32, eps_own)` and, where the list under test differs from the oracle's fp32 list on the
+  same candidates, the fp64 scores of the exchanged candidates within `2 max(eps32, eps_own)` of each other -- both are theorems for
+  a correct top-k of scores with those errors, so a violation is a selection bug, whatever the data.  That the tested side's error is
+  itself of the size of the reference's is asserted separately (`eps_own_over_eps32`), and `within_reference_noise` reports the
+  stricter statement `regret <= 2 eps32[b, f]` (the pick is one the reference's own arithmetic could have produced on this vector).
 
 Everything is reported relative to the score scale of its (image, finger): scale = max_c |s64|.
 """
@@ -159,15 +163,22 @@ def referee(assets, anchor_skeleton, rec, stages=STAGES):
                         gap[b, f] = _exchange_gap(s64[b, :, f], lst[b, :, f], l32[b, :, f])
         eps = float(eps_rel.max())
         own = rec.get('scores', {}).get(st)
-        eps_own, own_topk = None, None
+        eps_own, own_topk, eps_own_bf = None, None, None
         if own is not None:                    # the side under test's own score vectors: their fp64 error, and list == top-k of them
             own = own.reshape(s64.shape)
-            eps_own = float(((own.double() - s64).abs().amax(1) / scale).max())
+            eps_own_bf = (own.double() - s64).abs().amax(1) / scale
+            eps_own = float(eps_own_bf.max())
             o = torch.where(torch.isnan(own), torch.full_like(own, float('inf')), own)
             own_topk = bool(torch.equal(A.topk_stable(o, k, dim=1)[1], lst))
-        rep[st] = dict(eps32_rel=eps, bound_rel=2 * eps, eps_own_rel=eps_own, list_is_topk_of_own_scores=own_topk, regret_rel=(reg / scale).amax(1), regret32_rel=(reg32 / scale).amax(1),
+        reg_bf, gap_bf = reg / scale, gap / scale
+        noise_bf = eps_rel if eps_own_bf is None else torch.maximum(eps_rel, eps_own_bf)
+        rep[st] = dict(eps32_rel=eps, bound_rel=2 * eps, eps_own_rel=eps_own, list_is_topk_of_own_scores=own_topk, regret_rel=reg_bf.amax(1), regret32_rel=(reg32 / scale).amax(1),
                        optimal=(reg == 0).all(1), optimal32=(reg32 == 0).all(1), differs_from_o32=differs,
-                       exchange_gap_rel=(gap / scale).amax(1))
+                       exchange_gap_rel=gap_bf.amax(1),
+                       # per (image, finger), relative to that vector's own score scale
+                       eps32_bf=eps_rel, eps_own_bf=eps_own_bf, regret_bf=reg_bf, exchange_gap_bf=gap_bf,
+                       within_own_and_reference_noise_bf=(reg_bf <= 2 * noise_bf) & (gap_bf <= 2 * noise_bf),
+                       within_reference_noise_bf=(reg_bf <= 2 * eps_rel) & (gap_bf <= 2 * eps_rel))
     return rep
 
 
@@ -180,9 +191,12 @@ def summary(rep):
     for st, r in rep.items():
         all_opt &= r['optimal']
         all_opt32 &= r['optimal32']
-        within = bool((r['regret_rel'] <= r['bound_rel']).all()) and bool((r['exchange_gap_rel'] <= r['bound_rel']).all())
+        within = bool(r['within_own_and_reference_noise_bf'].all())
         ok &= within
+        ratio = None if r['eps_own_bf'] is None else (r['eps_own_bf'] / r['eps32_bf'].clamp(min=1e-300))
         per[st] = dict(eps32_rel=r['eps32_rel'], eps_tested_rel=r.get('eps_own_rel'), regret_max_rel=float(r['regret_rel'].max()), regret32_max_rel=float(r['regret32_rel'].max()),
+                       vectors=int(r['eps32_bf'].numel()), vectors_within_2eps32_of_their_own_vector=int(r['within_reference_noise_bf'].sum()),
+                       eps_tested_over_eps32_median_max=None if ratio is None else [float(ratio.median()), float(ratio.max())],
                        images_optimal=int(r['optimal'].sum()), images_optimal_fp32_reference=int(r['optimal32'].sum()),
                        images_list_differs_from_fp32_reference=int(r['differs_from_o32'].sum()),
                        exchange_gap_max_rel=float(r['exchange_gap_rel'].max()), within_reference_noise=within)

@@ -4,6 +4,11 @@ import copy
 import torch
 
 BS, S, STEPS, KH, KO, T0 = 64, 100, 50, 30, 10, 0.65
+# bounds of assert_within_reference_noise; measured values are in DESIGN.md section 2(B)
+EPS_RATIO_MAX, EPS_RATIO_MEDIAN = 8.0, 2.0
+EPS32_MAX = dict(hand_level0=1e-4, hand_level1=1e-4, hand_level2=1e-4, hand_level3=2e-4, obj_transl=1e-4, obj_rot=1e-4, obj_heat=1e-4,
+                 obj_physics=1e-2, hand_physics=1e-2)
+OPTIMAL_SLACK = 4
 
 
 def run_hip(model_cpu, assets, data, nh, no, cfg_values=None):
@@ -31,14 +36,25 @@ def assert_within_reference_noise(rep, tag=''):
     for st, p in s['per_stage'].items():
         print(f'   {st:13s} eps32 {p["eps32_rel"]:.2e} (tested side {p["eps_tested_rel"] or 0:.2e})  regret HIP {p["regret_max_rel"]:.2e} / oracle {p["regret32_max_rel"]:.2e}  optimal {p["images_optimal"]}/{p["images_optimal_fp32_reference"]}'
               f'  lists differ {p["images_list_differs_from_fp32_reference"]} (exchange gap {p["exchange_gap_max_rel"]:.2e})')
+        print(f'   {"":13s} per (image, finger) vector: {p["vectors_within_2eps32_of_their_own_vector"]}/{p["vectors"]} within 2 eps32 of THEIR OWN vector; '
+              f'eps(tested) / eps32 median, max {p["eps_tested_over_eps32_median_max"]}')
     for st, r in rep.items():
         if r['list_is_topk_of_own_scores'] is not None:                # the top-k kernels: exactly the stable descending order of their own scores
             assert r['list_is_topk_of_own_scores'], st
-        assert float(r['regret_rel'].max()) <= r['bound_rel'], (st, float(r['regret_rel'].max()), r['bound_rel'])
-        assert float(r['exchange_gap_rel'].max()) <= r['bound_rel'], (st, float(r['exchange_gap_rel'].max()), r['bound_rel'])
-        # sanity: the noise of the reference's arithmetic is fp32 rounding (1e-6 ... 1e-5 of the score scale for the heat-map sums after FK and
-        # projection; ~1e-3 for the object physics score, whose torque term sums 32 cross products that nearly cancel), not a formula difference
-        assert r['eps32_rel'] < 1e-2, (st, r['eps32_rel'])
+        # per (image, finger), against the noise of THAT score vector (not the batch maximum): regret and exchange gap are
+        # bounded by twice the larger of the two sides' score errors -- a theorem for any correct top-k, so a failure is a selection bug
+        bad = (~r['within_own_and_reference_noise_bf']).nonzero()
+        assert bad.numel() == 0, (st, bad[:5].tolist(), r['regret_bf'][tuple(bad[0])], r['exchange_gap_bf'][tuple(bad[0])], r['eps32_bf'][tuple(bad[0])])
+        # and the tested side's own score error is of the size of the reference's own fp32 noise: per vector at most EPS_RATIO_MAX x
+        # (both are maxima over ~100 candidates of fp32 rounding, so they scatter by a small factor), in the median at most EPS_RATIO_MEDIAN x
+        if r['eps_own_bf'] is not None:
+            ratio = r['eps_own_bf'] / r['eps32_bf'].clamp(min=1e-12)
+            assert float(ratio.max()) <= EPS_RATIO_MAX and float(ratio.median()) <= EPS_RATIO_MEDIAN, (st, float(ratio.median()), float(ratio.max()))
+        # the noise of the reference's arithmetic is fp32 rounding, not a formula difference: heat-map sums after FK and projection 1e-6 ...
+        # 1e-5 of the score scale; the physics scores (torque term: 32 cross products that nearly cancel) up to ~1e-3
+        assert r['eps32_rel'] < EPS32_MAX[st], (st, r['eps32_rel'])
+    # the HIP lists are fp64-optimal on (nearly) as many images as the fp32 oracle's lists on the same candidates
+    assert s['images_identical_to_fp64_order'] >= s['images_identical_to_fp64_order_fp32_reference'] - OPTIMAL_SLACK, s
     return s
 
 

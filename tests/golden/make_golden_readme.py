@@ -14,7 +14,13 @@ are not stored (size).
 
     python make_golden_readme.py             -> golden_predict_readme.npz    (8 images; also the CPU pin of the oracle)
     python make_golden_readme.py --bs 64     -> golden_predict_readme64.npz  (the benchmark's batch: the batch-coupled quirks Q3 / Q5 see
-                                                64 images; hypotheses stored for every 4th sample, heat-maps every 8th pixel)"""
+                                                64 images; hypotheses stored for every 4th sample, heat-maps every 8th pixel)
+    python make_golden_readme.py --bs 64 --variant default,threads1,mkldnn_off
+                                             -> golden_predict_readme64_selfcheck.npz: the REFERENCE's forward run again on the same
+                                                inputs and the same prior draws under other execution settings of the same fp32
+                                                arithmetic (1 intra-op thread instead of all; oneDNN convolutions / matmuls off = ATen's
+                                                native kernels); only the 13 top-k index tensors and the three aggregated outputs are
+                                                stored.  It answers "does the reference reproduce its own top-k lists?" with data."""
 import os
 import sys
 import tempfile
@@ -33,6 +39,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=CFG['bs'])
+    ap.add_argument('--variant', default=None, help="comma-separated: default, threads1, threads2, mkldnn_off -> the self-check fixture")
     args = ap.parse_args()
     big = args.bs != CFG['bs']
     CFG['bs'] = args.bs
@@ -85,6 +92,8 @@ def main():
     for name, den in (('hand', ref.denoiser_hand), ('obj', ref.denoiser_obj)):
         den.forward = lambda d, _o=den.forward, _c=tcalls[name]: (_c.append(float(d['t'][0, 0])), _o(d))[1]
 
+    if args.variant:
+        return self_check(ref, data, c, args.variant.split(','), topk_calls, rec_topk, orig_topk)
     torch.manual_seed(c['draw_seed'])
     state = torch.get_rng_state()
     torch.Tensor.topk = rec_topk
@@ -123,6 +132,42 @@ def main():
     np.savez_compressed(path, **P)
     print({k: v.shape for k, v in P.items()})
     print('nfev hand/obj', len(tcalls['hand']), len(tcalls['obj']), '|', os.path.getsize(path) // 1024, 'KiB')
+
+
+TOPK_NAMES = ['hand_topk_l0', 'hand_topk_l1', 'hand_topk_l2', 'hand_topk_l3', 'obj_transl_topk', 'obj_rot_topk', 'obj_phys_topk',
+              'obj_heat_topk'] + [f'hand_phys_topk_f{f}' for f in range(5)]
+
+
+def self_check(ref, data, c, variants, topk_calls, rec_topk, orig_topk):
+    """Same module, same inputs, same prior draws; only HOW the fp32 arithmetic is executed changes."""
+    import contextlib
+    import time
+    n_default = torch.get_num_threads()
+    P = dict(cfg=np.array([c['bs'], c['sample_num'], c['sampling_steps'], c['topk_hand'], c['topk_obj']]), sample_T0=np.array(c['sample_T0']),
+             data_seed=np.array(c['data_seed']), draw_seed=np.array(c['draw_seed']), variants=np.array(len(variants)),
+             threads_default=np.array(n_default))
+    for vi, v in enumerate(variants):
+        torch.set_num_threads({'threads1': 1, 'threads2': 2}.get(v, n_default))
+        ctx = torch.backends.mkldnn.flags(enabled=False) if v == 'mkldnn_off' else contextlib.nullcontext()
+        del topk_calls[:]
+        torch.manual_seed(c['draw_seed'])
+        torch.Tensor.topk = rec_topk
+        t0 = time.time()
+        try:
+            with torch.no_grad(), ctx:
+                out = ref(dict(data), mode='predict')
+        finally:
+            torch.Tensor.topk = orig_topk
+        assert len(topk_calls) == 13, len(topk_calls)
+        for nm, call in zip(TOPK_NAMES, topk_calls):
+            P[f'v{vi}_{nm}'] = call[2].numpy().astype(np.int16)
+        for k in ('agg_obj_6d', 'agg_hand_joint', 'agg_hand_vert'):
+            P[f'v{vi}_{k}'] = out[k].numpy()
+        P[f'v{vi}_code'] = np.array({'default': 0, 'threads1': 1, 'threads2': 2, 'mkldnn_off': 3}[v])
+        print(v, 'done in %.0f s' % (time.time() - t0), flush=True)
+    path = os.path.join(HERE, 'golden_predict_readme64_selfcheck.npz' if c['bs'] == 64 else 'golden_predict_readme_selfcheck.npz')
+    np.savez_compressed(path, **P)
+    print(sorted(P), os.path.getsize(path) // 1024, 'KiB')
 
 
 if __name__ == '__main__':

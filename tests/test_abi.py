@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.vpho_abi_version() == 7
 
 
+def test_library_exports_nothing_but_the_header():
+    """-fvisibility=hidden + VPHO_API + the linker version script (vpho_amd/build.py): the dynamic symbol table IS the C ABI --
+    no C++ helper (vpho::fail, prof_record), kernel host stub, __hip_cuid_* or weak STL instantiation leaks out of the library"""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    out = subprocess.run(['nm', '-D', '--defined-only', os.path.join(ROOT, 'vpho_amd', 'libvpho_hip.so')], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == _declared(), (sorted(set(exported) - set(_declared())), sorted(set(_declared()) - set(exported)))
+    hdr = open(os.path.join(ROOT, 'include', 'vpho_hip.h')).read()
+    assert hdr.count('VPHO_API ') - 1 == len(exported)            # every declaration carries the export attribute (+ the #define)
+
+
 def test_state_dict_layout_matches_reference_contract(model_cpu):
     sd = model_cpu.state_dict()
     assert len([k for k in sd if k.startswith('feature_extractor.')]) == 530

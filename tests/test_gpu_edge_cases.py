@@ -87,3 +87,29 @@ def test_predict_edge_case_matches_oracle(model_cpu, sd, model_contrast_cpu, sd_
         for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_obj_6d'):
             e = res[f'max_abs_{k}_where_identical']                 # None: no image of this (small) batch has every list identical
             assert e is None or e < 1e-4, (name, k, res)
+
+
+def test_documented_kernel_limits_raise(assets):
+    """2 * sample_num <= 1024 candidates per image (wavefront top-k: 16 slots of 64 lanes), batch <= 256
+    (CrossModule attends over the batch axis, quirk Q3: one sequence of bs tokens per workgroup), object / hand point clouds that fit
+    LDS.  Each limit is an error with a message, not a wrong answer or a launch failure."""
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    # 2 * sample_num = 1026 candidates in the hand cascade (sample_num = 513)
+    hv = torch.rand(1, 1026, 20, device='cuda')
+    pose = torch.zeros(1, 1026, 48, device='cuda')
+    with pytest.raises(ops.VphoError, match='at most 1024 candidates'):
+        agg.hand_fuse_level(hv, pose, 30, 0)
+    ok = agg.hand_fuse_level(hv[:, :1024].contiguous(), pose[:, :1024].contiguous(), 30, 0)      # the limit itself is served
+    assert ok[1].shape == (1, 1, 30)
+    with pytest.raises(ops.VphoError, match='at most 1024 candidates'):
+        agg.topk(torch.rand(2, 1025, device='cuda'), 5)
+    # batch of 257 images: the cross module's sequence axis
+    with pytest.raises(ops.VphoError, match='<= 256'):
+        ops.mha(torch.zeros(257 * 65, 3 * 512, device='cuda'), 257, 65, 512, 2)
+    # hand physics: 16-byte LDS records per object vertex (ADVICE r3: the check said 12)
+    fp = torch.zeros(1, 31, 32, 3, device='cuda')
+    with pytest.raises(ops.VphoError, match='does not fit LDS'):
+        agg.hand_phys_score(fp, fp.clone(), torch.zeros(1, 4200, 3, device='cuda'), 1, 31)
+    torch.cuda.synchronize()

@@ -75,3 +75,38 @@ def test_main_eval_bad_checkpoint_path_fails_loudly(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--mode', 'eval'] + ARGS + ['--checkpoint', str(tmp_path / 'missing.state')],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and 'FileNotFoundError' in r.stderr
+
+
+def test_trainer_eval_consumes_any_iterable_of_batch_dicts(assets):
+    """``Trainer.eval(loader)`` is the reference's ``evaluate(testing_dataloader)`` (train_diff_hand_obj.py:202-258): fed the SAME synthetic
+    batches as dicts that carry their ground truth (gt_joint / gt_hand_vert, dexycb6.py:471-509) it prints the table of the default
+    synthetic run, row for row; a ragged last batch and host-resident tensors are fine; a batch without ground truth is refused."""
+    from vpho_amd.configs.args import cfg
+    from vpho_amd.synth import synth_batch
+    from vpho_amd.trainer import Trainer
+    keys = ('sample_num', 'sampling_steps', 'topk_hand', 'topk_obj', 'sample_T0', 'eval_batch_size', 'num_batches', 'random_seed', 'checkpoint')
+    saved = {k: getattr(cfg, k) for k in keys}
+    cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = 4, 5, 8, 3, 0.2
+    cfg.eval_batch_size, cfg.num_batches, cfg.random_seed, cfg.checkpoint = 2, 3, 7, None
+    try:
+        t = Trainer(cfg)
+        torch.manual_seed(11)
+        want = t.eval()
+        batches = [synth_batch(2, t.assets, seed=7 + i, rank=0) for i in range(3)]
+        b0 = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batches[0].items()}
+        out0 = t.model(b0, mode='predict')
+        gt_j, gt_v = (out0['reg_hand_joint'] + b0['root_joint'][:, None]).cpu(), (out0['reg_hand_vert'] + b0['root_joint'][:, None]).cpu()
+        for b in batches:
+            b['gt_joint'], b['gt_hand_vert'] = gt_j.clone(), gt_v.clone()
+        torch.manual_seed(11)
+        got = t.eval(loader=iter(batches))                     # a one-shot iterator, tensors on the host
+        assert torch.equal(got, want)
+        # ragged last batch: one image
+        last = {k: (v[:1] if torch.is_tensor(v) else v[:1]) for k, v in batches[2].items()}
+        rows = t.eval(loader=[batches[0], batches[1], last])
+        assert rows.shape[0] == 5 and torch.isfinite(rows).all()
+        with pytest.raises(KeyError, match='gt_joint'):
+            t.eval(loader=[synth_batch(2, t.assets, seed=1, rank=0)])
+    finally:
+        for k, v in saved.items():
+            setattr(cfg, k, v)

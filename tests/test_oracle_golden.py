@@ -273,3 +273,26 @@ def test_oracle_force_optimisation_loop_matches_reference(assets):
         assert float((r['scale'] - torch.as_tensor(g[f'scale_{iters}'])).abs().max()) < tol, iters
         assert float((r['weight'] - torch.as_tensor(g[f'weight_{iters}'])).abs().max()) < tol, iters
     close(r['force_point'], g['force_point'], 1e-5, 1e-7)
+
+
+def test_reference_self_agreement_is_reported():
+    """does the reference reproduce its OWN top-k lists?  golden_predict_readme64_selfcheck.npz = the reference's
+    forward('predict') at the README config on the 64-image fixture batch, re-run with 1 / 2 intra-op threads and with oneDNN off (same
+    inputs, same prior draws, same fp32 arithmetic; make_golden_readme.py --variant).  Reported, not asserted: a property of the
+    reference, printed here and by bench.py (parity.reference_self_agreement).  Asserted: the default run of the self-check IS the
+    committed 64-image fixture (the variants were compared with the run every other test is pinned to)."""
+    import json
+    from oracle.compare import reference_self_agreement, SELFCHECK_LISTS
+    GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+    path = os.path.join(GOLDEN, 'golden_predict_readme64_selfcheck.npz')
+    P, G = np.load(path), np.load(os.path.join(GOLDEN, 'golden_predict_readme64.npz'))
+    for nm in SELFCHECK_LISTS[:8]:
+        assert np.array_equal(P['v0_' + nm], G[nm]), nm
+    assert np.array_equal(np.stack([P[f'v0_hand_phys_topk_f{f}'] for f in range(5)], 1), G['hand_phys_topk'])
+    for k in ('agg_obj_6d', 'agg_hand_joint', 'agg_hand_vert'):
+        assert np.array_equal(P['v0_' + k], G[k]), k
+    rep = reference_self_agreement(path)
+    print('[reference self-agreement] ' + json.dumps(rep))
+    assert rep['images'] == 64 and len(rep['variants']) >= 2
+    for name, r in rep['variants'].items():
+        assert 0 <= r['images_all_selections_identical'] <= 64

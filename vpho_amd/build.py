@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libvpho_hip.so')
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-ffp-contract=off', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wall', '-Wno-unused-function']
 
 
 def _hipcc():
@@ -56,7 +56,12 @@ def build_extension(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs)
+        # the C ABI of include/vpho_hip.h is the library's whole dynamic symbol table: -fvisibility=hidden + VPHO_API on the
+        # declarations, and a version script for what the compiler exports on its own (kernel host stubs, __hip_cuid_*, weak STL code)
+        vmap = os.path.join(OBJ, 'exports.map')
+        with open(vmap, 'w') as f:
+            f.write('{ global: vpho_*; local: *; };\n')
+        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', f'-Wl,--version-script={vmap}', '-o', LIB] + objs)
     return LIB
 
 

@@ -683,8 +683,8 @@ extern "C" int vpho_hand_phys_candidates_f32(const float* agg_pose, int ld_agg, 
 
 extern "C" int vpho_hand_phys_score_f32(const float* force_point, const float* force_global, const float* obj_vert, int n_vert,
                                         int bs, int n_cand, float* finger_score, void* stream) {
-    VPHO_REQUIRE(force_point && force_global && obj_vert && finger_score && bs > 0 && n_cand > 0 && n_vert > 0 && (size_t)n_vert * 12 <= 64 * 1024,
-                 "vpho_hand_phys_score_f32: bad argument");
+    VPHO_REQUIRE(force_point && force_global && obj_vert && finger_score && bs > 0 && n_cand > 0 && n_vert > 0, "vpho_hand_phys_score_f32: bad argument");
+    VPHO_REQUIRE((size_t)n_vert * 16 <= 64 * 1024, "vpho_hand_phys_score_f32: object point cloud of %d vertices does not fit LDS", n_vert);
     hipLaunchKernelGGL(hand_phys_score_kernel, dim3(bs * n_cand), dim3(256), (size_t)n_vert * 16, (hipStream_t)stream,
                        force_point, force_global, obj_vert, n_vert, n_cand, finger_score);
     return vpho::check_launch("hand_phys_score_kernel");

@@ -54,6 +54,12 @@ def synthetic_mano_targets(mano, gt_rot6d, gt_shape, is_right):
     return dict(gt_hand_vert_flip=gv, gt_hand_jt3d_flip=gj, gt_mano=torch.cat([z(bs, 48), gt_shape], 1))
 
 
+def loader_indices_are_consecutive(index):
+    """a collated ``index`` column (dexycb6.py:472) can serve as the row's image index only if the batch is a run"""
+    i = index.reshape(-1).long()
+    return bool((i[1:] - i[:-1] == 1).all()) if i.numel() > 1 else True
+
+
 class Trainer:
     def __init__(self, cfg):
         self.cfg = cfg
@@ -92,33 +98,54 @@ class Trainer:
         gt_obj = torch.cat([rot[:, 16, :2, :].reshape(bs, 6), torch.randn(bs, 3, generator=g) * 0.05], -1).to(self.device)
         return gt_hand, gt_obj, g
 
-    def run_full(self, n_batches=None):
-        """End-to-end training over synthetic batches (train_diff_hand_obj.py:169-199) with all 13 losses of VPHO.py:190-212
-        (train_step.DiffusionTrainStep): backbone, heat-map heads, encoders, score networks, head_mano, both cross modules and
-        head_physics are updated.  Returns the per-batch loss dicts (floats)."""
-        from .train_step import DiffusionTrainStep
+    def _train_batches(self, loader, n_batches, mano):
+        """yields (batch on the device, gt_hand (bs,96) rot6d, gt_obj (bs,9)).  ``loader`` None: synthetic batches with synthetic targets.
+        Otherwise any iterable of collated Appendix-A batch dicts with the training keys of lib/dataset/dexycb6.py:471-509 (hm_hand,
+        hm_obj, gt_mano, gt_obj, gt_hand_vert_flip, gt_hand_jt3d_flip, force_local, ...): the targets are derived as the reference's
+        forward does, gt_hand = mano_aa_to_6D(gt_mano)[..., :96] (VPHO.py:190, head_mano.py:10-18), gt_obj as it stands."""
         cfg, bs = self.cfg, self.cfg.batch_size
-        n_batches = cfg.num_batches if n_batches is None else n_batches
-        step = DiffusionTrainStep(self.model.state_dict(), self.device, assets=self.assets)
-        hist = []
-        for i in range(n_batches):
-            batch = {k: (v.to(self.device) if torch.is_tensor(v) else v)
-                     for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
+        if loader is not None:
+            from .model.VPHO import _aa_to_rot6d
+            for i, b in enumerate(loader):
+                if n_batches is not None and i >= n_batches:
+                    return
+                b = self._to_device(b)
+                missing = [k for k in ('gt_mano', 'gt_obj', 'hm_hand', 'hm_obj') if k not in b]
+                if missing:
+                    raise KeyError(f'training batch lacks {missing} (lib/dataset/dexycb6.py:471-509)')
+                yield b, _aa_to_rot6d(b['gt_mano'][:, :48].float()), b['gt_obj'].float().contiguous()
+            return
+        for i in range(cfg.num_batches if n_batches is None else n_batches):
+            batch = self._to_device(synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank))
             gt_hand, gt_obj, g = self._synthetic_targets(bs, i)
             batch['hm_hand'] = (torch.rand(bs, 21, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
             batch['hm_obj'] = (torch.rand(bs, 27, cfg.heatmap_size, cfg.heatmap_size, generator=g) * 0.2).to(self.device)
-            batch.update(synthetic_mano_targets(step.mano_head.mano, gt_hand, (torch.randn(bs, 10, generator=g) * 0.5).to(self.device), batch['is_right']))
+            batch.update(synthetic_mano_targets(mano, gt_hand, (torch.randn(bs, 10, generator=g) * 0.5).to(self.device), batch['is_right']))
             batch['force_local'] = (torch.randn(bs, 32, 3, generator=g) * 0.1).to(self.device)      # pseudo-force labels (force_optim.py's output)
+            yield batch, gt_hand, gt_obj
+
+    def run_full(self, n_batches=None, loader=None):
+        """End-to-end training (train_diff_hand_obj.py:169-199) with all 13 losses of VPHO.py:190-212 (train_step.DiffusionTrainStep):
+        backbone, heat-map heads, encoders, score networks, head_mano, both cross modules and head_physics are updated.  Batches:
+        ``_train_batches`` (synthetic by default, or any iterable of Appendix-A dicts).  Returns the per-batch loss dicts (floats)."""
+        from .train_step import DiffusionTrainStep
+        cfg = self.cfg
+        step = DiffusionTrainStep(self.model.state_dict(), self.device, assets=self.assets)
+        hist = []
+        for i, (batch, gt_hand, gt_obj) in enumerate(self._train_batches(loader, n_batches, step.mano_head.mano)):
             L = step.step(batch, gt_hand, gt_obj)
             hist.append({k: float(v) for k, v in L.items()})
             if self.rank == 0 and i % max(1, getattr(cfg, 'print_freq', 10)) == 0:
-                print(f'[{i:04d}/{n_batches}] ' + '  '.join(f'{k.replace("_loss", "")} {v:.3e}' for k, v in hist[-1].items()))
+                print(f'[{i:04d}] ' + '  '.join(f'{k.replace("_loss", "")} {v:.3e}' for k, v in hist[-1].items()))
         self.model.load_state_dict(step.state_dict(), strict=False)
         return hist
 
-    def run(self, n_batches=None):
+    def run(self, n_batches=None, loader=None):
+        """``Trainer.run`` (train_diff_hand_obj.py:126-153).  ``loader``: an iterable of Appendix-A batch dicts; default synthetic."""
         if getattr(self.cfg, 'train_scope', 'full') == 'full':
-            return self.run_full(n_batches)
+            return self.run_full(n_batches, loader)
+        if loader is not None:
+            raise NotImplementedError("--train_scope score trains on frozen features of synthetic batches only; use --train_scope full with a loader")
         return self.run_score(n_batches)
 
     def run_score(self, n_batches=None):
@@ -144,31 +171,70 @@ class Trainer:
         self.model.load_state_dict({**hand.state_dict(), **obj.state_dict()}, strict=False)
         return losses
 
-    @torch.no_grad()
-    def eval(self):
+    def _to_device(self, batch):
+        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def _eval_batches(self, loader):
+        """yields (batch on the device, (gt_joint, gt_vert), index of its first image).  ``loader`` None: ``cfg.num_batches`` synthetic
+        batches whose ground truth is batch 0's own regression output (there is no data set in this build).  Otherwise ANY iterable of
+        collated Appendix-A batch dicts (lib/dataset/dexycb6.py:471-509; what ``accel.prepare`` hands each rank,
+        train_diff_hand_obj.py:211-217): ground truth = ``gt_joint`` / ``gt_hand_vert`` in the camera frame (:237-238), the object's
+        ``gt_obj_rt`` or, like the reference's postprocess of the batch (:578-597), ``gt_obj`` (9-D) + root joint."""
         cfg, bs = self.cfg, self.cfg.eval_batch_size
+        if loader is None:
+            gt = None
+            for i in range(cfg.num_batches):
+                b = self._to_device(synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank))
+                gt = yield b, gt, (self.rank * cfg.num_batches + i) * bs
+            return
+        seen = 0
+        for b in loader:
+            b = self._to_device(b)
+            missing = [k for k in ('gt_joint', 'gt_hand_vert') if k not in b]
+            if missing:
+                raise KeyError(f'evaluation batch lacks {missing}: Trainer.eval(loader) needs the ground truth of lib/dataset/dexycb6.py:471-509')
+            if 'gt_obj_rt' not in b and 'gt_obj' in b:
+                from . import ops
+                b['gt_obj_rt'] = ops.obj_9d_to_rt(b['gt_obj'].double().contiguous(), b['root_joint'].float().contiguous()).float()
+            n = b['rgb'].shape[0]
+            # column 0 of the metric rows: the data set's own index where the batch is a run of it, else the rank's running count
+            first = int(b['index'].reshape(-1)[0]) if torch.is_tensor(b.get('index')) and loader_indices_are_consecutive(b['index']) else seen
+            yield b, (b['gt_joint'].float(), b['gt_hand_vert'].float()), first
+            seen += n
+
+    @torch.no_grad()
+    def eval(self, loader=None):
+        """``evaluate(testing_dataloader)`` (train_diff_hand_obj.py:202-357).  ``loader``: see ``_eval_batches``; default synthetic."""
         rows = []
         t0 = time.perf_counter()
-        # three batches in flight (independent images; see evaluate.PipelinedPredictor); batch 0 also provides the synthetic
-        # ground truth (its own regression output), so it is evaluated first
+        # three batches in flight (independent images; see evaluate.PipelinedPredictor)
         pipe = E.PipelinedPredictor(self.model, depth=3)
-        make = lambda i: {k: (v.to(self.device) if torch.is_tensor(v) else v)
-                          for k, v in synth_batch(bs, self.assets, seed=cfg.random_seed + i, rank=self.rank).items()}
-        b0 = make(0)
-        out0 = pipe.submit(b0).result()
-        gt = (out0['reg_hand_joint'] + b0['root_joint'][:, None], out0['reg_hand_vert'] + b0['root_joint'][:, None])
-        rows.append(E.metric_rows(out0, b0, gt[0], gt[1], self.rank * cfg.num_batches * bs, self.assets))
         futs = []
-        for i in range(1, cfg.num_batches):
-            first = (self.rank * cfg.num_batches + i) * bs
-            futs.append(pipe.submit(make(i), lambda out, batch, eng, first=first: E.metric_rows(out, batch, gt[0], gt[1], first, self.assets)))
+        gen = self._eval_batches(loader)
+        try:
+            item = next(gen)
+            while True:
+                b, gt, first = item
+                if gt is None:
+                    # synthetic run: batch 0 provides the ground truth (its own regression output), so it is evaluated first
+                    out0 = pipe.submit(b).result()
+                    gt = (out0['reg_hand_joint'] + b['root_joint'][:, None], out0['reg_hand_vert'] + b['root_joint'][:, None])
+                    rows.append(E.metric_rows(out0, b, gt[0], gt[1], first, self.assets))
+                else:
+                    futs.append(pipe.submit(b, lambda out, batch, eng, first=first, gt=gt: E.metric_rows(out, batch, gt[0], gt[1], first, self.assets)))
+                item = gen.send(gt)
+        except StopIteration:
+            pass
         rows += [f.result() for f in futs]
         pipe.close()
+        if not rows:
+            raise ValueError('Trainer.eval: the loader yielded no batch')
         rows = E.gather_rows(torch.cat(rows, 0))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if self.rank == 0:
-            print(f'evaluated {rows.shape[0]} synthetic images on {self.world} GPU(s) in {dt:.2f} s ({rows.shape[0] / dt:.1f} images/s)')
+            what = 'synthetic images' if loader is None else 'images'
+            print(f'evaluated {rows.shape[0]} {what} on {self.world} GPU(s) in {dt:.2f} s ({rows.shape[0] / dt:.1f} images/s)')
             table = E.summarize(rows.cpu())
             for name, r in table.items():
                 if name != 'object':
