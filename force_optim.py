@@ -58,6 +58,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ops.prof_enable('force_optim', True)                  # HIP events around the persistent kernel (one launch)
     t0 = time.perf_counter()
     out = agg.force_optimize(verts, grav, com, fc, grasped, args.batch_size, iters=args.iters, phase1=args.phase1)
     torch.cuda.synchronize()
@@ -70,9 +71,20 @@ def main():
             dt, tot = dt.cpu(), tot.cpu()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot)
+    kprof = ops.prof_collect('force_optim')
+    ops.prof_enable('force_optim', False)
     if rank == 0:
         losses = out['losses'].mean(0).tolist()
-        print(json.dumps({'metric': 'pseudo-force optimisation pairs/s (3000 AdamW iterations per pair)', 'value': float(tot.item() / dt.item()),
+        # ALU-bound, not HBM / MFMA: 480 fp32 operations per (pair, anchor) item and iteration (counted in csrc/force_optim.hip) against
+        # the fp32 vector peak; the kernel is one 1024-thread workgroup per batch of 64 pairs -- a chain of dependent scalar arithmetic,
+        # half-wave reductions and one workgroup barrier per iteration: latency-bound far below the ALU peak
+        tf = kprof['flops'] / kprof['total_ms'] / 1e9 if kprof['total_ms'] else None
+        roof = {'bound': 'valu', 'kernel': 'force_optim_kernel (3000 AdamW iterations per batch in one persistent workgroup)', 'achieved': tf, 'peak': 157.3,
+                'unit': 'TFLOP/s', 'frac': tf / 157.3 if tf else None, 'traffic': None, 'flop_per_pair_per_iteration': 480 * 32,
+                'kernel_ms': kprof['total_ms'], 'workgroups': (hi - lo), 'timing': 'HIP events around the launch on the launch stream',
+                'limited_by': 'latency: 157 workgroups of 16 waves for 256 CUs at 10 048 pairs; dependent exp / div / sqrt chains, 7 half-wave '
+                              'reductions and a workgroup barrier per iteration'}
+        print(json.dumps({'roofline': roof, 'metric': 'pseudo-force optimisation pairs/s (3000 AdamW iterations per pair)', 'value': float(tot.item() / dt.item()),
                           'unit': 'pairs/s', 'n_gpus': world, 'pairs': int(tot.item()), 'batch_size': args.batch_size, 'iters': args.iters,
                           'seconds': float(dt.item()), 'mean_losses_force_gravity_moment_dist': losses, 'data': 'synthetic'}))
     if world > 1:

@@ -31,7 +31,8 @@ VPHO_API int vpho_abi_version(void);   /* 7 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
- * reported in bytes: 4 = MANO FK, 5 = object physics score, 6 = hand cascade fuse, 7 = RoIAlign, 8 = bilinear resize).
+ * reported in bytes: 4 = MANO FK, 5 = object physics score, 6 = hand cascade fuse, 7 = RoIAlign, 8 = bilinear resize; 9 = Winograd
+ * convolution, 10 / 11 = weight-gradient TN GEMM with 64x64 / 128x128 tiles, 12 = pseudo-force optimiser, 13 = pose encoder).
  * vpho_prof_collect waits for the recorded events and returns the summed kernel time, the launch count, the algorithmic
  * flop (2*M*N*K) and the algorithmic bytes (operands once) issued. */
 VPHO_API int vpho_prof_enable(int kernel_class, int on);

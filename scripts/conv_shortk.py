@@ -1,6 +1,6 @@
 """The short-K 1x1 layers (+ residual + LeakyReLU) under a forced tile (VPHO_CONV_TILE=1288|12864|64; unset: the plan's own choice)."""
 import os, sys, torch
-sys.argv = sys.argv[:1]; sys.path.insert(0, '.')
+sys.argv = sys.argv[:1]; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpho_amd import ops
 shapes = [(64, 64, 64, 256, True), (64, 32, 128, 512, True), (64, 16, 256, 1024, True), (64, 32, 128, 256, False), (64, 64, 256, 64, False),
           (64, 32, 512, 128, False), (64, 16, 1024, 256, False), (128, 8, 512, 2048, True)]

@@ -1,6 +1,6 @@
 """Exclusive timing of score_head_kernel (HIP events around each launch) for the hand and object score networks."""
 import sys, torch
-sys.argv = ['x']; sys.path.insert(0, '.')
+import os; sys.argv = ['x']; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpho_amd.model.VPHO import vpho_net
 from vpho_amd.synth import synth_state_dict
 from vpho_amd.assets import synthetic_assets

@@ -1,7 +1,7 @@
 """Isolated score evaluations (time_embed + pose encoder + score head, one stream, nothing else on the GPU) for rocprofv3:
     rocprofv3 --kernel-trace --stats -d out -o pe -- python3 scripts/pe_bench.py"""
 import sys, torch
-sys.argv = ['x']; sys.path.insert(0, '.')
+import os; sys.argv = ['x']; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpho_amd.model.VPHO import vpho_net
 from vpho_amd.synth import bench_state_dict
 from vpho_amd.assets import synthetic_assets

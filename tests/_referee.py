@@ -5,10 +5,15 @@ import torch
 
 BS, S, STEPS, KH, KO, T0 = 64, 100, 50, 30, 10, 0.65
 # bounds of assert_within_reference_noise; measured values are in DESIGN.md section 2(B)
-EPS_RATIO_MAX, EPS_RATIO_MEDIAN = 8.0, 2.0
+# (max, median) of eps(tested side) / max(eps32 of the vector, stage median).  Heat-map stages: a sum of ~20 bicubic look-ups, the noise of
+# the two sides is alike on every vector (measured max 1.3 ... 2.8, median 0.8 ... 1.0).  Physics stages: the score is a difference of nearly
+# cancelling cross products, its noise is heavy-tailed over images (stage median 4e-7, maximum 8e-4) and the two sides' worst vectors
+# need not coincide (measured max 1.6 ... 37, median 0.8 ... 1.1)
+EPS_RATIO = dict(heat=(4.0, 1.5), physics=(64.0, 2.0))
 EPS32_MAX = dict(hand_level0=1e-4, hand_level1=1e-4, hand_level2=1e-4, hand_level3=2e-4, obj_transl=1e-4, obj_rot=1e-4, obj_heat=1e-4,
                  obj_physics=1e-2, hand_physics=1e-2)
 OPTIMAL_SLACK = 4
+STRICT_ALLOWANCE = 0.01
 
 
 def run_hip(model_cpu, assets, data, nh, no, cfg_values=None):
@@ -45,11 +50,20 @@ def assert_within_reference_noise(rep, tag=''):
         # bounded by twice the larger of the two sides' score errors -- a theorem for any correct top-k, so a failure is a selection bug
         bad = (~r['within_own_and_reference_noise_bf']).nonzero()
         assert bad.numel() == 0, (st, bad[:5].tolist(), r['regret_bf'][tuple(bad[0])], r['exchange_gap_bf'][tuple(bad[0])], r['eps32_bf'][tuple(bad[0])])
-        # and the tested side's own score error is of the size of the reference's own fp32 noise: per vector at most EPS_RATIO_MAX x
-        # (both are maxima over ~100 candidates of fp32 rounding, so they scatter by a small factor), in the median at most EPS_RATIO_MEDIAN x
+        # the stricter statement -- regret and exchange gap within 2 eps32 of the vector's OWN reference noise, i.e. a pick the reference's
+        # arithmetic could have produced on this very vector -- is not a theorem (the tested side has its own rounding); measured: it
+        # holds on every one of the 6 656 vectors of the four batches.  Asserted with a 1 % allowance per stage
+        strict_bad = int((~r['within_reference_noise_bf']).sum())
+        assert strict_bad <= STRICT_ALLOWANCE * r['eps32_bf'].numel(), (st, strict_bad, r['eps32_bf'].numel())
+        # and the tested side's own score error is of the size of the reference's own fp32 noise: per vector at most a small multiple of
+        # reference's on that vector (both are maxima over ~100 candidates of fp32 rounding, so they scatter by a small factor; a vector
+        # the reference happens to evaluate almost exactly is held to the stage's median noise instead), and in the median about equal
         if r['eps_own_bf'] is not None:
-            ratio = r['eps_own_bf'] / r['eps32_bf'].clamp(min=1e-12)
-            assert float(ratio.max()) <= EPS_RATIO_MAX and float(ratio.median()) <= EPS_RATIO_MEDIAN, (st, float(ratio.median()), float(ratio.max()))
+            floor = r['eps32_bf'].median()
+            ratio = r['eps_own_bf'] / torch.maximum(r['eps32_bf'], floor)
+            print(f'   {st:13s} eps(tested) / max(eps32 of the vector, stage median {float(floor):.1e}): median {float(ratio.median()):.2f}, max {float(ratio.max()):.2f}')
+            rmax, rmed = EPS_RATIO['physics' if st.endswith('physics') else 'heat']
+            assert float(ratio.max()) <= rmax and float(ratio.median()) <= rmed, (st, float(ratio.median()), float(ratio.max()))
         # the noise of the reference's arithmetic is fp32 rounding, not a formula difference: heat-map sums after FK and projection 1e-6 ...
         # 1e-5 of the score scale; the physics scores (torque term: 32 cross products that nearly cancel) up to ~1e-3
         assert r['eps32_rel'] < EPS32_MAX[st], (st, r['eps32_rel'])

@@ -58,6 +58,28 @@ def test_conv_epilogue_residual_lrelu_and_prologue_affine():
     _close(y.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize('N,H,Cin,Cout', [(16, 32, 64, 256), (16, 32, 32, 256), (8, 16, 128, 512), (5, 13, 96, 192), (3, 9, 256, 64), (64, 8, 512, 2048)])
+def test_residual_requested_before_the_last_k_stage(N, H, Cin, Cout):
+    """round 4: the residual tile of a 1x1 expansion (conv3 of every bottleneck, backbone_FPN_HFL.py:311-350) is loaded in front of the last
+    k stage instead of after it.  K = 32 (one stage: requested before the only stage), 64, 96 ... 512 in all three tile classes, ragged
+    pixel counts and Cout tails; against torch, and bit-identical to the round-3 order of the same kernel (VPHO_CONV_DBG=8)."""
+    import os
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    x, w, b = _rand((N, Cin, H, H), 50), _rand((Cout, Cin, 1, 1), 51, (2.0 / Cin) ** 0.5), _rand((Cout,), 52)
+    res = _rand((N, Cout, H, H), 53)
+    ref = F.leaky_relu(F.conv2d(x, w, b) + res, 0.01)
+    xg, wg, bg, rg = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda(), res.permute(0, 2, 3, 1).contiguous().cuda()
+    y = ops.conv2d_nhwc(xg, wg, bg, res=rg, out_slope=0.01)
+    _close(y.permute(0, 3, 1, 2), ref)
+    os.environ['VPHO_CONV_DBG'] = '8'
+    try:
+        y_late = ops.conv2d_nhwc(xg, wg, bg, res=rg, out_slope=0.01)
+    finally:
+        os.environ.pop('VPHO_CONV_DBG', None)
+    assert torch.equal(y, y_late)
+
+
 @pytest.mark.parametrize('N,H,Cin,Cout', [(16, 32, 256, 256), (9, 31, 128, 64), (3, 17, 512, 128), (2, 8, 544, 64)])
 def test_prologue_affine_on_the_direct_to_lds_kernel(N, H, Cin, Cout):
     """Pre-activation BN + LeakyReLU applied to the fragments as they are read from LDS (1x1, Cin % 32 == 0, Cin <= 512) in all

@@ -31,6 +31,30 @@ def test_score_matches_oracle(sd, nets, name, D):
         assert (got - ref).abs().max().item() <= 2e-5 * scale, (t, (got - ref).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_register_ring_pose_encoder_is_bit_identical_to_the_lds_ring_kernel(nets, name, D):
+    """round 4: pose_encoder_reg_kernel (weight fragments in a register ring, 35 KB of LDS, 3 barriers) against round 3's
+    pose_encoder_kernel (143 KB LDS ring, VPHO_PE_RING=1): the same k order of the same fp32 MFMAs, so the whole score is bit-identical;
+    ragged last block (6 387 = 199 x 32 + 19 rows), and a whole ODE solve (the stage-state prologue: y + h sum c_j K_j in fp64)"""
+    import os
+    bs, S = 3, 2129
+    feat, x = seeded((bs, 1024), 60, 0.3).cuda(), seeded((bs * S, D), 61, 1.5).cuda()
+    init = seeded((8 * 50, D), 62, 20.0).cuda()
+    feat8 = seeded((8, 1024), 63, 0.3).cuda()
+    res = {}
+    for ring in ('1', '0'):
+        os.environ['VPHO_PE_RING'] = ring
+        try:
+            sc = nets[name].score(feat, x, 0.3, S).clone()
+            xs, xf, st = nets[name].sample(feat8, init, 50, 0.65, 12, xs_f64=True)
+            res[ring] = (sc, xs.clone(), xf.clone(), st['nfev'])
+        finally:
+            os.environ.pop('VPHO_PE_RING', None)
+    assert torch.isfinite(res['0'][0]).all() and float(res['0'][0].abs().max()) > 0
+    assert torch.equal(res['0'][0], res['1'][0])
+    assert res['0'][3] == res['1'][3] and torch.equal(res['0'][1], res['1'][1]) and torch.equal(res['0'][2], res['1'][2])
+
+
 def test_score_tail_tiles_match_oracle(sd, nets):
     """6 387 rows x 32 heads = 1 600 tiles on 512 workgroup slots: the launch runs 48 ordinary tiles per head and the remaining 243
     rows as 32-row tail tiles (the last one ragged).  Rows of every kind of tile against the oracle, and against a launch of

@@ -84,6 +84,32 @@ def main():
            'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
            'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),
            'loss_first': first, 'loss_last': {k: float(v) for k, v in L.items()}}
+    if rank == 0:
+        # roofline of the step's dominant kernel, measured live: HIP events around every weight-gradient launch (conv_wgrad.hip) in a
+        # separate instrumented repeat of the step (the events serialise nothing, but they are kept out of the timed region)
+        from vpho_amd import ops
+        names = ('conv_wgrad_64x64', 'conv_wgrad_128x128')
+        for nm in names:
+            ops.prof_enable(nm, True)
+        n_prof = 2
+        for _ in range(n_prof):
+            step.step(data, gt_h, gt_o, repeat_num=args.repeat_num)
+        torch.cuda.synchronize()
+        prof = {nm: ops.prof_collect(nm) for nm in names}
+        for nm in names:
+            ops.prof_enable(nm, False)
+        PEAK = 157.3                                                   # fp32 MFMA, dense (MI355X_MICROARCH.md)
+        blk = {}
+        for nm, r in prof.items():
+            if r['launches']:
+                blk[nm] = {'TFLOP/s': r['flops'] / r['total_ms'] / 1e9, 'frac': r['flops'] / r['total_ms'] / 1e9 / PEAK, 'launches_per_step': r['launches'] / n_prof,
+                           'kernel_ms_per_step': r['total_ms'] / n_prof, 'avg_launch_us': 1e3 * r['total_ms'] / r['launches'], 'flop_per_launch_avg': r['flops'] / r['launches']}
+        dom = max(blk, key=lambda k: blk[k]['kernel_ms_per_step'])
+        res['roofline'] = {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2>'}[dom]
+                           + ' (weight gradient dW = dY^T . im2col(x) as an implicit TN GEMM on fp32 MFMA)',
+                           'achieved': blk[dom]['TFLOP/s'], 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': blk[dom]['frac'], 'traffic': None,
+                           'share_of_step': blk[dom]['kernel_ms_per_step'] / res['ms_per_step'],
+                           'timing': 'HIP events around every launch on the launch stream, instrumented repeat of the step', 'classes': blk}
     if args.breakdown:
         draws = dict(t_h=torch.rand(args.repeat_num, bs, device=dev) * 0.99 + 0.01, z_h=torch.randn(args.repeat_num, bs, 96, device=dev),
                      t_o=torch.rand(args.repeat_num, bs, device=dev) * 0.99 + 0.01, z_o=torch.randn(args.repeat_num, bs, 9, device=dev))

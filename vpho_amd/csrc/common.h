@@ -16,7 +16,9 @@ inline int check_launch(const char* what) {
 // Opt-in per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
 enum ProfClass { PROF_CONV128 = 0, PROF_CONV64 = 1, PROF_SCORE_HEAD = 2, PROF_CONV128x64 = 3,
                  // HBM-bound kernels: `bytes` = algorithmic bytes of the launch (operands read once + results written once)
-                 PROF_MANO_FK = 4, PROF_OBJ_PHYSICS = 5, PROF_HAND_FUSE = 6, PROF_ROI_ALIGN = 7, PROF_RESIZE = 8, PROF_WINOGRAD = 9, PROF_NCLASS = 10 };
+                 PROF_MANO_FK = 4, PROF_OBJ_PHYSICS = 5, PROF_HAND_FUSE = 6, PROF_ROI_ALIGN = 7, PROF_RESIZE = 8, PROF_WINOGRAD = 9,
+                 // widened rows: weight-gradient TN GEMM by tile class (train.py), the persistent pseudo-force optimiser (force_optim.py)
+                 PROF_WGRAD64 = 10, PROF_WGRAD128 = 11, PROF_FORCE_OPTIM = 12, PROF_POSE_ENC = 13, PROF_NCLASS = 14 };
 bool prof_on(int cls);
 void prof_record(int cls, hipEvent_t start, hipEvent_t stop, double flops, double bytes);
 struct ProfScope {

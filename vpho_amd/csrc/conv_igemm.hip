@@ -27,7 +27,9 @@ struct Geo {
     long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions; 0 for ordinary launches)
     int y_linear, r_linear, vec_epilogue;
     int uni;   // Cin % 32 == 0: wave-uniform taps (direct-to-LDS kernel)
-    int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores
+    int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores,
+               // 8 = residual tile requested in the epilogue (round 3) instead of in front of the last k stage, 16 = second stage requested
+               // after the first has landed (round 3) (A/B measurements, read per call)
 };
 
 // VEC = number of consecutive 16-byte pieces (of one tile row) a thread moves per pass: 2 halves the per-K-step address
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 // instruction's scalar offset and the per-lane offsets are loop constants (only the padding test of a 3x3 stays per stage; for 1x1
 // unpadded convolutions the loop has no per-lane address work at all).
 template <int BM, int BN, int WM, int WN, bool PRE = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo g) {
+__global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const Geo g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int ROWS = NT / 8;                      // tile rows per pass: every wave fills 8 consecutive rows
@@ -462,11 +464,56 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
         for (int c = tid; c < d.Cin; c += NT) { pre_tab[c] = d.in_scale[c]; pre_tab[GLDS_PRE_MAX + c] = d.in_shift[c]; }
         __syncthreads();
     }
+    // ---- epilogue items of this thread (16-byte epilogue): tile row / channel quad, destination offset, residual.  The residual is
+    // REQUESTED in front of the last k stage's matrix work, not after it: a 1x1 expansion with a residual (conv3 of every bottleneck:
+    // K = 64 ... 512) has 2 ... 16 stages, and its tile then spent an HBM round trip of the residual tile on top of them with both
+    // workgroups of the CU marching in step (44 / 65 / 94 TF/s on the K = 64 / 128 / 256 layers).  Nothing else is in flight
+    // during the last stage (no next fill), so the stage-end wait costs nothing extra.
+    constexpr int V_PER_ROW = BN / 4, ITERS = BM * V_PER_ROW / NT;
+    f32x4 rv[ITERS];                                                // the only epilogue state that lives through the last stage
+    auto offsets = [&](int row, long long& yoff, long long& ro) {
+        if (d.row_map && d.rows_scatter) row = d.row_map[row];          // pixel list, results stored at the pixels' own positions
+        if (g.y_linear && g.r_linear) {
+            yoff = (long long)row * d.y_sx;
+            ro = (long long)row * d.r_sx;
+        } else {
+            int n = row / ohw, rem = row - n * ohw;
+            int oy = rem / d.OW, ox = rem - oy * d.OW;
+            yoff = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
+            ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+        }
+    };
+    auto item = [&](int it, long long& yoff, long long& ro) -> bool {
+        const int idx = tid + it * NT;
+        const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
+        const int row = m0 + r, col = n0 + 4 * c4;
+        const bool live = row < M_live && col < d.Cout;
+        yoff = ro = 0;
+        if (live) { offsets(row, yoff, ro); yoff += col; ro += col; }
+        return live;
+    };
+    auto load_res = [&]() {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            long long yoff, ro;
+            const bool live = item(it, yoff, ro);
+            rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d.res && live) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
+        }
+    };
+    const bool res_early = g.vec_epilogue && d.res != nullptr && !(g.dbg & 8);
+    // the first TWO stages are requested back to back and only the first is waited for (counted vmcnt: fills complete in issue order):
+    // a short-K tile (K = 64: two stages in all) pays one memory round trip at its start, not one and a half
     if (UNI) fill_uni(0, 0); else fill(0);
-    VPHO_SYNC_LDS_DMA();
-    for (int kt = 0; kt < nk; ++kt) {
+    if (nk > 1 && !(g.dbg & 16)) {
+        if (UNI) fill_uni(1, 1); else fill(1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");
+        __syncthreads();
+    } else {
+        VPHO_SYNC_LDS_DMA();
+    }
+    auto compute = [&](int kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) { if (UNI) fill_uni(buf ^ 1, kt + 1); else fill(buf ^ 1); }
         const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * BK;
         const float* Bs = smem + buf * TILE + BM * BK + (wn * (BN / WN) + li) * BK;
 #pragma unroll
@@ -496,21 +543,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        if (kt > 0 || (g.dbg & 16)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
+        compute(kt);
         VPHO_SYNC_LDS_DMA();
     }
+    // last stage: no next fill; the residual tile is requested here and lands under this stage's matrix work
+    if (res_early) { load_res(); __builtin_amdgcn_sched_barrier(0); }
+    compute(nk - 1);
+    VPHO_SYNC_LDS_DMA();
 
-    auto offsets = [&](int row, long long& yo, long long& ro) {
-        if (d.row_map && d.rows_scatter) row = d.row_map[row];          // pixel list, results stored at the pixels' own positions
-        if (g.y_linear && g.r_linear) {
-            yo = (long long)row * d.y_sx;
-            ro = (long long)row * d.r_sx;
-        } else {
-            int n = row / ohw, rem = row - n * ohw;
-            int oy = rem / d.OW, ox = rem - oy * d.OW;
-            yo = n * d.y_sn + oy * d.y_sy + ox * d.y_sx;
-            ro = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
-        }
-    };
     if (g.vec_epilogue) {
         constexpr int C_LD = BN;                                    // ds_write_b32 halves are separate bank groups: no pad needed
         float* Cs = smem;
@@ -525,39 +568,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
                     Cs[r * C_LD + wn * (BN / WN) + j * 32 + li] = acc[i][j][e];
                 }
         __syncthreads();
-        constexpr int V_PER_ROW = BN / 4, ITERS = BM * V_PER_ROW / NT;
-        f32x4 v[ITERS], rv[ITERS];
-        long long yo[ITERS];
-        bool ok[ITERS];
+        if (!res_early) load_res();
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
+            long long yoff, ro;
+            if (!item(it, yoff, ro)) continue;
             const int idx = tid + it * NT;
             const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
-            const int row = m0 + r, col = n0 + 4 * c4;
-            ok[it] = row < M_live && col < d.Cout;
-            v[it] = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
-            long long ro = 0;
-            yo[it] = 0;
-            if (ok[it]) { offsets(row, yo[it], ro); yo[it] += col; ro += col; }
-            rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (d.res && ok[it]) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            if (!ok[it]) continue;
-            const int idx = tid + it * NT;
-            const int c4 = idx % V_PER_ROW;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * C_LD + 4 * c4);
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n0 + 4 * c4);
             f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float t = v[it][k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+            for (int k = 0; k < 4; ++k) { const float t = v[k] + bv[k] + rv[it][k]; o[k] = t > 0.f ? t : t * d.out_slope; }
             if (d.gate) {                                            // backward of a LeakyReLU whose output is `gate` (same layout as y)
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(d.gate + yo[it]);
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(d.gate + yoff);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = gt[k] > 0.f ? o[k] : o[k] * d.gate_slope;
             }
-            *reinterpret_cast<f32x4*>(d.y + yo[it]) = o;
+            *reinterpret_cast<f32x4*>(d.y + yoff) = o;
         }
         return;
     }
@@ -573,13 +602,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_glds_kernel(const Geo
             for (int e = 0; e < 16; ++e) {
                 const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
                 if (row >= M_live) continue;
-                long long yo, ro;
-                offsets(row, yo, ro);
+                long long yoff, ro;
+                offsets(row, yoff, ro);
                 float v = acc[i][j][e] + bv;
                 if (d.res) v += d.res[ro + col];
                 v = v > 0.f ? v : v * d.out_slope;
-                if (d.gate) v = d.gate[yo + col] > 0.f ? v : v * d.gate_slope;
-                d.y[yo + col] = v;
+                if (d.gate) v = d.gate[yoff + col] > 0.f ? v : v * d.gate_slope;
+                d.y[yoff + col] = v;
             }
         }
     }
@@ -859,8 +888,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                       (!d.bias || al16(d.bias)) &&
                       (!d.gate || al16(d.gate)) &&
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
-    static const int dbg = getenv("VPHO_CONV_DBG") ? atoi(getenv("VPHO_CONV_DBG")) : 0;
-    g.dbg = dbg;
+    const char* dbg_env = getenv("VPHO_CONV_DBG");
+    g.dbg = dbg_env ? atoi(dbg_env) : 0;
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * splits;
     const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes

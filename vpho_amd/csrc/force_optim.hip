@@ -274,6 +274,10 @@ extern "C" int vpho_force_optimize_f32(const float* pts, const float* frames, co
     a.pts = pts; a.frames = frames; a.gravity = gravity; a.com = com; a.fc = force_contact; a.grasped = is_grasped;
     a.B = B; a.iters = iters; a.phase1 = phase1_iters; a.lr = lr; a.wd = 0.01f; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f; a.friction = 0.8f;
     a.fl_out = force_local; a.fg_out = force_global; a.scale_out = scale; a.weight_out = weight; a.losses_out = losses;
+    // vector-ALU work of one iteration per (pair, anchor) item, counted on the kernel above (add / mul / fma = 1 / 1 / 2, division, sqrt,
+    // exp, log = 1 each): forward 174 (soft-max over 8 cone anchors 39, cone mix + normalise 63, frame 15, resultant / moment / norms
+    // incl. the 7 half-wave reductions 57), backward 190, AdamW on 1 + 8 parameters 116 = 480 flop; x 32 anchors x iters per pair
+    vpho::ProfScope prof(vpho::PROF_FORCE_OPTIM, (hipStream_t)stream, 480.0 * 32.0 * (double)iters * (double)n_batches * B, 0.0);
     hipLaunchKernelGGL(force_optim_kernel, dim3(n_batches), dim3(FO_THREADS), 0, (hipStream_t)stream, a);
     return vpho::check_launch("force_optim_kernel");
 }

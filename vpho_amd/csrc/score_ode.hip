@@ -273,6 +273,161 @@ __global__ __launch_bounds__(512) void pose_encoder_kernel(const PoseEncArgs a) 
     }
 }
 
+// Round 4: the same two layers with the weight fragments in REGISTERS.  A wave only ever reads its own 32 rows of a weight chunk,
+// so the ring above used LDS as a prefetch buffer, not for sharing: 96 of the kernel's 143 KB, which made a workgroup own its CU --
+// under the pipelined evaluator a pose-encoder workgroup had to wait until BOTH convolution workgroups of a CU had drained (135 us
+// average against 22 us exclusive), 102 times per step on the sampler's serial chain.  Here a lane loads its B fragments
+// (W[32 wave + lane&31][32 c + 8 kk + 4 (lane>>5) .. +3], 16 bytes) straight from L2 into a three-chunk register ring, three chunks
+// ahead of their use; the k order of the products is the ring kernel's, so the outputs are bit-identical.  What is left in LDS: the
+// A operand (stage state X, then -- aliased, the state is dead by then -- the 32 x 256 intermediate) and the biases: 35 KB, three
+// workgroup barriers instead of twelve, <= 128 registers: the footprint of ONE direct-convolution workgroup, so it takes the next
+// free slot of any CU instead of a whole CU.
+template <int N1>
+__global__ __launch_bounds__(512, 4) void pose_encoder_reg_kernel(const PoseEncArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int K1 = N1 * 32, X_LD = K1 + 4, NCH = N1 + 8;
+    float* H1 = smem;                              // [32][PE_H_LD]   (layer 2's A operand)
+    float* Xs = smem;                              // [32][X_LD]      (layer 1's A operand; dead before H1 is written)
+    float* Bs = smem + PE_ROWS * PE_H_LD;          // [2][256] biases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int r0 = blockIdx.x * PE_ROWS;
+    if (ctl_skip(a.ctl, a.ctl_mode)) return;
+    KSlots ks = a.ks;
+    const double* yv = a.y;
+    double* ynew = a.ynew;
+    double lch = a.lc.h;
+    if (a.ctl && a.ctl_mode == 1 && a.use_lc) {
+        const int par = a.ctl->parity, sw = a.ctl->kswap;
+        yv = par ? a.ybuf1 : a.ybuf0;
+        ynew = a.write_ynew ? (par ? a.ybuf0 : a.ybuf1) : nullptr;
+        lch = a.ctl->h;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ks.p[j] = a.kbase + (long long)kslot(j, sw) * a.n_el;
+    }
+    struct WFrag { f32x4 b[4]; };
+    const float* w0row = a.w0 + (long long)(wave * 32 + li) * a.Dp + 4 * lh;
+    const float* w2row = a.w2 + (long long)(wave * 32 + li) * 256 + 4 * lh;
+    auto wload = [&](int c, WFrag& w) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (c < N1) {
+                const int k = c * 32 + 8 * kk + 4 * lh;                      // beyond Dp: load column 0 instead and drop it (no branch)
+                const f32x4 v = *reinterpret_cast<const f32x4*>(k < a.Dp ? w0row + c * 32 + 8 * kk : w0row - 4 * lh);
+                w.b[kk] = k < a.Dp ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                w.b[kk] = *reinterpret_cast<const f32x4*>(w2row + (c - N1) * 32 + 8 * kk);
+            }
+        }
+    };
+    WFrag wr[3];
+    wload(0, wr[0]);
+    wload(1, wr[1]);
+    wload(2, wr[2]);
+    __builtin_amdgcn_sched_barrier(0);       // the first three weight chunks are out and stay in flight (L2 hits) while the stage state is formed
+
+    Bs[tid] = tid < 256 ? a.b0[tid] : a.b2[tid - 256];
+    for (int i = tid; i < PE_ROWS * (K1 / 4); i += 512) {
+        const int r = i / (K1 / 4), c = (i - r * (K1 / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < a.R && c < a.Dp) {
+            if (!a.use_lc) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(r0 + r) * a.Dp + c);
+            else {
+                // all seven stage slots are loaded up front (one memory round trip instead of lc.n dependent ones);
+                // slots >= lc.n are read from slot 0 and never enter the sum, which keeps its order j = 0..n-1
+                const long long e0 = (long long)(r0 + r) * a.D + c;
+                float kv[7][4];
+                double yl[4];
+                if ((a.D & 3) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const f32x4 k4 = *reinterpret_cast<const f32x4*>(ks.p[j < a.lc.n ? j : 0] + e0);
+                        kv[j][0] = k4[0]; kv[j][1] = k4[1]; kv[j][2] = k4[2]; kv[j][3] = k4[3];
+                    }
+                    const f64x2 y01 = *reinterpret_cast<const f64x2*>(yv + e0), y23 = *reinterpret_cast<const f64x2*>(yv + e0 + 2);
+                    yl[0] = y01[0]; yl[1] = y01[1]; yl[2] = y23[0]; yl[3] = y23[1];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long long e = c + u < a.D ? e0 + u : e0;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) kv[j][u] = ks.p[j < a.lc.n ? j : 0][e];
+                        yl[u] = yv[e];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) sacc = j < a.lc.n ? sacc + (double)kv[j][u] * a.lc.c[j] : sacc;
+                    const double xv = yl[u] + sacc * lch;
+                    if (c + u < a.D) {
+                        v[u] = (float)xv;
+                        if (ynew) ynew[e0 + u] = xv;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(Xs + r * X_LD + c) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    struct AFrag { f32x4 a[4]; };
+    auto aload = [&](int c, AFrag& f) {
+        const float* As = c < N1 ? Xs + li * X_LD + c * 32 + 4 * lh : H1 + li * PE_H_LD + (c - N1) * 32 + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) f.a[kk] = *reinterpret_cast<const f32x4*>(As + kk * 8);
+    };
+    auto mfmas = [&](const AFrag& f, const WFrag& w) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk][q], w.b[kk][q], acc, 0, 0, 0);
+    };
+    AFrag fa[2];
+    aload(0, fa[0]);
+    // the sched_barriers pin the order "next A fragments, this chunk's 16 MFMAs, the weight loads of chunk c + 3": left to itself the
+    // scheduler sinks every weight load to just in front of its use (shorter live ranges under the 128-register cap): 4 MFMAs of cover
+    // for an L2 round trip instead of 2 chunks
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH && c + 1 != N1) aload(c + 1, fa[(c + 1) & 1]);       // next chunk's A fragments while this chunk multiplies
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa[c & 1], wr[c % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 < NCH) wload(c + 3, wr[c % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 == N1) {
+            // layer boundary: every wave's last reads of Xs are consumed (their products have issued) before H1 = relu(acc + b0) is
+            // written over it, and H1 is complete in every wave before anyone reads it as the next A operand
+            __syncthreads();
+            const int col = wave * 32 + li;
+            const float bv = Bs[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = acc[e] + bv;
+                H1[row * PE_H_LD + col] = v > 0.f ? v : 0.f;
+                acc[e] = 0.f;
+            }
+            __syncthreads();
+            aload(N1, fa[N1 & 1]);
+        }
+    }
+    const int col = wave * 32 + li;
+    const float bv = Bs[256 + col];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < a.R) {
+            const float v = acc[e] + bv;
+            a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------- fused score head
 struct HeadArgs {
     const float* w1p;    // [NH][256]
@@ -1023,14 +1178,29 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         pa.ctl = cc.mode ? c.ws.ctl : nullptr; pa.ctl_mode = cc.mode; pa.write_ynew = cc.write_ynew; pa.kbase = c.ws.K; pa.n_el = c.n_el;
         pa.ybuf0 = c.ws.y; pa.ybuf1 = c.ws.ynew;
         const int K1 = (pa.Dp + 31) / 32 * 32;
-        const size_t pe_lds = (size_t)(PE_NST * PE_STAGE + PE_ROWS * PE_H_LD + 512 + PE_ROWS * (K1 + 4)) * sizeof(float);
-        static bool pe_opt_in = false;
-        if (!pe_opt_in) {
-            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            pe_opt_in = true;
+        const char* pe_env = getenv("VPHO_PE_RING");                            // round 3's LDS-ring kernel (A/B measurements, read per call)
+        const bool pe_ring = pe_env && atoi(pe_env);
+        const dim3 pe_grid((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS));
+        vpho::ProfScope pe_prof(vpho::PROF_POSE_ENC, c.s, 2.0 * (double)c.R * 256.0 * (K1 + 256.0), 0.0);
+        if (pe_ring) {
+            const size_t pe_lds = (size_t)(PE_NST * PE_STAGE + PE_ROWS * PE_H_LD + 512 + PE_ROWS * (K1 + 4)) * sizeof(float);
+            static bool pe_opt_in = false;
+            if (!pe_opt_in) {
+                VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                pe_opt_in = true;
+            }
+            VPHO_REQUIRE(pe_lds <= 150 * 1024, "pose encoder: input dimension %d too large for the LDS tile", pa.Dp);
+            hipLaunchKernelGGL(pose_encoder_kernel, pe_grid, dim3(512), pe_lds, c.s, pa);
+        } else {
+            const size_t pe_lds = (size_t)(PE_ROWS * PE_H_LD + 512) * sizeof(float);            // 35 328 B
+            VPHO_REQUIRE(K1 <= 128 && (pa.Dp & 3) == 0, "pose encoder: input dimension %d (padded %d) not supported (<= 128, multiple of 4)", c.w->D, pa.Dp);
+            switch (K1 / 32) {
+                case 1: hipLaunchKernelGGL(pose_encoder_reg_kernel<1>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
+                case 2: hipLaunchKernelGGL(pose_encoder_reg_kernel<2>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
+                case 3: hipLaunchKernelGGL(pose_encoder_reg_kernel<3>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
+                default: hipLaunchKernelGGL(pose_encoder_reg_kernel<4>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
+            }
         }
-        VPHO_REQUIRE(pe_lds <= 150 * 1024, "pose encoder: input dimension %d too large for the LDS tile", pa.Dp);
-        hipLaunchKernelGGL(pose_encoder_kernel, dim3((unsigned)((c.R + PE_ROWS - 1) / PE_ROWS)), dim3(512), pe_lds, c.s, pa);
         if (int e = vpho::check_launch("pose_encoder_kernel")) return e;
     }
     VPHO_REQUIRE((double)c.R * 256.0 * 4.0 < 4.0e9, "score head: %lld hypothesis rows exceed the 32-bit buffer offsets", (long long)c.R);

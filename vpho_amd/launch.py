@@ -44,6 +44,15 @@ def launched_by_torchrun():
     return 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
 
 
+def _die_with_parent():
+    """preexec_fn of the launcher child (runs between fork and exec, nothing has touched a GPU): prctl(PR_SET_PDEATHSIG, SIGTERM)"""
+    try:
+        import ctypes
+        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)
+    except Exception:
+        pass
+
+
 def maybe_spawn(gpus, script=None, argv=None):
     """Call FIRST in main(), before importing anything that may touch the GPU.  Returns normally in a rank process (or for
     N == 1); in the parent of an N > 1 job it never returns: it runs the ranks as a child process group and exits with
@@ -53,9 +62,12 @@ def maybe_spawn(gpus, script=None, argv=None):
     script = script or os.path.abspath(sys.argv[0])
     argv = sys.argv[1:] if argv is None else argv
     cmd = launch_command(script, gpus, argv)
-    # the ranks run in their own session (process group): a SIGTERM / SIGINT that reaches only this parent (a scheduler or watchdog
-    # killing one PID) is forwarded to the whole group, so no rank is left behind holding a GPU; still a CHILD, never an exec
-    child = subprocess.Popen(cmd, env=child_env(gpus), start_new_session=True)
+    # the ranks run in their own session (process group): a SIGTERM / SIGINT / SIGHUP / SIGQUIT that reaches only this parent (a
+    # scheduler or watchdog killing one PID, a terminal or ssh hang-up -- the ranks' session has no controlling tty, so they would never
+    # see it) is forwarded to the whole group, so no rank is left behind holding a GPU; and should this parent die without running its
+    # handlers (SIGKILL), the kernel sends the launcher child SIGTERM (PR_SET_PDEATHSIG), which torch.distributed.run passes on to its
+    # ranks.  Still a CHILD, never an exec
+    child = subprocess.Popen(cmd, env=child_env(gpus), start_new_session=True, preexec_fn=_die_with_parent)
 
     def forward(signum, frame):
         try:
@@ -63,7 +75,7 @@ def maybe_spawn(gpus, script=None, argv=None):
         except ProcessLookupError:
             pass
 
-    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP, signal.SIGQUIT)}
     try:
         rc = child.wait()
     finally:

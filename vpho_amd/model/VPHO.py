@@ -128,7 +128,15 @@ class _DepositGrads(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        # a parameter no loss of this batch reached: under a process group an explicit zero, so that DistributedDataParallel's hook for it
+        # fires and every rank steps every tensor; single-process None, like the reference's autograd -- torch optimisers skip
+        # such a parameter (no weight decay, no momentum update), as DiffusionTrainStep.step() does
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         out = []
         for gr, (shape, dtype, device) in zip(ctx.grads, ctx.meta):
-            out.append(torch.zeros(shape, dtype=dtype, device=device) if gr is None else gr.reshape(shape).to(dtype) * g)
+            if gr is None:
+                out.append(torch.zeros(shape, dtype=dtype, device=device) if ddp else None)
+            else:
+                out.append(gr.reshape(shape).to(dtype) * g)
         return (None, None, *out)

@@ -635,6 +635,11 @@ class AnchorTables(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('face_idx', 'anchor_weight', 'vert2joint', 'skeleton')]
 
 
+def _ids_to_device(ids, device):
+    host = torch.tensor(ids, dtype=torch.int32).pin_memory()        # the caching host allocator keeps the block until the copy's event
+    return host.to(device, non_blocking=True)
+
+
 class Aggregation:
     """Device tables + thin wrappers of the aggregation kernels."""
 
@@ -642,7 +647,6 @@ class Aggregation:
         ycb = assets['ycb']
         self.names = list(ycb.keys())
         self.name_to_id = {n: i for i, n in enumerate(self.names)}
-        self._ids = {}
         f = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
         stack = lambda key: torch.stack([torch.as_tensor(ycb[n][key], dtype=torch.float32).reshape(-1, 3) for n in self.names]).to(device).contiguous()
         self.kpt, self.vert = stack('kpt3d'), stack('verts_sampled')
@@ -657,15 +661,10 @@ class Aggregation:
         self.device = device
 
     def obj_ids(self, names):
-        """class indices of a batch as a device tensor; kept per name tuple: building it is a synchronous host-to-device copy, which in the
-        middle of a step would park the calling thread behind everything already queued on its stream"""
-        key = tuple(names)
-        ids = self._ids.get(key)
-        if ids is None:
-            if len(self._ids) > 256:
-                self._ids.clear()
-            ids = self._ids[key] = torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
-        return ids
+        """class indices of a batch as a device tensor: filled into pinned host memory and copied asynchronously on the CALLER's current
+        stream, every call (a pageable-memory copy would park the calling thread behind everything queued on its stream; a cache shared
+        by the evaluator's slot threads would hand a tensor allocated on one stream to kernels of another -- ADVICE r3)"""
+        return _ids_to_device([self.name_to_id[n] for n in names], self.device)
 
     def hand_candidates(self, diff_pose, reg_pose, bs, S):
         pose = _new((bs, 2 * S, 48), diff_pose)
@@ -836,7 +835,6 @@ class ObjectMetrics:
         import numpy as np
         self.names = list(ycb.keys())
         self.name_to_id = {n: i for i, n in enumerate(self.names)}
-        self._ids = {}
         d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
         self.bbox3d = d(np.stack([np.asarray(ycb[n]['bbox3d']).reshape(8, 3) for n in self.names]))
         self.verts_sampled = d(np.stack([np.asarray(ycb[n]['verts_sampled']).reshape(-1, 3) for n in self.names]))
@@ -850,15 +848,10 @@ class ObjectMetrics:
         self.device = device
 
     def obj_ids(self, names):
-        """class indices of a batch as a device tensor; kept per name tuple: building it is a synchronous host-to-device copy, which in the
-        middle of a step would park the calling thread behind everything already queued on its stream"""
-        key = tuple(names)
-        ids = self._ids.get(key)
-        if ids is None:
-            if len(self._ids) > 256:
-                self._ids.clear()
-            ids = self._ids[key] = torch.tensor([self.name_to_id[n] for n in names], dtype=torch.int32, device=self.device)
-        return ids
+        """class indices of a batch as a device tensor: filled into pinned host memory and copied asynchronously on the CALLER's current
+        stream, every call (a pageable-memory copy would park the calling thread behind everything queued on its stream; a cache shared
+        by the evaluator's slot threads would hand a tensor allocated on one stream to kernels of another -- ADVICE r3)"""
+        return _ids_to_device([self.name_to_id[n] for n in names], self.device)
 
     def __call__(self, pd_rt, gt_rt, cam_intr, obj_id):
         """pd_rt, gt_rt (n,3,4), cam_intr (n,3,3) fp64, obj_id (n,) int32 -> (n,16) fp64 in the order of OBJ_METRIC_NAMES."""
@@ -1131,7 +1124,8 @@ def physics_loss(scale_raw, logits, com, anchor, frame, point, gt_force_local, g
 
 # ----------------------------------------------------------------------------------------------- profiling hooks
 PROF_CLASSES = {'conv_igemm_128x128': 0, 'conv_igemm_64x64': 1, 'score_head': 2, 'conv_igemm_128x64': 3,
-                'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8, 'conv_winograd': 9}
+                'mano_fk': 4, 'obj_physics': 5, 'hand_fuse': 6, 'roi_align': 7, 'resize_bilinear': 8, 'conv_winograd': 9,
+                'conv_wgrad_64x64': 10, 'conv_wgrad_128x128': 11, 'force_optim': 12, 'pose_encoder': 13}
 
 
 _prof_on = False
