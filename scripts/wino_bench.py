@@ -1,6 +1,6 @@
 """Winograd F(2x2,3x3) kernel against the direct implicit-GEMM kernel on the feature path's 3x3 / stride-1 layers: error and time."""
 import sys, time, torch
-sys.argv = sys.argv[:1]; sys.path.insert(0, '.')
+import os; sys.argv = sys.argv[:1]; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpho_amd import ops
 from vpho_amd.model.pack import winograd_weights
 dev = 'cuda'

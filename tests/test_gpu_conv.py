@@ -180,3 +180,29 @@ def test_winograd_3x3_matches_fp64_and_the_direct_kernel(N, H, W, Cin, Cout, cap
     assert ew <= 2 * ed + 1e-9 and ew < 5e-6, (ed, ew)
     with capsys.disabled():
         print(f'\n[winograd] {(N, H, W, Cin, Cout)}: max error vs fp64: direct {ed:.2e}, winograd {ew:.2e}', end='')
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(4, 32, 32, 128, 128), (3, 8, 8, 512, 64), (2, 4, 6, 16, 64), (5, 64, 64, 64, 64), (2, 16, 16, 48, 192), (9, 16, 16, 256, 256)])
+def test_two_waves_per_simd_winograd_is_bit_identical_to_the_one_wave_kernel(N, H, W, Cin, Cout):
+    """round 4: conv_winograd8_kernel (8 waves, each frequency half of a 32 x 32 block in its own wave, producer roles alternating between
+    the two waves of a SIMD, output-transform exchange through LDS; VPHO_WINO8=1) against conv_winograd_kernel (VPHO_WINO8=0): same k order,
+    same transform expressions -> bit-identical, incl. Cin = 16 (one super-stage), an odd number of super-stages (Cin = 48), ragged tile
+    blocks and Cout = 192 (three channel blocks: the non-XCD block order)."""
+    import os
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv, winograd_weights
+    x = _rand((N, H, W, Cin), 70).cuda()
+    w = _rand((Cout, Cin, 3, 3), 71, (2.0 / (9 * Cin)) ** 0.5)
+    b = _rand((Cout,), 72).cuda()
+    u = winograd_weights(pack_conv(w).cuda())
+    try:
+        os.environ['VPHO_WINO8'] = '1'
+        y8 = ops.conv3x3_winograd(x, u, b, 0.01)
+        os.environ['VPHO_WINO8'] = '0'
+        y4 = ops.conv3x3_winograd(x, u, b, 0.01)
+    finally:
+        os.environ.pop('VPHO_WINO8', None)
+    assert torch.isfinite(y8).all() and float(y8.abs().max()) > 0.1
+    assert torch.equal(y8, y4)
+    ref = F.leaky_relu(F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w.double(), b.cpu().double(), 1, 1), 0.01)
+    _close(y8.permute(0, 3, 1, 2), ref, tol=3e-6)

@@ -84,9 +84,10 @@ def main():
            'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
            'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),
            'loss_first': first, 'loss_last': {k: float(v) for k, v in L.items()}}
-    if rank == 0:
+    if True:
         # roofline of the step's dominant kernel, measured live: HIP events around every weight-gradient launch (conv_wgrad.hip) in a
-        # separate instrumented repeat of the step (the events serialise nothing, but they are kept out of the timed region)
+        # separate instrumented repeat of the step (the events serialise nothing, but they are kept out of the timed region).  EVERY rank
+        # runs the repeat -- the step's gradient exchange is collective --, rank 0 reports its own kernels
         from vpho_amd import ops
         names = ('conv_wgrad_64x64', 'conv_wgrad_128x128')
         for nm in names:

@@ -36,6 +36,7 @@ struct WinoArgs {
     const int* wins;                           // [N][5] = (first row, y0, x0, w, h) or NULL
     const int* tile_base;                      // [N + 1] first tile of every image; [N] = live tiles (vpho_winograd_window_tiles_i32)
     int scatter;                               // with wins: 1 = y is the ordinary (N,H,W,y_ld) map, window pixels written in place, the rest untouched
+    int abl;                                   // timing ablations of conv_winograd8_kernel (VPHO_WINO_ABL; wrong results): 1 no transform / V stores, 2 no patch loads, 4 no U fill, 8 no exchange epilogue, 16 no stage barrier
 };
 
 // tile t -> image n, tile coordinates (ty, tx) on the image's even grid; false past the last live tile
@@ -277,6 +278,224 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4 experiment, used for the short-K layers only (see wino_launch): the same arithmetic with TWO waves per SIMD.  conv_winograd_kernel keeps all 16 frequencies of a 32 x 32 (tile, channel) block
+// in one wave: 256 accumulator registers, ONE wave per SIMD -- whatever that wave does besides matrix instructions (patch loads, the
+// input transform, V stores, waits) is time the matrix pipe idles (PMC: 0.61 busy; the floor of a pure MFMA loop is 0.79 of the kernel's
+// time).  Here a workgroup is 8 waves: wave (q, fh) holds the frequencies fy in {2 fh, 2 fh + 1} (8 of 16: 128 accumulators) of the
+// 32 x 32 block q = (wt, wc).  The two waves that share a SIMD alternate roles: the four waves of one frequency half PRODUCE V for the
+// even 16-channel super-stages, the other four for the odd ones (patch loads two stages ahead of their transform: one 64-register patch
+// buffer, no second one), so a wave's load / transform stretches meet its SIMD partner's matrix instructions.  Same stage layout in LDS,
+// same U, same k order, same transform expressions: the output is bit-identical to conv_winograd_kernel.  Only the output transform
+// needs an exchange, once per workgroup: A^T M A mixes all four fy, so each wave hands its partner the half of its accumulators the
+// partner finishes (16 KB per wave through the idle stage buffers) and transforms the other half of the tile rows itself.
+__global__ __launch_bounds__(512) void conv_winograd8_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+    const int q = wave & 3, fh = wave >> 2, wt = q & 1, wc = q >> 1;
+    const int ncb = a.Cout / W_CB;
+    int tb, cb;
+    if (ncb <= 8 && (8 % ncb) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, G = 8 / ncb;
+        cb = xcd % ncb; tb = slot * G + xcd / ncb;
+    } else { tb = blockIdx.x / ncb; cb = blockIdx.x % ncb; }
+    if (tb * W_TB >= a.T) return;
+    const int t0 = tb * W_TB, c0 = cb * W_CB;
+    if (a.wins && t0 >= a.tile_base[a.N]) return;
+    __shared__ int s_row[W_TB], s_pitch[W_TB];
+    if (tid < W_TB) {
+        int n, ty, tx, row = 0, pitch = (a.W << 4);
+        if (wino_tile(a, t0 + tid, n, ty, tx)) {
+            if (!a.wins) { row = (n * a.H + 2 * ty) * a.W + 2 * tx; pitch = (a.W << 4) | 0xF; }
+            else {
+                const int* w = a.wins + 5 * n;
+                const int y = 2 * ty - w[1], x = 2 * tx - w[2];
+                const int my = (y >= 0 ? 1 : 0) | (y + 1 < w[4] ? 2 : 0), mx = (x >= 0 ? 1 : 0) | (x + 1 < w[3] ? 2 : 0);
+                row = a.scatter ? (n * a.H + 2 * ty) * a.W + 2 * tx : w[0] + y * w[3] + x;
+                pitch = ((a.scatter ? a.W : w[3]) << 4) | ((my & 1) && (mx & 1) ? 1 : 0) | ((my & 1) && (mx & 2) ? 2 : 0) | ((my & 2) && (mx & 1) ? 4 : 0) | ((my & 2) && (mx & 2) ? 8 : 0);
+            }
+        }
+        s_row[tid] = row; s_pitch[tid] = pitch;
+    }
+
+    // ---- V producer (the four waves of one frequency half at a time): thread = (tile tl, channel quad cp) of a 16-channel super-stage
+    const int tl = q * 16 + (lane >> 2), cp = lane & 3;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0xFFFFFFF0u, 0x00020000);
+    // patch addressing without a 16-register offset table: the offset of the patch's (virtual) top-left pixel + one validity bit per pixel
+    int pbase;
+    unsigned pmask = 0;
+    {
+        int pn = 0, ty = 0, tx = 0;
+        const bool tile_live = wino_tile(a, t0 + tl, pn, ty, tx);
+        const int py0 = 2 * ty - 1, px0 = 2 * tx - 1;
+        pbase = (int)((((long long)(pn * a.H + py0) * a.W + px0) * a.x_ld + 4 * cp) * 4);       // mod 2^32; only used where the pixel is valid
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int iy = py0 + (p >> 2), ix = px0 + (p & 3);
+            if (tile_live && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) pmask |= 1u << p;
+        }
+    }
+    const int row_b = a.W * a.x_ld * 4, pix_b = a.x_ld * 4;
+    f32x4 pc[16];
+    auto load_patch = [&](int ss) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int live = -(int)((pmask >> p) & 1u);                    // all ones / zero: no branch per pixel
+            const int off = ((pbase + (p >> 2) * row_b + (p & 3) * pix_b) & live) | ~live;                // dead pixel: offset -1, out of range, the hardware returns zeros
+            pc[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, ss * 64, 0));
+        }
+    };
+    const int sw = (tl >> 3) & 1;
+    // B^T d B of channel pair e of the patch buffer -> V of one k stage (the expressions of conv_winograd_kernel::row_transform / store_v_row)
+    auto produce = [&](int e, int buf) {
+        float* V = smem + buf * W_STAGE;
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+            f32x2 r[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x2 p0 = e ? f32x2{pc[0 * 4 + c][2], pc[0 * 4 + c][3]} : f32x2{pc[0 * 4 + c][0], pc[0 * 4 + c][1]};
+                const f32x2 p1 = e ? f32x2{pc[1 * 4 + c][2], pc[1 * 4 + c][3]} : f32x2{pc[1 * 4 + c][0], pc[1 * 4 + c][1]};
+                const f32x2 p2 = e ? f32x2{pc[2 * 4 + c][2], pc[2 * 4 + c][3]} : f32x2{pc[2 * 4 + c][0], pc[2 * 4 + c][1]};
+                const f32x2 p3 = e ? f32x2{pc[3 * 4 + c][2], pc[3 * 4 + c][3]} : f32x2{pc[3 * 4 + c][0], pc[3 * 4 + c][1]};
+                r[c] = fy == 0 ? p0 - p2 : fy == 1 ? p1 + p2 : fy == 2 ? p2 - p1 : p1 - p3;
+            }
+            const f32x2 vv[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+#pragma unroll
+            for (int fx = 0; fx < 4; ++fx)
+                *reinterpret_cast<f32x2*>(V + ((fy * 4 + fx) * 64 + tl) * WK + (((cp >> 1) ^ sw) * 4) + (cp & 1) * 2) = vv[fx];
+        }
+    };
+    // ---- U fill: 32 wave instructions of 1 KB per stage, 4 per wave
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int ustage = 16 * a.Cout * WK * 4;
+    int uoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int fr = (wave * 4 + j) * 32 + (lane >> 1);
+        const int f = fr >> 6, r_ = fr & 63;
+        const int ch = (lane & 1) ^ ((r_ >> 3) & 1);
+        const int co = c0 + r_;
+        uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * WK + ch * 4) * 4) : -1;
+    }
+    auto fill_u = [&](int buf, int kc) {
+        float* U = smem + buf * W_STAGE + 16 * 64 * WK + wave * 4 * 32 * WK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * ustage, 0, 0);
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+
+    const int nss = a.Cin / (2 * WK), nst = 2 * nss;
+    const int fsw = (li >> 3) & 1;
+    // prologue: group fh owns the super-stages ss = fh (mod 2).  Group 0 produces V of stage 0; group 1's first patches are on their way
+    fill_u(0, 0);
+    if (fh == 0 || nss > 1) load_patch(fh);
+    if (fh == 0) produce(0, 0);
+    VPHO_SYNC_LDS_DMA();
+    for (int kc = 0; kc < nst; ++kc) {
+        const int buf = kc & 1;
+        const int ph = (kc + 2 * fh) & 3;               // 1: request the patches of super-stage (kc + 3) / 2; 2: they travel; 3 / 0: transform pair 0 / 1
+        // transform phases FIRST consume their patches (landed two stages ago) and only then request U: vector-memory operations complete
+        // in order, so a wait for a patch register behind a freshly issued fill would wait for the fill; the request phase issues the
+        // fill first, so that its stage-end wait (vmcnt(16)) covers the fill and lets the 16 patch loads fly
+        const bool loads = ph == 1 && (kc + 3) / 2 < nss && !(a.abl & 2);
+        if (ph == 3) { if ((kc + 1) / 2 < nss && !(a.abl & 1)) produce(0, buf ^ 1); }            // V of stage kc + 1 = 2 ss
+        else if (ph == 0 && !(a.abl & 1)) produce(1, buf ^ 1);                                    // V of stage kc + 1 = 2 ss + 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nst && !(a.abl & 4)) fill_u(buf ^ 1, kc + 1);
+        if (loads) load_patch((kc + 3) / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* V = smem + buf * W_STAGE + ((fh * 8) * 64 + wt * 32 + li) * WK + ((lh ^ fsw) * 4);
+        const float* U = smem + buf * W_STAGE + 16 * 64 * WK + ((fh * 8) * 64 + wc * 32 + li) * WK + ((lh ^ fsw) * 4);
+        f32x4 av[2], bv[2];
+        av[0] = *reinterpret_cast<const f32x4*>(V);
+        bv[0] = *reinterpret_cast<const f32x4*>(U);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            if (f < 7) {
+                av[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(V + (f + 1) * 64 * WK);
+                bv[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(U + (f + 1) * 64 * WK);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f & 1][k], bv[f & 1][k], acc[f], 0, 0, 0);
+            // the next frequency's fragments are REQUESTED before this frequency's four matrix instructions issue (left alone the compiler
+            // reads two frequencies, waits, and issues their eight MFMAs: an LDS round trip exposed every 512 cycles)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // U of the next stage must have landed; patches requested in this stage (after the fills) may stay in flight
+        if (a.abl & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else if (loads) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
+        else VPHO_SYNC_LDS_DMA();
+    }
+
+    // ---- output transform.  Wave (q, fh) finishes the accumulator rows e in [8 fh, 8 fh + 8) of its 32 x 32 block; the other 8 rows of
+    // its 8 frequencies go to the partner (q, 1 - fh) through LDS: [wave][f 0..7][e 0..7][lane]
+    float* X = smem;
+    {
+        // [wave][e8 0..7][frequency quad 0..1][lane][4]: 16-byte stores and loads, lane-contiguous (conflict-free)
+        f32x4* mine = reinterpret_cast<f32x4*>(X + wave * (8 * 8 * 64)) + lane;
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+            for (int hv = 0; hv < 2; ++hv) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fh ? acc[4 * hv + k][e8] : acc[4 * hv + k][8 + e8];
+                mine[(e8 * 2 + hv) * 64] = v;
+            }
+    }
+    __syncthreads();
+    const f32x4* theirs = reinterpret_cast<const f32x4*>(X + (wave ^ 4) * (8 * 8 * 64)) + lane;
+    const int co = c0 + wc * 32 + li;
+    const float bias = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+        const int e = 8 * fh + e8;
+        const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float m[16];                                     // all 16 frequencies of this (tile, channel): own half from registers, the other from LDS
+        const f32x4 t0 = theirs[(e8 * 2 + 0) * 64], t1 = theirs[(e8 * 2 + 1) * 64];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float own = fh ? acc[f][8 + e8] : acc[f][e8];
+            const float oth = f < 4 ? t0[f & 3] : t1[f & 3];
+            m[fh * 8 + f] = own;
+            m[(1 - fh) * 8 + f] = oth;
+        }
+        float s0[4], s1[4];
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+            s0[fx] = m[0 * 4 + fx] + m[1 * 4 + fx] + m[2 * 4 + fx];
+            s1[fx] = m[1 * 4 + fx] - m[2 * 4 + fx] - m[3 * 4 + fx];
+        }
+        const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+        const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+        const int pm = s_pitch[trow];
+        if ((pm & 0xF) && co < a.Cout) {
+            const int pitch = pm >> 4;
+            float* yp = a.y + (long long)s_row[trow] * a.y_ld + co;
+            const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
+            const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
+            const float* gp = a.gate ? a.gate + (long long)s_row[trow] * a.y_ld + co : nullptr;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
+                float v = o[p];
+                if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
+                yp[offs[p]] = v > 0.f ? v : v * a.out_slope;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // tile_base[n] = first tile of image n, tile_base[N] = number of live tiles: the 2 x 2 tiles of the even grid that touch window n
@@ -375,6 +594,7 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
     a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope; a.scatter = scatter;
+    { const char* ab = getenv("VPHO_WINO_ABL"); a.abl = ab ? atoi(ab) : 0; }
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {
@@ -390,6 +610,21 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     const int ncb = Cout / W_CB;
     unsigned blocks = (unsigned)(tbs * ncb);
     if (ncb <= 8 && (8 % ncb) == 0) { const int G = 8 / ncb; blocks = (unsigned)((tbs + G - 1) / G) * 8u; }
-    hipLaunchKernelGGL(conv_winograd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    return vpho::check_launch("conv_winograd_kernel");
+    // Which kernel: measured on MI355X (scripts/wino_bench.py, profiles/r04_winograd_two_waves.txt) the 8-wave kernel wins only where a
+    // tile has few k stages (Cin = 64: 124 against 131 us at 64 x 64 x 64 images) -- its per-stage barrier joins 8 unequally loaded waves
+    // and costs 14 % of its time against 4 % for the 4-wave kernel -- and loses 1 ... 10 % on the long-K layers.  VPHO_WINO8 = 1 / 0 forces
+    // either kernel (read per call; the two are bit-identical, tests/test_gpu_conv.py).
+    const char* w8 = getenv("VPHO_WINO8");
+    const bool use8 = w8 ? atoi(w8) != 0 : Cin <= 64;
+    if (!use8) {
+        hipLaunchKernelGGL(conv_winograd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+        return vpho::check_launch("conv_winograd_kernel");
+    }
+    static bool opt_in8 = false;
+    if (!opt_in8) {
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        opt_in8 = true;
+    }
+    hipLaunchKernelGGL(conv_winograd8_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, a);
+    return vpho::check_launch("conv_winograd8_kernel");
 }
