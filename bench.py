@@ -26,7 +26,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 FEATURE_GFLOP_PER_IMAGE = 37.09
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-HBM_LIMITS = {'mano_fk': 'vector ALU, not HBM: pose blend [hands x 135] x [135 x 2334] + 16-joint transform blend per vertex as packed fp32 FMAs (6 GFLOP per 6400-hand launch); the table streams from L2',
+HBM_LIMITS = {'mano_fk': 'matrix cores / vector ALU, not HBM: pose blend [hands x 135] x [135 x 2334] + 16-joint transform blend per vertex (6 GFLOP per 6400-hand launch) -- fp32 MFMA in mano_fk_mfma_kernel (the one launch with vertices for all hypotheses: 105 us, and the class\'s HBM bytes: 12-byte vertex stores reach HBM as 1.9 x their size), packed fp32 FMAs in the joints-only mano_fk_kernel<HB> launches; the tables stream from L2',
               'obj_physics': 'vector ALU: 65 536 squared distances per candidate from an LDS-resident point cloud',
               'hand_fuse': 'latency: one workgroup per (image, finger) -- ranking by counting, 30 quaternions, a 4x4 Jacobi eigen-solve',
               'roi_align': 'HBM / L2 gather: window rows read once, pooled output written once',
@@ -212,7 +212,7 @@ def main():
     # ---- roofline leg: the same K steps again with HIP events recorded around every launch of the timed kernel
     # classes on their launch streams (kept out of the timed region: ~500 event pairs per step perturb it by 10-15 %)
     hbm_classes = ('mano_fk', 'obj_physics', 'hand_fuse', 'roi_align', 'resize_bilinear')
-    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head', 'conv_winograd') + hbm_classes
+    timed_classes = ('conv_igemm_128x128', 'conv_igemm_128x64', 'conv_igemm_64x64', 'score_head', 'conv_winograd', 'pose_encoder') + hbm_classes
     prof = {c: dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0) for c in timed_classes}
     if not args.no_kernel_timing:
         for c in timed_classes:
@@ -278,8 +278,12 @@ def main():
                          else f'conv_igemm_split_kernel<128,128,4,2,{conv_mfma[-1]}> (split-bf16 products, opt-in)', 'achieved': conv_tf,
                          'peak': conv_peak, 'unit': 'TFLOP/s', 'frac': conv_tf / conv_peak,
                          'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>') or pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
+                         'traffic_source': (pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>', per_kernel=True) or {}).get('source'),
                          'timing': 'HIP events around every launch, in a separate instrumented repeat of the K steps',
                          'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
+                         'pose_encoder': ({'TFLOP/s': prof['pose_encoder']['flops'] / (prof['pose_encoder']['total_ms'] * 1e-3) / 1e12, 'frac': prof['pose_encoder']['flops'] / (prof['pose_encoder']['total_ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                           'avg_launch_us': prof['pose_encoder']['total_ms'] * 1e3 / max(prof['pose_encoder']['launches'], 1), 'launches_per_step': prof['pose_encoder']['launches'] / max(args.steps, 1),
+                                           'note': 'durations span the other solve\'s kernels, like score_head'} if prof.get('pose_encoder', {}).get('total_ms', 0) > 0 else None),
                          'other_kernels': {k: {'TFLOP/s': (v['flops'] / (v['total_ms'] * 1e-3) / 1e12 if v['total_ms'] > 0 else 0.0),
                                                'kernel_ms_per_step': v['total_ms'] / max(args.steps, 1),
                                                'launches_per_step': v['launches'] / max(args.steps, 1)}
@@ -312,14 +316,15 @@ def main():
             # HBM-bound kernels of the path (north star: MANO skinning, distance kernels, top-k as GB/s against the chip's HBM peak):
             # achieved = ALGORITHMIC bytes (operands read once + results written once, stated at the launch site) / HIP-event kernel time
             'hbm': {'peak_GBps': HBM_PEAK_GBPS, 'note': 'achieved = algorithmic bytes / kernel time (HIP events, instrumented repeat of the K steps); '
-                                                          'traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE), null when absent',
+                                                          'traffic = HBM bytes per launch from the newest committed rocprofv3 --pmc summary (2 x FETCH_SIZE + WRITE_SIZE; traffic_by_kernel names the file and every kernel of the class, traffic is their launch-weighted mean), null when absent',
                     'kernels': {k: {'GB/s': (prof[k]['bytes'] / (prof[k]['total_ms'] * 1e-3) / 1e9 if prof[k]['total_ms'] > 0 else 0.0),
                                     'frac': (prof[k]['bytes'] / (prof[k]['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS if prof[k]['total_ms'] > 0 else 0.0),
                                     'avg_launch_us': prof[k]['total_ms'] * 1e3 / max(prof[k]['launches'], 1),
                                     'launches_per_step': prof[k]['launches'] / max(args.steps, 1),
                                     'kernel_ms_per_step': prof[k]['total_ms'] / max(args.steps, 1),
                                     'algorithmic_bytes_per_launch': prof[k]['bytes'] / max(prof[k]['launches'], 1),
-                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k]), 'limited_by': HBM_LIMITS[k]} for k in hbm_classes}},
+                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k]), 'traffic_by_kernel': pmc_traffic(HBM_KERNEL_NAMES[k], per_kernel=True),
+                                    'limited_by': HBM_LIMITS[k]} for k in hbm_classes}},
             'metrics_rows_gathered': int(all_rows.shape[0]),
             'host_cpu': host_cpu,
         }
@@ -364,19 +369,28 @@ def opt_in_leg(args, model, batches, E, post):
                                      '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`'}}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` (name prefix) from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE; profiles/r0N_pmc_hbm_traffic.json, produced by scripts/pmc_summary.py, newest round first); None when absent."""
-    for rnd in ('r03', 'r02', 'r01'):
+PMC_ROUNDS = ('r04', 'r03', 'r02', 'r01')
+
+
+def pmc_traffic(kernel, per_kernel=False):
+    """HBM bytes per launch of the kernels whose name starts with `kernel`, LAUNCH-WEIGHTED over them (a profiling class such as
+    mano_fk covers several kernels: the matrix-core FK kernel and the packed-FMA ones), from the newest committed rocprofv3 --pmc
+    summary (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r0N_pmc_hbm_traffic.json by scripts/pmc_summary.py); None when
+    absent.  per_kernel: {'source': file, 'kernels': {name: bytes per launch, launches}} instead."""
+    for rnd in PMC_ROUNDS:
         path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_hbm_traffic.json')
         try:
             with open(path) as f:
                 tab = json.load(f)
         except Exception:
             continue
-        for name, v in tab.items():
-            if name.startswith(kernel) or kernel in name.split('(')[0]:
-                return v['hbm_bytes_per_launch']
+        hit = {name: v for name, v in tab.items() if name.startswith(kernel) or kernel in name.split('(')[0]}
+        if not hit:
+            continue
+        if per_kernel:
+            return {'source': os.path.relpath(path, ROOT), 'kernels': {n: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'launches_in_pass': v['launches']} for n, v in hit.items()}}
+        n = sum(v['launches'] for v in hit.values())
+        return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit.values()) / max(n, 1)
     return None
 
 

@@ -23,7 +23,7 @@ bool prof_on(int cls);
 void prof_record(int cls, hipEvent_t start, hipEvent_t stop, double flops, double bytes);
 struct ProfScope {
     int cls; hipStream_t s; double flops, bytes; bool on; hipEvent_t e0, e1;
-    ProfScope(int c, hipStream_t st, double f, double b = 0) : cls(c), s(st), flops(f), bytes(b), on(prof_on(c)) {
+    ProfScope(int c, hipStream_t st, double f, double b = 0) : cls(c), s(st), flops(f), bytes(b), on(c >= 0 && prof_on(c)) {        // c < 0: never timed
         if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(e1, s); prof_record(cls, e0, e1, flops, bytes); } }

@@ -303,7 +303,9 @@ static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((a.ntiles + 7) / 8 * 8, p.splits);
     // dW[Cout][taps * Cin] = dY^T (M x Cout) . im2col(x) (M x taps * Cin): 2 M Cout K flop; operands read once + dW written once
-    vpho::ProfScope prof(p.bm == 128 ? vpho::PROF_WGRAD128 : vpho::PROF_WGRAD64, s, 2.0 * (double)M * Cout * (double)a.K,
+    // (a launch on a pixel-group list reduces only over the live groups -- device data --: it is timed with its full-size count and
+    // reported as an upper bound by its own class id would mislead, so group launches are left out of the classes)
+    vpho::ProfScope prof(glist ? -1 : (p.bm == 128 ? vpho::PROF_WGRAD128 : vpho::PROF_WGRAD64), s, 2.0 * (double)M * Cout * (double)a.K,
                          4.0 * ((double)N * H * W * Cin + (double)M * Cout + (double)Cout * a.K));
     if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
