@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 VPHO_API const char* vpho_last_error(void);
-VPHO_API int vpho_abi_version(void);   /* 7 */
+VPHO_API int vpho_abi_version(void);   /* 8 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -85,6 +85,14 @@ typedef struct {
      * Cin % 16 == 0, no prologue affine, no splits / gate, 16-byte addressable output rows; other shapes run the fp32 kernels. */
     const void* w_planes;
     int plane_terms;
+    /* Optional (NULL = off; ABI version 8): the residual is a COARSER map, added after bilinear up-sampling to the output grid --
+     * y = act(conv + bias + F.interpolate(res_up, size=(OH, OW), mode='bilinear', align_corners=False)[n, oy, ox, co]) -- the FPN's
+     * top-down step `_upsample_add(p, lateral(c))` (backbone_FPN_HFL.py:66-68,98-104) inside the lateral 1x1 convolution's epilogue:
+     * the finer map is written once instead of written, re-read and re-written by a separate pass.  res_up: (N, ru_H, ru_W, ru_ld)
+     * NHWC, ru_ld % 4 == 0, 16-byte aligned; exclusive with `res`; the same arithmetic, in the same order, as
+     * vpho_resize_bilinear_nhwc_f32(accumulate = 1) after the convolution: bit-identical.  Works with row_map / rows_scatter. */
+    const float* res_up;
+    int ru_H, ru_W, ru_ld;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 VPHO_API int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);

@@ -206,3 +206,44 @@ def test_two_waves_per_simd_winograd_is_bit_identical_to_the_one_wave_kernel(N, 
     assert torch.equal(y8, y4)
     ref = F.leaky_relu(F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w.double(), b.cpu().double(), 1, 1), 0.01)
     _close(y8.permute(0, 3, 1, 2), ref, tol=3e-6)
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout', [(64, 16, 1024, 256), (8, 32, 512, 256), (3, 10, 64, 128), (2, 6, 96, 64)])
+def test_upsampled_residual_in_the_epilogue_equals_the_separate_top_down_pass(N, H, Cin, Cout):
+    """round 4: `_upsample_add(p, lateral(c))` (backbone_FPN_HFL.py:66-68,98-104) inside the lateral 1x1 convolution's epilogue
+    (vpho_conv_desc.res_up): bit-identical to the convolution followed by resize_bilinear_nhwc(accumulate=True), in all three tile
+    classes, odd coarse sizes (10 <- 5, 6 <- 3 and a non-2x ratio 10 <- 4), and against torch (F.interpolate, align_corners=False)."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    x, w, b = _rand((N, Cin, H, H), 80), _rand((Cout, Cin, 1, 1), 81, (2.0 / Cin) ** 0.5), _rand((Cout,), 82)
+    xg, wg, bg = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda()
+    for h in ((H // 2, H // 2), (4, 4) if H == 10 else (H // 2, H // 2)):
+        p = _rand((N, Cout, h[0], h[1]), 83)
+        pg = p.permute(0, 2, 3, 1).contiguous().cuda()
+        fused = ops.conv2d_nhwc(xg, wg, bg, res_up=pg)
+        q = ops.conv2d_nhwc(xg, wg, bg)
+        ops.resize_bilinear_nhwc(pg, H, H, out=q, accumulate=True)
+        assert torch.equal(fused, q)
+        ref = F.conv2d(x, w, b) + F.interpolate(p, size=(H, H), mode='bilinear', align_corners=False)
+        _close(fused.permute(0, 3, 1, 2), ref)
+
+
+def test_upsampled_residual_on_scattered_roi_windows():
+    """the stride-4 FPN level: lateral convolution + top-down add only on the pixels of the dilated RoI windows, written in place"""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    N, H, Cin, Cout = 6, 64, 256, 256
+    x, w, b = _rand((N, Cin, H, H), 90), _rand((Cout, Cin, 1, 1), 91, (2.0 / Cin) ** 0.5), _rand((Cout,), 92)
+    xg, wg, bg = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv(w).cuda(), b.cuda()
+    pg = _rand((N, H // 2, H // 2, Cout), 93).cuda()
+    g = torch.Generator().manual_seed(5)
+    c = torch.rand(N, 2, generator=g) * 160 + 48
+    hw = torch.rand(N, 2, generator=g) * 60 + 20
+    boxes = torch.cat([c - hw, c + hw], 1).cuda()
+    win = ops.roi_windows(boxes, None, N, H, H, 0.25, dilate=1)
+    base = torch.full((N, H, H, Cout), 7.0, device='cuda')
+    fused = ops.conv2d_nhwc(xg, wg, bg, rows=win, rows_scatter=True, res_up=pg, out=base.clone())
+    sep = ops.conv2d_nhwc(xg, wg, bg, rows=win, rows_scatter=True, out=base.clone())
+    ops.resize_bilinear_nhwc(pg, H, H, out=sep, accumulate=True, rows=win)
+    assert torch.equal(fused, sep)
+    assert float((fused == 7.0).float().mean()) > 0.2            # pixels outside the windows are untouched

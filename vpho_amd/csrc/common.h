@@ -38,6 +38,15 @@ struct ProfScope {
 // wave itself reads afterwards and may leave a barrier with the fill still in flight -- other waves then read the tile too early.
 #define VPHO_SYNC_LDS_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 
+// F.interpolate(mode='bilinear', align_corners=False): src = max((dst+0.5)*scale-0.5, 0), scale = in/out
+__device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = ((float)dst + 0.5f) * scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

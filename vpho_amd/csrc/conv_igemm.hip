@@ -501,7 +501,36 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
             if (d.res && live) rv[it] = *reinterpret_cast<const f32x4*>(d.res + ro);
         }
     };
-    const bool res_early = g.vec_epilogue && d.res != nullptr && !(g.dbg & 8);
+    // residual = a coarser map, bilinearly up-sampled to this output pixel (the FPN's top-down add): the expression, operand order
+    // included, of resize_bilinear_nhwc_kernel (misc.hip), so that conv + fused add == conv, then the accumulate pass, bit for bit
+    auto load_res_up = [&]() {
+        const float sy = (float)d.ru_H / (float)d.OH, sx = (float)d.ru_W / (float)d.OW;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / V_PER_ROW, c4 = idx - r * V_PER_ROW;
+            int row = m0 + r;
+            const int col = n0 + 4 * c4;
+            rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < M_live && col < d.Cout) {
+                if (d.row_map) row = d.row_map[row];
+                const int n = row / ohw, rem = row - n * ohw;
+                const int oy = rem / d.OW, ox = rem - oy * d.OW;
+                int y0, y1, x0, x1; float ly, lx;
+                lin_src(oy, sy, d.ru_H, y0, y1, ly);
+                lin_src(ox, sx, d.ru_W, x0, x1, lx);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float* b = d.res_up + (long long)n * d.ru_H * d.ru_W * d.ru_ld + col;
+                const f32x4 a00 = *reinterpret_cast<const f32x4*>(b + ((long long)y0 * d.ru_W + x0) * d.ru_ld);
+                const f32x4 a01 = *reinterpret_cast<const f32x4*>(b + ((long long)y0 * d.ru_W + x1) * d.ru_ld);
+                const f32x4 a10 = *reinterpret_cast<const f32x4*>(b + ((long long)y1 * d.ru_W + x0) * d.ru_ld);
+                const f32x4 a11 = *reinterpret_cast<const f32x4*>(b + ((long long)y1 * d.ru_W + x1) * d.ru_ld);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rv[it][u] = hy * (hx * a00[u] + lx * a01[u]) + ly * (hx * a10[u] + lx * a11[u]);
+            }
+        }
+    };
+    const bool res_early = g.vec_epilogue && (d.res != nullptr || d.res_up != nullptr) && !(g.dbg & 8);
     // the first TWO stages are requested back to back and only the first is waited for (counted vmcnt: fills complete in issue order):
     // a short-K tile (K = 64: two stages in all) pays one memory round trip at its start, not one and a half
     if (UNI) fill_uni(0, 0); else fill(0);
@@ -550,7 +579,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
         VPHO_SYNC_LDS_DMA();
     }
     // last stage: no next fill; the residual tile is requested here and lands under this stage's matrix work
-    if (res_early) { load_res(); __builtin_amdgcn_sched_barrier(0); }
+    if (res_early) { if (d.res_up) load_res_up(); else load_res(); __builtin_amdgcn_sched_barrier(0); }
     compute(nk - 1);
     VPHO_SYNC_LDS_DMA();
 
@@ -568,7 +597,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
                     Cs[r * C_LD + wn * (BN / WN) + j * 32 + li] = acc[i][j][e];
                 }
         __syncthreads();
-        if (!res_early) load_res();
+        if (!res_early) { if (d.res_up) load_res_up(); else load_res(); }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             long long yoff, ro;
@@ -890,12 +919,20 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
     const char* dbg_env = getenv("VPHO_CONV_DBG");
     g.dbg = dbg_env ? atoi(dbg_env) : 0;
+    if (d.res_up) {
+        // up-sampled residual (the FPN's top-down add): served by the direct-to-LDS kernels' 16-byte epilogue only
+        VPHO_REQUIRE(!d.res && !d.gate && splits == 1 && d.ru_H > 0 && d.ru_W > 0 && d.ru_ld >= d.Cout && d.ru_ld % 4 == 0 && al16(d.res_up),
+                     "vpho_conv2d_nhwc_f32: res_up needs no res / gate / splits, a (N, ru_H, ru_W, ru_ld >= Cout) map with ru_ld %% 4 == 0, 16-byte aligned");
+        VPHO_REQUIRE(g.vec_epilogue && d.in_scale == nullptr && !d.w_planes && (!d.row_map || d.rows_scatter),
+                     "vpho_conv2d_nhwc_f32: res_up needs 16-byte addressable output rows, no prologue affine, no split-bf16 planes, scattered pixel lists");
+        VPHO_REQUIRE(4.0 * d.N * d.ru_H * d.ru_W * (double)d.ru_ld < 3.9e9, "vpho_conv2d_nhwc_f32: res_up map too large");
+    }
     hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * splits;
     const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes
     const double flops = 2.0 * m_acc * d.Cout * g.K * splits;
     // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
-    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout);
+    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout + (d.res_up ? (double)d.N * d.ru_H * d.ru_W * d.Cout : 0.0));
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
@@ -922,7 +959,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // a pre-activation prologue rides on the direct-to-LDS kernel when the fragment's k is a plain channel index (1x1, unpadded,
     // Cin a multiple of 32 and within the LDS table); everything else with a prologue takes the register-staged kernel
     const bool pre_on_read = d.in_scale != nullptr && g.uni && d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin <= GLDS_PRE_MAX;
-    const bool glds = (d.in_scale == nullptr || pre_on_read) && !no_glds;
+    const bool glds = (d.in_scale == nullptr || pre_on_read) && (!no_glds || d.res_up != nullptr);
+    VPHO_REQUIRE(!d.res_up || variant != 128, "vpho_conv2d_nhwc_f32: res_up is not served by the forced register-staged tile");
     // opt-in split-bf16 products (never the default): shapes the split kernel takes, everything else stays on the fp32 kernels
     const bool split_ok = d.w_planes != nullptr && (d.plane_terms == 6 || d.plane_terms == 9) && d.in_scale == nullptr && splits == 1 && !d.gate &&
                           d.Cin % SBK == 0 && g.vec_epilogue && d.pad_y >= 0 && d.pad_x >= 0 && g.w_ld == g.K &&

@@ -59,14 +59,7 @@ __global__ void maxpool_nhwc_kernel(const float* __restrict__ x, int N, int H, i
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear resize
-// F.interpolate(mode='bilinear', align_corners=False): src = max((dst+0.5)*scale-0.5, 0), scale = in/out
-__device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
-    float s = ((float)dst + 0.5f) * scale - 0.5f;
-    s = s < 0.f ? 0.f : s;
-    i0 = (int)s;
-    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-    l1 = s - (float)i0;
-}
+// lin_src (F.interpolate's source index and weight): common.h, shared with the convolution epilogue's up-sampled residual
 
 // V consecutive channels per thread (V = 4: 16-B accesses when every leading dimension and offset is a multiple of 4)
 template <int V>

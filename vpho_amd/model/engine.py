@@ -118,6 +118,9 @@ class Engine:
         # FPN outputs only where RoIAlign reads them (VPHO_ROI_WINDOW=0: the full 64 x 64 maps; same results)
         self.roi_window = os.environ.get('VPHO_ROI_WINDOW', '1') != '0'
         self.feature_streams = int(os.environ.get('VPHO_FEATURE_STREAMS', '1'))
+        # the FPN's three top-down adds (F.interpolate + add, backbone_FPN_HFL.py:66-68) ride in the lateral 1x1 convolutions' epilogues
+        # (vpho_conv_desc.res_up; VPHO_FPN_FUSE=0: separate read-modify-write passes; bit-identical)
+        self.fpn_fuse = os.environ.get('VPHO_FPN_FUSE', '1') != '0'
         # 3x3 / stride-1 convolutions in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25 x fewer multiply-adds, smaller error
         # against fp64 than the direct kernel).  VPHO_WINOGRAD=0: the direct implicit GEMM everywhere
         self.winograd = os.environ.get('VPHO_WINOGRAD', '1') != '0'
@@ -209,6 +212,9 @@ class Engine:
         for lat, c in ((f'latlayer1_{br}', c4), (f'latlayer2_{br}', c3), (f'latlayer3_{br}', c2)):
             # the stride-4 level: lateral convolution and top-down add only inside the windows dilated by the 3x3 halo
             halo = windows[br][1] if (windows is not None and c is c2) else None
+            if self.fpn_fuse:       # top-down add inside the lateral convolution's epilogue: the finer map is written once
+                p = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None, res_up=p)
+                continue
             q = ops.conv2d_nhwc(c, *self.fpn[lat], rows=halo, rows_scatter=halo is not None)
             p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
         return ops.conv3x3(p, *self.fpn[f'smooth3_{br}'], winograd=self.winograd, rows=None if windows is None else windows[br][0])
@@ -411,7 +417,7 @@ class Engine:
         S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
         with torch.cuda.device(self.dev):
             if self.use_graphs:
-                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams, self.winograd))
+                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams, self.winograd, self.fpn_fuse))
                 keep = lambda t: t.clone()                 # graph-owned buffers are overwritten by the next replay
             else:
                 f = self.features(data)

@@ -60,7 +60,8 @@ class ConvDesc(C.Structure):
                 ('w_ld', C.c_int), ('splits', C.c_int), ('x_split', C.c_longlong), ('w_split', C.c_longlong), ('y_split', C.c_longlong),
                 ('gate', C.c_void_p), ('gate_slope', C.c_float),
                 ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int),
-                ('w_planes', C.c_void_p), ('plane_terms', C.c_int)]
+                ('w_planes', C.c_void_p), ('plane_terms', C.c_int),
+                ('res_up', C.c_void_p), ('ru_H', C.c_int), ('ru_W', C.c_int), ('ru_ld', C.c_int)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -109,8 +110,10 @@ def _planes_of(w):
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
                 out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None,
-                rows=None, rows_scatter=False):
+                rows=None, rows_scatter=False, res_up=None):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
+    ``res_up`` = a coarser (N,h,w,Cout) map added after bilinear up-sampling to the output grid (the FPN's top-down add fused into the
+    lateral convolution, backbone_FPN_HFL.py:66-68; bit-identical to ``resize_bilinear_nhwc(..., accumulate=True)`` after the convolution).
 
     ``out_view`` = (tensor, y_sn, y_sy, y_sx, element_offset) writes into a strided destination (concat buffers,
     transposed-convolution phases).  ``res`` is a contiguous (N,OH,OW,Cout) tensor.  ``gate`` = (tensor shaped like the
@@ -134,7 +137,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     for t in (x, w, bias, in_scale, in_shift, res):
         _ptr(t, torch.float32)
     if rows is not None:
-        assert out_view is None and res is None and gate is None and rows.shape == (N, OH, OW)
+        assert out_view is None and res is None and gate is None and rows.shape == (N, OH, OW) and (res_up is None or rows_scatter)
         if out is None:
             out = torch.empty((N, OH, OW, cout) if rows_scatter else (N * OH * OW, cout), device=x.device, dtype=torch.float32)
         _ptr(out, torch.float32)
@@ -165,13 +168,16 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     if res is not None:
         assert res.shape == (N, OH, OW, cout)
         d.r_sx, d.r_sy, d.r_sn = cout, cout * OW, cout * OW * OH
+    if res_up is not None:
+        assert res is None and res_up.shape[0] == N and res_up.shape[3] == cout and res_up.is_contiguous()
+        d.res_up, d.ru_H, d.ru_W, d.ru_ld = _ptr(res_up, torch.float32).value, res_up.shape[1], res_up.shape[2], res_up.shape[3]
     d.N, d.H, d.W, d.Cin, d.x_ld = N, H, W, cin, x_ld
     d.Cout, d.KH, d.KW, d.stride, d.pad_y, d.pad_x, d.OH, d.OW = cout, kh, kw, stride, py, px, OH, OW
     d.in_slope, d.out_slope = in_slope, out_slope
     if split is not None:                                   # (splits, w_ld, x_split, w_split, y_split): see vpho_conv_desc
         d.splits, d.w_ld, d.x_split, d.w_split, d.y_split = split
     terms = getattr(_conv_split, 'terms', 0)
-    if terms and split is None and in_scale is None and gate is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
+    if terms and split is None and in_scale is None and gate is None and res_up is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
         planes = _planes_of(w)                              # kept alive by the cache
         d.w_planes, d.plane_terms = planes.data_ptr(), terms
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
