@@ -93,6 +93,15 @@ typedef struct {
      * vpho_resize_bilinear_nhwc_f32(accumulate = 1) after the convolution: bit-identical.  Works with row_map / rows_scatter. */
     const float* res_up;
     int ru_H, ru_W, ru_ld;
+    /* Optional (NULL = off; ABI version 8): a SECOND input of a 1x1 convolution, concatenated behind x along the channel axis without a
+     * copy: y = act(w[:, :Cin] . x[n, oy*stride, ox*stride, :] + w[:, Cin:] . x2[n, oy*stride2, ox*stride2, :] + bias (+ res)), w packed as
+     * [Cout][Cin + Cin2].  It merges the projection shortcut of a ResNet stage's first bottleneck (downsample.0/1: a 1x1 convolution +
+     * BatchNorm of the block input, stride 1 or 2, backbone_FPN_HFL.py:311-350) into conv3: one launch, and the 4C-wide shortcut map is
+     * neither written nor re-read.  x2: (N, H2, W2, x2_ld) NHWC; needs KH = KW = 1, no padding, Cin % 32 == 0, Cin2 % 32 == 0, no pixel
+     * list / prologue / splits.  The sum over the Cin + Cin2 products is one accumulation chain: results differ from the two-launch
+     * form (sum, bias, add) by fp32 rounding. */
+    const float* x2;
+    int Cin2, x2_ld, stride2, H2, W2;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 VPHO_API int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);

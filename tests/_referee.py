@@ -5,11 +5,14 @@ import torch
 
 BS, S, STEPS, KH, KO, T0 = 64, 100, 50, 30, 10, 0.65
 # bounds of assert_within_reference_noise; measured values are in DESIGN.md section 2(B)
-# (max, median) of eps(tested side) / max(eps32 of the vector, stage median).  Heat-map stages: a sum of ~20 bicubic look-ups, the noise of
-# the two sides is alike on every vector (measured max 1.3 ... 2.8, median 0.8 ... 1.0).  Physics stages: the score is a difference of nearly
-# cancelling cross products, its noise is heavy-tailed over images (stage median 4e-7, maximum 8e-4) and the two sides' worst vectors
-# need not coincide (measured max 1.6 ... 37, median 0.8 ... 1.1)
-EPS_RATIO = dict(heat=(4.0, 1.5), physics=(64.0, 2.0))
+# How the tested side's own score error (eps_own, per vector) is held to the reference's (eps32).  Heat-map stages: a sum of ~20 bicubic
+# look-ups, the noise of the two sides is alike on EVERY vector: eps_own <= 4 x max(eps32 of the vector, stage median) (measured max 1.3 ...
+# 2.8, median 0.8 ... 1.0).  Physics stages: the score is a difference of nearly cancelling cross products, its noise is heavy-tailed over
+# the images (stage median 4e-7, maximum 2e-3) and the two sides' unlucky vectors do not coincide (one batch had a vector at 1 350 x the
+# other side's), so the two DISTRIBUTIONS are compared instead: median of eps_own within 1.5 x the reference's, 90th percentile and maximum
+# within 16 x (measured over seven batches of 64 images: median 0.87 ... 1.34; 90th percentile 0.9 ... 1.25 and once 8.8; maximum 0.35 ... 7.3)
+EPS_RATIO_HEAT = (4.0, 1.5)
+EPS_DIST_PHYSICS = (1.5, 16.0, 16.0)
 EPS32_MAX = dict(hand_level0=1e-4, hand_level1=1e-4, hand_level2=1e-4, hand_level3=2e-4, obj_transl=1e-4, obj_rot=1e-4, obj_heat=1e-4,
                  obj_physics=1e-2, hand_physics=1e-2)
 OPTIMAL_SLACK = 4
@@ -62,8 +65,15 @@ def assert_within_reference_noise(rep, tag=''):
             floor = r['eps32_bf'].median()
             ratio = r['eps_own_bf'] / torch.maximum(r['eps32_bf'], floor)
             print(f'   {st:13s} eps(tested) / max(eps32 of the vector, stage median {float(floor):.1e}): median {float(ratio.median()):.2f}, max {float(ratio.max()):.2f}')
-            rmax, rmed = EPS_RATIO['physics' if st.endswith('physics') else 'heat']
-            assert float(ratio.max()) <= rmax and float(ratio.median()) <= rmed, (st, float(ratio.median()), float(ratio.max()))
+            if st.endswith('physics'):
+                q = lambda t, p: float(torch.quantile(t.flatten().double(), p))
+                own, ref = r['eps_own_bf'], r['eps32_bf']
+                stats = (q(own, 0.5) / max(q(ref, 0.5), 1e-12), q(own, 0.9) / max(q(ref, 0.9), 1e-12), float(own.max()) / max(float(ref.max()), 1e-12))
+                print(f'   {st:13s} eps(tested) / eps32 as distributions: median {stats[0]:.2f}, 90th percentile {stats[1]:.2f}, maximum {stats[2]:.2f}')
+                assert all(a <= b for a, b in zip(stats, EPS_DIST_PHYSICS)), (st, stats)
+            else:
+                rmax, rmed = EPS_RATIO_HEAT
+                assert float(ratio.max()) <= rmax and float(ratio.median()) <= rmed, (st, float(ratio.median()), float(ratio.max()))
         # the noise of the reference's arithmetic is fp32 rounding, not a formula difference: heat-map sums after FK and projection 1e-6 ...
         # 1e-5 of the score scale; the physics scores (torque term: 32 cross products that nearly cancel) up to ~1e-3
         assert r['eps32_rel'] < EPS32_MAX[st], (st, r['eps32_rel'])

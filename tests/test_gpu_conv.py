@@ -247,3 +247,25 @@ def test_upsampled_residual_on_scattered_roi_windows():
     ops.resize_bilinear_nhwc(pg, H, H, out=sep, accumulate=True, rows=win)
     assert torch.equal(fused, sep)
     assert float((fused == 7.0).float().mean()) > 0.2            # pixels outside the windows are untouched
+
+
+@pytest.mark.parametrize('N,H,C1,C2,Cout,stride2', [(64, 64, 64, 64, 256, 1), (16, 32, 128, 256, 512, 2), (5, 9, 96, 64, 192, 2), (128, 8, 512, 1024, 2048, 2), (2, 6, 32, 32, 64, 1)])
+def test_second_input_of_a_1x1_convolution_is_the_merged_projection_shortcut(N, H, C1, C2, Cout, stride2):
+    """round 4 (vpho_conv_desc.x2): conv3 and the projection shortcut of a stage-opening bottleneck (backbone_FPN_HFL.py:311-350: 1x1
+    convolution + BatchNorm of the block input, stride 1 or 2) as ONE convolution over [conv2 output | block input].  Against torch
+    (two convolutions + add + LeakyReLU) and against the two-launch form of the same kernels (one accumulation chain instead of sum,
+    bias, add: fp32 rounding apart); all tile classes, odd sizes, strided second input."""
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv
+    H2 = H * stride2 - (1 if stride2 == 2 and H % 2 else 0)            # an odd strided input size too: the last pixel read is (H - 1) * 2
+    y, x = _rand((N, C1, H, H), 100), _rand((N, C2, H2, H2), 101)
+    w3, wd = _rand((Cout, C1, 1, 1), 102, (1.0 / C1) ** 0.5), _rand((Cout, C2, 1, 1), 103, (1.0 / C2) ** 0.5)
+    b3, bd = _rand((Cout,), 104), _rand((Cout,), 105)
+    ref = F.leaky_relu(F.conv2d(y, w3, b3) + F.conv2d(x, wd, bd, stride=stride2), 0.01)
+    yg, xg = y.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_cat = torch.cat([pack_conv(w3), pack_conv(wd)], 1).contiguous().cuda()
+    got = ops.conv2d_nhwc(yg, w_cat, (b3 + bd).cuda(), x2=xg, stride2=stride2, out_slope=0.01)
+    _close(got.permute(0, 3, 1, 2), ref)
+    r = ops.conv2d_nhwc(xg, pack_conv(wd).cuda(), bd.cuda(), stride=stride2)
+    two = ops.conv2d_nhwc(yg, pack_conv(w3).cuda(), b3.cuda(), res=r, out_slope=0.01)
+    assert float((got - two).abs().max()) <= 4e-6 * max(1.0, float(two.abs().max()))

@@ -424,10 +424,33 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) u_boff[j] = b_ok[j] ? (int)b_off[j] : -1;
     }
+    // second input (vpho_conv_desc.x2: the projection shortcut merged into a 1x1 convolution): the stages with k >= Cin read it -- a
+    // whole 32-k stage lies in one source, so the switch is wave-uniform: another buffer resource, another set of per-lane offsets
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x2 ? d.x2 : d.x), 0, 0xFFFFFFF0u, 0x00020000);
+    int u_voff2[A_LD];
+    if (d.x2) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int m = m0 + lrow + ROWS * j;
+            if (m < M_live) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int oy = rem / d.OW, ox = rem - oy * d.OW;
+                u_voff2[j] = (int)((((long long)(n * d.H2 + oy * d.stride2) * d.W2 + ox * d.stride2) * d.x2_ld) * 4 + 16 * kq);
+            } else u_voff2[j] = -1;
+        }
+    }
     auto fill_uni = [&](int buf, int kt) {
         float* As = smem + buf * TILE + wave * 8 * BK;
         float* Bs = smem + buf * TILE + BM * BK + wave * 8 * BK;
         const int tap_s = ((u_r * d.W + u_s) * d.x_ld + u_c) * 4;
+        if (d.x2 && kt * BK >= d.Cin) {
+            const int c2 = (kt * BK - d.Cin) * 4;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int vo = u_voff2[j];       // (a local, like u_boff below: an array element passed straight to the builtin makes this hipcc drop the host stub)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x2r, (lds_ptr)(As + ROWS * j * BK), 16, vo, c2, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             int off = u_voff[j];
@@ -437,6 +460,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xu, (lds_ptr)(As + ROWS * j * BK), 16, off, tap_s, 0, 0);
         }
+        }
         const int koff = kt * BK * 4;
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Bs + ROWS * j * BK), 16, bo, koff, 0, 0);
         }
         u_c += BK;
-        if (u_c >= d.Cin) { u_c = 0; if (++u_s == d.KW) { u_s = 0; ++u_r; } }
+        if (u_c >= d.Cin && !d.x2) { u_c = 0; if (++u_s == d.KW) { u_s = 0; ++u_r; } }
     };
 
     f32x16 acc[TM][TN];
@@ -898,7 +922,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     Geo g;
     g.d = d;
     g.M = (int)M;
-    g.K = d.KH * d.KW * d.Cin;
+    g.K = d.KH * d.KW * d.Cin + (d.x2 ? d.Cin2 : 0);
     const int splits = d.splits > 1 ? d.splits : 1;
     g.w_ld = d.w_ld > 0 ? d.w_ld : g.K;
     g.x_zs = splits > 1 ? d.x_split : 0; g.w_zs = splits > 1 ? d.w_split : 0; g.y_zs = splits > 1 ? d.y_split : 0;
@@ -919,6 +943,14 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
     const char* dbg_env = getenv("VPHO_CONV_DBG");
     g.dbg = dbg_env ? atoi(dbg_env) : 0;
+    if (d.x2) {
+        // second input concatenated along the channels (projection shortcut merged into conv3): direct-to-LDS kernels, wave-uniform taps
+        VPHO_REQUIRE(d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin % BK == 0 && d.Cin2 > 0 && d.Cin2 % BK == 0 && d.x2_ld % 4 == 0 &&
+                     d.x2_ld >= d.Cin2 && d.stride2 > 0 && al16(d.x2) && !d.row_map && !d.in_scale && splits == 1 && !d.w_planes,
+                     "vpho_conv2d_nhwc_f32: x2 needs a 1x1 unpadded convolution, Cin and Cin2 multiples of 32, no pixel list / prologue / splits / planes");
+        VPHO_REQUIRE((d.OH - 1) * d.stride2 < d.H2 && (d.OW - 1) * d.stride2 < d.W2 && 4.0 * d.N * d.H2 * d.W2 * (double)d.x2_ld < 3.9e9,
+                     "vpho_conv2d_nhwc_f32: x2 of %d x %d pixels read at stride %d does not cover the %d x %d output (or exceeds 3.9 GB)", d.H2, d.W2, d.stride2, d.OH, d.OW);
+    }
     if (d.res_up) {
         // up-sampled residual (the FPN's top-down add): served by the direct-to-LDS kernels' 16-byte epilogue only
         VPHO_REQUIRE(!d.res && !d.gate && splits == 1 && d.ru_H > 0 && d.ru_W > 0 && d.ru_ld >= d.Cout && d.ru_ld % 4 == 0 && al16(d.res_up),
@@ -932,7 +964,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes
     const double flops = 2.0 * m_acc * d.Cout * g.K * splits;
     // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
-    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout + (d.res_up ? (double)d.N * d.ru_H * d.ru_W * d.Cout : 0.0));
+    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (d.x2 ? (double)d.N * d.OH * d.OW * d.Cin2 : 0.0) + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout + (d.res_up ? (double)d.N * d.ru_H * d.ru_W * d.Cout : 0.0));
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
@@ -959,7 +991,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // a pre-activation prologue rides on the direct-to-LDS kernel when the fragment's k is a plain channel index (1x1, unpadded,
     // Cin a multiple of 32 and within the LDS table); everything else with a prologue takes the register-staged kernel
     const bool pre_on_read = d.in_scale != nullptr && g.uni && d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin <= GLDS_PRE_MAX;
-    const bool glds = (d.in_scale == nullptr || pre_on_read) && (!no_glds || d.res_up != nullptr);
+    const bool glds = (d.in_scale == nullptr || pre_on_read) && (!no_glds || d.res_up != nullptr || d.x2 != nullptr);
+    VPHO_REQUIRE(!d.x2 || (g.uni && variant != 128), "vpho_conv2d_nhwc_f32: x2 is served by the direct-to-LDS kernels with wave-uniform taps only");
     VPHO_REQUIRE(!d.res_up || variant != 128, "vpho_conv2d_nhwc_f32: res_up is not served by the forced register-staged tile");
     // opt-in split-bf16 products (never the default): shapes the split kernel takes, everything else stays on the fp32 kernels
     const bool split_ok = d.w_planes != nullptr && (d.plane_terms == 6 || d.plane_terms == 9) && d.in_scale == nullptr && splits == 1 && !d.gate &&

@@ -49,6 +49,9 @@ class Engine:
                            c3=fold(p + '.conv3', p + '.bn3'), stride=stride if i == 0 else 1, down=None)
                 if (p + '.downsample.0.weight') in sd:
                     blk['down'] = fold(p + '.downsample.0', p + '.downsample.1')
+                    # conv3 and the projection shortcut as ONE 1x1 convolution over the concatenated inputs [conv2 output | block input]
+                    # (vpho_conv_desc.x2): weights side by side along k, biases added
+                    blk['c3_down'] = (torch.cat([blk['c3'][0], blk['down'][0]], 1).contiguous(), (blk['c3'][1] + blk['down'][1]).contiguous())
                 out.append(blk)
             return out
 
@@ -121,6 +124,8 @@ class Engine:
         # the FPN's three top-down adds (F.interpolate + add, backbone_FPN_HFL.py:66-68) ride in the lateral 1x1 convolutions' epilogues
         # (vpho_conv_desc.res_up; VPHO_FPN_FUSE=0: separate read-modify-write passes; bit-identical)
         self.fpn_fuse = os.environ.get('VPHO_FPN_FUSE', '1') != '0'
+        # projection shortcuts of the six stage-opening bottlenecks merged into their conv3 (VPHO_DOWN_FUSE=0: two launches + residual add)
+        self.down_fuse = os.environ.get('VPHO_DOWN_FUSE', '1') != '0'
         # 3x3 / stride-1 convolutions in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25 x fewer multiply-adds, smaller error
         # against fp64 than the direct kernel).  VPHO_WINOGRAD=0: the direct implicit GEMM everywhere
         self.winograd = os.environ.get('VPHO_WINOGRAD', '1') != '0'
@@ -149,6 +154,10 @@ class Engine:
             y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd)
         else:
             y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01)
+        if b['down'] is not None and self.down_fuse and x.shape[-1] % 32 == 0 and y.shape[-1] % 32 == 0:
+            # the first block of a stage: its projection shortcut (1x1 convolution + BatchNorm of the block input, stride 1 or 2) rides in
+            # conv3 as a second input: one launch, and the 4C-wide shortcut map is neither written nor re-read
+            return ops.conv2d_nhwc(y, *b['c3_down'], x2=x, stride2=b['stride'], out_slope=0.01, out=out)
         r = x if b['down'] is None else ops.conv2d_nhwc(x, *b['down'], stride=b['stride'])
         return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01, out=out)
 
@@ -417,7 +426,7 @@ class Engine:
         S, T0, steps = cfg.sample_num, cfg.sample_T0, cfg.sampling_steps
         with torch.cuda.device(self.dev):
             if self.use_graphs:
-                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams, self.winograd, self.fpn_fuse))
+                f = self._features_graph({k: v for k, v in data.items() if torch.is_tensor(v)}, (cfg.roi_size, cfg.heatmap_size, self.conv_terms, self.roi_window, self.feature_streams, self.winograd, self.fpn_fuse, self.down_fuse))
                 keep = lambda t: t.clone()                 # graph-owned buffers are overwritten by the next replay
             else:
                 f = self.features(data)

@@ -61,7 +61,8 @@ class ConvDesc(C.Structure):
                 ('gate', C.c_void_p), ('gate_slope', C.c_float),
                 ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int),
                 ('w_planes', C.c_void_p), ('plane_terms', C.c_int),
-                ('res_up', C.c_void_p), ('ru_H', C.c_int), ('ru_W', C.c_int), ('ru_ld', C.c_int)]
+                ('res_up', C.c_void_p), ('ru_H', C.c_int), ('ru_W', C.c_int), ('ru_ld', C.c_int),
+                ('x2', C.c_void_p), ('Cin2', C.c_int), ('x2_ld', C.c_int), ('stride2', C.c_int), ('H2', C.c_int), ('W2', C.c_int)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -110,10 +111,12 @@ def _planes_of(w):
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
                 out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None,
-                rows=None, rows_scatter=False, res_up=None):
+                rows=None, rows_scatter=False, res_up=None, x2=None, stride2=1):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
     ``res_up`` = a coarser (N,h,w,Cout) map added after bilinear up-sampling to the output grid (the FPN's top-down add fused into the
     lateral convolution, backbone_FPN_HFL.py:66-68; bit-identical to ``resize_bilinear_nhwc(..., accumulate=True)`` after the convolution).
+    ``x2`` = a second (N,H2,W2,C2) input of a 1x1 convolution, read at stride ``stride2`` and concatenated behind x along the channels
+    (w: (Cout, Cin + C2)): the projection shortcut of a bottleneck merged into conv3 (vpho_conv_desc.x2).
 
     ``out_view`` = (tensor, y_sn, y_sy, y_sx, element_offset) writes into a strided destination (concat buffers,
     transposed-convolution phases).  ``res`` is a contiguous (N,OH,OW,Cout) tensor.  ``gate`` = (tensor shaped like the
@@ -124,7 +127,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     N, H, W, x_ld = x.shape
     cin = x_ld if cin is None else cin
     cout = w.shape[0]
-    assert split is not None or w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
+    assert split is not None or w.shape[1] == kh * kw * cin + (0 if x2 is None else x2.shape[-1]), (w.shape, kh, kw, cin)
     py = pad if pad_y is None else pad_y
     px = pad if pad_x is None else pad_x
     if out_hw is None:
@@ -168,6 +171,9 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     if res is not None:
         assert res.shape == (N, OH, OW, cout)
         d.r_sx, d.r_sy, d.r_sn = cout, cout * OW, cout * OW * OH
+    if x2 is not None:
+        assert kh == kw == 1 and rows is None and split is None and in_scale is None and x2.shape[0] == N and x2.is_contiguous()
+        d.x2, d.Cin2, d.x2_ld, d.stride2, d.H2, d.W2 = _ptr(x2, torch.float32).value, x2.shape[3], x2.shape[3], stride2, x2.shape[1], x2.shape[2]
     if res_up is not None:
         assert res is None and res_up.shape[0] == N and res_up.shape[3] == cout and res_up.is_contiguous()
         d.res_up, d.ru_H, d.ru_W, d.ru_ld = _ptr(res_up, torch.float32).value, res_up.shape[1], res_up.shape[2], res_up.shape[3]
@@ -177,7 +183,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     if split is not None:                                   # (splits, w_ld, x_split, w_split, y_split): see vpho_conv_desc
         d.splits, d.w_ld, d.x_split, d.w_split, d.y_split = split
     terms = getattr(_conv_split, 'terms', 0)
-    if terms and split is None and in_scale is None and gate is None and res_up is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
+    if terms and split is None and in_scale is None and gate is None and res_up is None and x2 is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
         planes = _planes_of(w)                              # kept alive by the cache
         d.w_planes, d.plane_terms = planes.data_ptr(), terms
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
