@@ -31,7 +31,7 @@ HBM_LIMITS = {'mano_fk': 'matrix cores / vector ALU, not HBM: pose blend [hands 
               'hand_fuse': 'latency: one workgroup per (image, finger) -- ranking by counting, 30 quaternions, a 4x4 Jacobi eigen-solve',
               'roi_align': 'HBM / L2 gather: window rows read once, pooled output written once',
               'resize_bilinear': 'HBM: read-modify-write of the finer map (top-down add of the FPN)'}
-HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk_kernel', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
+HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
                     'roi_align': 'roi_align_nhwc_kernel', 'resize_bilinear': 'resize_bilinear_nhwc_kernel'}
 
 

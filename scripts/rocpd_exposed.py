@@ -37,7 +37,7 @@ def short(n):
 # sweep over the event points: at each elementary interval know which kernels are live
 ev = []
 for i, (s, e, n) in enumerate(rows):
-    ev.append((max(s, t0), 1, i)); ev.append((min(e, t_end), 0, i))
+    ev.append((max(s, t0), 0, i)); ev.append((max(min(e, t_end), max(s, t0)), 1, i))     # at equal times a start sorts before its own end
 ev.sort()
 live, live_big = set(), 0
 prev = t0
@@ -57,7 +57,7 @@ for t, kind, i in ev:
             for k in names:
                 excl[k] += dt / len(names)
         prev = t
-    if kind:
+    if kind == 0:
         live.add(i); live_big += isbig[i]
     else:
         live.discard(i); live_big -= isbig[i]
