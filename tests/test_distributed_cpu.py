@@ -51,6 +51,37 @@ def test_gather_rows_world2_gloo():
     assert s['both']['MJE_agg'] == pytest.approx(15.0)
 
 
+def _worker_ragged(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vpho_amd import evaluate as E
+    n = 5 if rank == 0 else 3                             # a data loader's ragged last batch on one rank
+    rows = torch.zeros((n, E.ROW))
+    rows[:, 0] = torch.arange(n) + 100 * rank
+    q.put((rank, E.gather_rows(rows).clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_takes_ragged_counts_like_gather_for_metrics():
+    """ranks with different numbers of images (train_diff_hand_obj.py:333-335 gathers pickled lists of any length): counts first,
+    rows padded to the largest count, padding dropped -- every image exactly once, rank order"""
+    from vpho_amd import evaluate as E
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert got[r].shape == (8, E.ROW)
+        assert got[r][:, 0].tolist() == [0, 1, 2, 3, 4, 100, 101, 102]
+
+
 def test_gather_rows_without_process_group_is_identity():
     from vpho_amd import evaluate as E
     rows = torch.randn(3, E.ROW)

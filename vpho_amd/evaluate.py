@@ -149,25 +149,30 @@ class PipelinedPredictor:
 
 
 def gather_rows(rows):
-    """All ranks' rows, concatenated in rank order: (world * n, ROW).  No-op without a process group."""
+    """All ranks' rows, concatenated in rank order.  Ranks may hold different numbers of rows (a data loader's ragged last batches, like
+    accelerate's ``gather_for_metrics``, train_diff_hand_obj.py:333-335): the counts travel first (one all-gather of a single integer per
+    rank), the rows padded to the largest count, the padding dropped again.  No-op without a process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
-    out = torch.empty((world * rows.shape[0], rows.shape[1]), device=rows.device, dtype=rows.dtype)
     try:
-        if dist.get_backend() == 'gloo' and rows.is_cuda:       # CPU rehearsal backend: stage through host memory
-            host = torch.empty(out.shape, dtype=rows.dtype)
-            dist.all_gather_into_tensor(host, rows.cpu().contiguous())
-            out.copy_(host)
-        else:
-            dist.all_gather_into_tensor(out, rows.contiguous())
-            if rows.is_cuda:
-                torch.cuda.current_stream(rows.device).synchronize()      # an RCCL failure surfaces HERE, with the context below
+        host_stage = dist.get_backend() == 'gloo' and rows.is_cuda       # CPU rehearsal backend: stage through host memory
+        dev = torch.device('cpu') if host_stage else rows.device
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev))
+        counts = counts.tolist()
+        cap = max(counts)
+        mine = torch.zeros((cap, rows.shape[1]), device=dev, dtype=rows.dtype)
+        mine[:rows.shape[0]] = rows.to(dev)
+        out = torch.empty((world * cap, rows.shape[1]), device=dev, dtype=rows.dtype)
+        dist.all_gather_into_tensor(out, mine)
+        if rows.is_cuda and not host_stage:
+            torch.cuda.current_stream(rows.device).synchronize()          # an RCCL failure surfaces HERE, with the context below
+        out = torch.cat([out[r * cap:r * cap + counts[r]] for r in range(world)], 0) if any(c != cap for c in counts) else out
+        return out.to(rows.device)
     except Exception as e:
         raise RuntimeError(f'gather_rows: the all-gather of the metric rows failed on rank {dist.get_rank()} of {world} (backend '
-                           f'{dist.get_backend()}, {tuple(rows.shape)} rows on {rows.device}; every rank must contribute the same '
-                           f'number of rows): {type(e).__name__}: {e}') from e
-    return out
+                           f'{dist.get_backend()}, {tuple(rows.shape)} rows on {rows.device}): {type(e).__name__}: {e}') from e
 
 
 def shard_range(n_items, rank, world):
