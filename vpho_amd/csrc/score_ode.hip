@@ -455,10 +455,9 @@ struct HeadArgs {
 // last full round into quarter tiles that all CUs share: 1 536 ordinary tiles = 3 rounds exactly, then 256 tail tiles, one per CU.
 template <int TI>
 __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
-    constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = TI == 4 ? 2 : 8;
+    constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
     constexpr int STAGE = (256 + 128) * HB_K;
     float* Eb = smem + 2 * STAGE;
-    float* Ob = Eb + 256 * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;   // hidden base of the wave = 32*TI*hh
     // one wave instruction fills 64 x 16 B = RPW whole tile rows; chunk swizzle f(row) = (row >> SW_SHIFT) & (CPR-1) keeps
@@ -547,9 +546,15 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     const int row = r0 + lrow_out;
     const bool live = row < a.R;
     const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    // The 256 hidden units of a row are summed as EIGHT partial sums of 32 (hidden 32 p .. 32 p + 31 = one 32 x 32 accumulator tile: two
+    // 16-term lane sums added), combined in ascending p -- in an ordinary 128-row tile (a wave holds four of the eight) exactly as in a
+    // 32-row tail tile (a wave holds one).  Round 3 let an ordinary tile sum 2 x 128: which rows of a launch fall into tail tiles
+    // depends on bs x sample_num and on the CU count, so a hypothesis rounded differently when the batch size or the GPU changed
+    // (ADVICE r2).  Now a row's score does not depend on the tile that computed it: bit-identical across tile kinds.
+    float* Ob = smem;                                               // [8 parts][ROWS][4]: the stage buffers are free (barrier above)
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int j = 32 * TI * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -558,13 +563,12 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
             h = h > 0.f ? h : 0.f;
             o0 += h * t[1]; o1 += h * t[2]; o2 += h * t[3];
         }
-    }
-    o0 += __shfl_xor(o0, 32);
-    o1 += __shfl_xor(o1, 32);
-    o2 += __shfl_xor(o2, 32);
-    if (lh == 0) {
-        float* ob = Ob + (hh * ROWS + lrow_out) * 4;
-        ob[0] = o0; ob[1] = o1; ob[2] = o2;
+        o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+        if (lh == 0) {
+            float* ob = Ob + ((hh * TI + i) * ROWS + lrow_out) * 4;
+            ob[0] = o0; ob[1] = o1; ob[2] = o2;
+        }
+        __builtin_amdgcn_sched_barrier(0);                          // one accumulator tile at a time: the four chains interleaved cost 130 more registers
     }
     __syncthreads();
     if (tid < ROWS) {
@@ -598,10 +602,10 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     }
 }
 
-__global__ __launch_bounds__(512) void score_head_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     // [2] stages x ([256][HB_K] weights | [128][HB_K] activations), unpadded rows filled by global_load_lds with the 16-B chunk
-    // index XOR-swizzled (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2} and 1024 floats of partial outputs
+    // index XOR-swizzled (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2}; the [8][ROWS][4] partial outputs of the epilogue reuse the stages
     if (ctl_skip(a.ctl, a.ctl_mode)) return;
     // (measured no better: dispatching the tail tiles first, next to ordinary tiles, 233 vs 230 us; giving each XCD whole heads of
     // tail tiles, 231 us -- a tail tile is bound by its chain of 16 barrier-separated weight stages, not by where the weights are)
