@@ -408,7 +408,7 @@ struct ObjFuseArgs {
     int bs, k;
     double* fused;                                // (bs, 9)
 };
-__global__ void obj_fuse_kernel(const ObjFuseArgs a) {
+__global__ __launch_bounds__(64) void obj_fuse_kernel(const ObjFuseArgs a) {          // launched with 64 threads: without the bound the compiler budgets for 1024 (128 registers) and spills the fp64 eigen-solve
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.bs) return;
     const bool useb = a.pick_b && a.pick_b[b];
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void hand_phys_score_kernel(const float* __res
 }
 
 // fuse: per image, per finger: un-weighted quaternion mean of the top-k candidates' proximal+distal joints  (:598-617)
-__global__ void hand_phys_fuse_kernel(const float* __restrict__ cand, int n_cand, const int* __restrict__ idx, int bs, int k,
+__global__ __launch_bounds__(256) void hand_phys_fuse_kernel(const float* __restrict__ cand, int n_cand, const int* __restrict__ idx, int bs, int k,
                                       float* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= bs * 10) return;

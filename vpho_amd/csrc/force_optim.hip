@@ -60,10 +60,13 @@ struct FoArgs {
     const unsigned char* grasped;
     int B, iters, phase1;
     float lr, wd, beta1, beta2, eps, friction;
+    float cone[8][3];       // friction-cone anchors (physics.py:183-188,281-282), wave-uniform: kernel arguments stay in scalar registers
     float *fl_out, *fg_out, *scale_out, *weight_out, *losses_out;
 };
 
 __device__ inline float half_sum(float v) {                 // sum over the 32 lanes of this half-wave (= one sample)
+    // (the same butterfly through DPP operands + one ds_swizzle instead of five ds_bpermute: bit-identical, and no faster -- 81.5 vs
+    // 81.7 ms per 3000 iterations: the loop is bound by vector-ALU issue, the permutes' latency is hidden by the other waves)
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
@@ -75,16 +78,19 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
     const long long base = (long long)batch * B;
     const int n_items = B * 32;
 
-    // friction-cone anchors (physics.py:183-188,281-282)
-    float cone[8][3];
-    for (int k = 0; k < 8; ++k) {
-        const float ang = (float)k * (2.0f * 3.14159265358979323846f / 8.0f);
-        cone[k][0] = cosf(ang) / 8.f * a.friction; cone[k][1] = sinf(ang) / 8.f * a.friction; cone[k][2] = 1.f / 8.f;
-    }
+    const auto& cone = a.cone;
 
     // per-item constants and parameters
     float F[FO_IPT][9], arm[FO_IPT][3], g[FO_IPT][3], fcn[FO_IPT], mask[FO_IPT];
-    float s[FO_IPT], w[FO_IPT][8], ms[FO_IPT], vs[FO_IPT], mw[FO_IPT][8], vw[FO_IPT][8];
+    float s[FO_IPT], w[FO_IPT][8];
+    // AdamW moments of the 8 cone weights: touched once per iteration, 32 registers per thread that the 128-register budget of a
+    // 1024-thread workgroup does not have (they went to scratch: 270 spilled registers) -> LDS, [moment][e][item], each thread its own
+    // slots (consecutive threads = consecutive words: conflict-free, no barrier needed)
+    extern __shared__ float s_mom[];
+    auto MW = [&](int k, int e) -> float& { return s_mom[(e * FO_IPT + k) * FO_THREADS + tid]; };
+    auto VW = [&](int k, int e) -> float& { return s_mom[((8 + e) * FO_IPT + k) * FO_THREADS + tid]; };
+    auto MS = [&](int k) -> float& { return s_mom[(16 * FO_IPT + k) * FO_THREADS + tid]; };        // ... and of the scale
+    auto VS = [&](int k) -> float& { return s_mom[(17 * FO_IPT + k) * FO_THREADS + tid]; };
     bool valid[FO_IPT];
 #pragma unroll
     for (int k = 0; k < FO_IPT; ++k) {
@@ -101,17 +107,16 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
         const float fnorm = sqrtf(half_sum(fc * fc));
         fcn[k] = fc / (fnorm + 1e-8f);
         mask[k] = (valid[k] && fc > 0.1f) ? 1.f : 0.f;
-        s[k] = 0.05f; ms[k] = vs[k] = 0.f;
-        for (int e = 0; e < 8; ++e) { w[k][e] = 0.f; mw[k][e] = vw[k][e] = 0.f; }
+        s[k] = 0.05f; MS(k) = 0.f; VS(k) = 0.f;
+        for (int e = 0; e < 8; ++e) { w[k][e] = 0.f; MW(k, e) = 0.f; VW(k, e) = 0.f; }
     }
 
     double b1t = 1.0, b2t = 1.0;
-    float fl[FO_IPT][3], fg[FO_IPT][3];
     for (int it = 0; it < a.iters; ++it) {
         if (it == a.phase1) {            // optimizer2 starts with fresh moments and step count (two AdamW objects, :36-37)
             b1t = b2t = 1.0;
 #pragma unroll
-            for (int k = 0; k < FO_IPT; ++k) { ms[k] = vs[k] = 0.f; for (int e = 0; e < 8; ++e) mw[k][e] = vw[k][e] = 0.f; }
+            for (int k = 0; k < FO_IPT; ++k) { MS(k) = 0.f; VS(k) = 0.f; for (int e = 0; e < 8; ++e) { MW(k, e) = 0.f; VW(k, e) = 0.f; } }
         }
         const bool ph1 = it < a.phase1, last = it == a.iters - 1;
         // ---------------- forward ----------------
@@ -128,12 +133,13 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
             for (int e = 0; e < 8; ++e) p[k][e] /= sum;
             for (int c = 0; c < 3; ++c) { float t = 0.f; for (int e = 0; e < 8; ++e) t += p[k][e] * cone[e][c]; vdir[k][c] = t; }
             vn[k] = sqrtf(vdir[k][0] * vdir[k][0] + vdir[k][1] * vdir[k][1] + vdir[k][2] * vdir[k][2]);
-            for (int c = 0; c < 3; ++c) { d[k][c] = vdir[k][c] / (vn[k] + 1e-8f); fl[k][c] = d[k][c] * ase[k]; }
-            for (int j = 0; j < 3; ++j) fg[k][j] = fl[k][0] * F[k][j * 3 + 0] + fl[k][1] * F[k][j * 3 + 1] + fl[k][2] * F[k][j * 3 + 2];
-            for (int c = 0; c < 3; ++c) R[k][c] = half_sum(fg[k][c]);
-            M[k][0] = half_sum(arm[k][1] * fg[k][2] - arm[k][2] * fg[k][1]);
-            M[k][1] = half_sum(arm[k][2] * fg[k][0] - arm[k][0] * fg[k][2]);
-            M[k][2] = half_sum(arm[k][0] * fg[k][1] - arm[k][1] * fg[k][0]);
+            float fl[3], fg[3];
+            for (int c = 0; c < 3; ++c) { d[k][c] = vdir[k][c] / (vn[k] + 1e-8f); fl[c] = d[k][c] * ase[k]; }
+            for (int j = 0; j < 3; ++j) fg[j] = fl[0] * F[k][j * 3 + 0] + fl[1] * F[k][j * 3 + 1] + fl[2] * F[k][j * 3 + 2];
+            for (int c = 0; c < 3; ++c) R[k][c] = half_sum(fg[c]);
+            M[k][0] = half_sum(arm[k][1] * fg[2] - arm[k][2] * fg[1]);
+            M[k][1] = half_sum(arm[k][2] * fg[0] - arm[k][0] * fg[2]);
+            M[k][2] = half_sum(arm[k][0] * fg[1] - arm[k][1] * fg[0]);
             const float rx = R[k][0] + g[k][0], ry = R[k][1] + g[k][1], rz = R[k][2] + g[k][2];
             rn[k] = sqrtf(rx * rx + ry * ry + rz * rz);
             snorm[k] = sqrtf(half_sum(se[k] * se[k]));
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
                 const int item = tid + FO_THREADS * k;
                 const long long sb = base + (item >> 5), ia = sb * 32 + (item & 31);
                 const float keep = a.grasped[sb] ? 1.f : 0.f;                                   // :199-202
-                for (int c = 0; c < 3; ++c) { a.fl_out[ia * 3 + c] = fl[k][c] * keep; a.fg_out[ia * 3 + c] = fg[k][c] * keep; }
+                float fl[3], fg[3];                                                            // the forward's values again (same operations)
+                for (int c = 0; c < 3; ++c) fl[c] = d[k][c] * ase[k];
+                for (int j = 0; j < 3; ++j) fg[j] = fl[0] * F[k][j * 3 + 0] + fl[1] * F[k][j * 3 + 1] + fl[2] * F[k][j * 3 + 2];
+                for (int c = 0; c < 3; ++c) { a.fl_out[ia * 3 + c] = fl[c] * keep; a.fg_out[ia * 3 + c] = fg[c] * keep; }
             }
         }
         // ---------------- AdamW (torch.optim.AdamW defaults: weight_decay 0.01) ----------------
@@ -232,15 +241,17 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
         for (int k = 0; k < FO_IPT; ++k) {
             if (!ph1) {
                 s[k] *= decay;
-                ms[k] = a.beta1 * ms[k] + (1.f - a.beta1) * gs[k];
-                vs[k] = a.beta2 * vs[k] + (1.f - a.beta2) * gs[k] * gs[k];
-                s[k] -= step * ms[k] / (sqrtf(vs[k]) / bc2s + a.eps);
+                const float m = a.beta1 * MS(k) + (1.f - a.beta1) * gs[k];
+                const float v = a.beta2 * VS(k) + (1.f - a.beta2) * gs[k] * gs[k];
+                MS(k) = m; VS(k) = v;
+                s[k] -= step * m / (sqrtf(v) / bc2s + a.eps);
             }
             for (int e = 0; e < 8; ++e) {
                 w[k][e] *= decay;
-                mw[k][e] = a.beta1 * mw[k][e] + (1.f - a.beta1) * gw[k][e];
-                vw[k][e] = a.beta2 * vw[k][e] + (1.f - a.beta2) * gw[k][e] * gw[k][e];
-                w[k][e] -= step * mw[k][e] / (sqrtf(vw[k][e]) / bc2s + a.eps);
+                const float m = a.beta1 * MW(k, e) + (1.f - a.beta1) * gw[k][e];
+                const float v = a.beta2 * VW(k, e) + (1.f - a.beta2) * gw[k][e] * gw[k][e];
+                MW(k, e) = m; VW(k, e) = v;
+                w[k][e] -= step * m / (sqrtf(v) / bc2s + a.eps);
             }
         }
     }
@@ -273,11 +284,21 @@ extern "C" int vpho_force_optimize_f32(const float* pts, const float* frames, co
     FoArgs a;
     a.pts = pts; a.frames = frames; a.gravity = gravity; a.com = com; a.fc = force_contact; a.grasped = is_grasped;
     a.B = B; a.iters = iters; a.phase1 = phase1_iters; a.lr = lr; a.wd = 0.01f; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f; a.friction = 0.8f;
+    for (int k = 0; k < 8; ++k) {
+        const float ang = (float)k * (2.0f * 3.14159265358979323846f / 8.0f);
+        a.cone[k][0] = cosf(ang) / 8.f * a.friction; a.cone[k][1] = sinf(ang) / 8.f * a.friction; a.cone[k][2] = 1.f / 8.f;
+    }
     a.fl_out = force_local; a.fg_out = force_global; a.scale_out = scale; a.weight_out = weight; a.losses_out = losses;
     // vector-ALU work of one iteration per (pair, anchor) item, counted on the kernel above (add / mul / fma = 1 / 1 / 2, division, sqrt,
     // exp, log = 1 each): forward 174 (soft-max over 8 cone anchors 39, cone mix + normalise 63, frame 15, resultant / moment / norms
     // incl. the 7 half-wave reductions 57), backward 190, AdamW on 1 + 8 parameters 116 = 480 flop; x 32 anchors x iters per pair
     vpho::ProfScope prof(vpho::PROF_FORCE_OPTIM, (hipStream_t)stream, 480.0 * 32.0 * (double)iters * (double)n_batches * B, 0.0);
-    hipLaunchKernelGGL(force_optim_kernel, dim3(n_batches), dim3(FO_THREADS), 0, (hipStream_t)stream, a);
+    constexpr int mom_lds = 2 * 9 * FO_IPT * FO_THREADS * (int)sizeof(float);      // 144 KB of the CU's 160 KB
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(force_optim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mom_lds));
+        lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(force_optim_kernel, dim3(n_batches), dim3(FO_THREADS), mom_lds, (hipStream_t)stream, a);
     return vpho::check_launch("force_optim_kernel");
 }
