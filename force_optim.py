@@ -77,13 +77,14 @@ def main():
         losses = out['losses'].mean(0).tolist()
         # ALU-bound, not HBM / MFMA: 480 fp32 operations per (pair, anchor) item and iteration (counted in csrc/force_optim.hip) against
         # the fp32 vector peak; the kernel is one 1024-thread workgroup per batch of 64 pairs -- a chain of dependent scalar arithmetic,
-        # half-wave reductions and one workgroup barrier per iteration: latency-bound far below the ALU peak
+        # half-wave reductions and one workgroup barrier per iteration.  The counted 480 operations are ~2 000 issued instructions (57 IEEE
+        # divisions and 20 square roots expand to ~10 each), and 157 workgroups leave 99 of the 256 CUs idle at the default 10 048 pairs
         tf = kprof['flops'] / kprof['total_ms'] / 1e9 if kprof['total_ms'] else None
         roof = {'bound': 'valu', 'kernel': 'force_optim_kernel (3000 AdamW iterations per batch in one persistent workgroup)', 'achieved': tf, 'peak': 157.3,
                 'unit': 'TFLOP/s', 'frac': tf / 157.3 if tf else None, 'traffic': None, 'flop_per_pair_per_iteration': 480 * 32,
                 'kernel_ms': kprof['total_ms'], 'workgroups': (hi - lo), 'timing': 'HIP events around the launch on the launch stream',
-                'limited_by': 'latency: 157 workgroups of 16 waves for 256 CUs at 10 048 pairs; dependent exp / div / sqrt chains, 7 half-wave '
-                              'reductions and a workgroup barrier per iteration'}
+                'limited_by': 'vector-ALU issue: ~2 000 instructions per thread and iteration for the 480 counted operations (57 IEEE divisions, 20 square '
+                              'roots, 16 exp), 4 waves per SIMD; 157 workgroups for 256 CUs at 10 048 pairs'}
         print(json.dumps({'roofline': roof, 'metric': 'pseudo-force optimisation pairs/s (3000 AdamW iterations per pair)', 'value': float(tot.item() / dt.item()),
                           'unit': 'pairs/s', 'n_gpus': world, 'pairs': int(tot.item()), 'batch_size': args.batch_size, 'iters': args.iters,
                           'seconds': float(dt.item()), 'mean_losses_force_gravity_moment_dist': losses, 'data': 'synthetic'}))
