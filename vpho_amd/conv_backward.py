@@ -39,6 +39,95 @@ def _flip_transpose(w_packed, cout, cin, kh, kw):
     return w_packed.view(cout, kh * kw, cin).permute(2, 1, 0).index_select(1, rev).reshape(cin, kh * kw * cout)
 
 
+def _pad_rows4(w_packed):
+    """the GEMM kernel wants a reduction length (= Cout of the forward convolution) that is a multiple of 4: zero rows"""
+    extra = (4 - w_packed.shape[0] % 4) % 4
+    return w_packed if extra == 0 else torch.cat([w_packed, w_packed.new_zeros(extra, w_packed.shape[1])], 0)
+
+
+def _phase_taps(parity, k, pad):
+    # input row iy = 2a + parity receives tap r from output row a + (parity + pad - r) / 2
+    rs = [r for r in range(k) if (parity + pad - r) % 2 == 0]
+    return sorted(((parity + pad - r) // 2, r) for r in rs)          # (offset of the output row, tap), ascending offset
+
+
+def _phase_weights(w_packed, cin, kh, kw, ty, tx):
+    """weights of one output-parity phase of a stride-2 input gradient: (cin, khp*kwp*cout) from the (padded) packed weights"""
+    cout = w_packed.shape[0]
+    w4 = w_packed.view(cout, kh, kw, cin)
+    oy0, ox0 = ty[0][0], tx[0][0]
+    khp, kwp = ty[-1][0] - oy0 + 1, tx[-1][0] - ox0 + 1
+    sub = torch.zeros((cin, khp, kwp, cout), device=w_packed.device, dtype=w_packed.dtype)
+    for offy, r in ty:
+        for offx, s in tx:
+            sub[:, offy - oy0, offx - ox0, :] = w4[:, r, s, :].t()
+    return sub.reshape(cin, khp * kwp * cout)
+
+
+class DgradWeightCache:
+    """The input-gradient convolutions read the weights in layouts of their own (transposed, taps reversed, cut into stride-2 phases,
+    zero rows up to a multiple of 4).  Built per call they cost a training step ~190 small launches (a transposing copy per 1x1
+    convolution, zeros + tap copies per phase).  They only change when the weights do, i.e. once per optimiser step: this cache keeps
+    every derived tensor in ONE flat buffer together with an index map into the concatenated packed weights (the layout recipe run once
+    on an index tensor instead of on values; index 0 = a constant zero), and ``refresh()`` rebuilds all of them with one concatenation
+    and one gather.  Owned by a DiffusionTrainStep and active only inside its backward (``with cache:``); everything else builds per call."""
+
+    def __init__(self):
+        self.entries, self.weights, self.offset = {}, [], {}
+        self.total, self.dirty, self.flat, self.map = 0, False, None, None
+
+    def __enter__(self):
+        global _ACTIVE
+        self._outer, _ACTIVE = _ACTIVE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE
+        _ACTIVE = self._outer
+
+    def get(self, w_packed, key, builder):
+        k = (w_packed.data_ptr(), tuple(w_packed.shape), key)
+        e = self.entries.get(k)
+        if e is None:
+            assert w_packed.is_contiguous()
+            wk = (w_packed.data_ptr(), tuple(w_packed.shape))
+            if wk not in self.offset:                      # the list keeps the tensor alive: its address cannot be handed out again
+                self.offset[wk] = self.total
+                self.weights.append(w_packed)
+                self.total += w_packed.numel()
+            off = self.offset[wk]
+            idx = torch.arange(off + 1, off + 1 + w_packed.numel(), device=w_packed.device, dtype=torch.int64).view(w_packed.shape)
+            m = builder(idx)
+            e = self.entries[k] = dict(tensor=builder(w_packed), map=m.reshape(-1).to(torch.int32), shape=tuple(m.shape))
+            self.dirty = True
+        return e['tensor']
+
+    def refresh(self):
+        """the weights have changed (optimiser step / load_params): rebuild every derived layout"""
+        if not self.entries:
+            return
+        dev = self.weights[0].device
+        if self.dirty:
+            self.map = torch.cat([e['map'] for e in self.entries.values()])
+            self.flat = torch.empty(self.map.numel(), device=dev, dtype=self.weights[0].dtype)
+            off = 0
+            for e in self.entries.values():
+                n = e['map'].numel()
+                e['tensor'] = self.flat[off:off + n].view(e['shape'])
+                off += n
+            self._zero = torch.zeros(1, device=dev, dtype=self.weights[0].dtype)
+            self.dirty = False
+        src = torch.cat([self._zero] + [w.reshape(-1) for w in self.weights])
+        torch.index_select(src, 0, self.map, out=self.flat)
+
+
+_ACTIVE = None
+
+
+def _derived(w_packed, key, builder):
+    return builder(w_packed) if _ACTIVE is None else _ACTIVE.get(w_packed, key, builder)
+
+
 def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None, rows=None):
     """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
     asymmetric top/left paddings of the transposed-convolution phases, stride 1 only).  ``gate`` = (y, slope): the result is
@@ -56,37 +145,26 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     if cout % 4:                                          # the GEMM kernel wants a reduction length that is a multiple of 4
         extra = 4 - cout % 4
         dy = torch.nn.functional.pad(dy, (0, extra)).contiguous()
-        w_packed = torch.cat([w_packed, w_packed.new_zeros(extra, w_packed.shape[1])], 0)
         cout += extra
     py = pad if pad_y is None else pad_y
     px = pad if pad_x is None else pad_x
     if stride == 1:
-        return ops.conv2d_nhwc(dy, _flip_transpose(w_packed, cout, cin, kh, kw), None, kh=kh, kw=kw, stride=1,
-                               pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate, res=res)
+        wt = _derived(w_packed, ('s1', kh, kw), lambda w, c=cout: _flip_transpose(_pad_rows4(w), c, cin, kh, kw))
+        return ops.conv2d_nhwc(dy, wt, None, kh=kh, kw=kw, stride=1, pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate, res=res)
     assert py == px == pad and res is None
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
-    w4 = w_packed.view(cout, kh, kw, cin)
     dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)
-
-    def taps(parity, k):
-        # input row iy = 2a + parity receives tap r from output row a + (parity + pad - r) / 2
-        rs = [r for r in range(k) if (parity + pad - r) % 2 == 0]
-        return sorted(((parity + pad - r) // 2, r) for r in rs)          # (offset of the output row, tap), ascending offset
-
     for py in (0, 1):
-        ty = taps(py, kh)
+        ty = _phase_taps(py, kh, pad)
         for px in (0, 1):
-            tx = taps(px, kw)
+            tx = _phase_taps(px, kw, pad)
             if not ty or not tx:
                 continue
             oy0, ox0 = ty[0][0], tx[0][0]
             khp, kwp = ty[-1][0] - oy0 + 1, tx[-1][0] - ox0 + 1
-            sub = torch.zeros((cin, khp, kwp, cout), device=dy.device, dtype=dy.dtype)
-            for offy, r in ty:
-                for offx, s in tx:
-                    sub[:, offy - oy0, offx - ox0, :] = w4[:, r, s, :].t()
+            sub = _derived(w_packed, ('s2', kh, kw, pad, py, px), lambda w, ty=ty, tx=tx: _phase_weights(_pad_rows4(w), cin, kh, kw, ty, tx))
             # phase output (a, b) reads dY rows a + oy0 .. : a stride-1 convolution with padding -oy0 / -ox0
-            ops.conv2d_nhwc(dy, sub.reshape(cin, khp * kwp * cout).contiguous(), None, kh=khp, kw=kwp, stride=1, pad_y=-oy0, pad_x=-ox0,
+            ops.conv2d_nhwc(dy, sub, None, kh=khp, kw=kwp, stride=1, pad_y=-oy0, pad_x=-ox0,
                             out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin), gate=gate)
     return dx
 

@@ -36,8 +36,12 @@ def bucket_of(name):
 
 
 class GradBuckets:
-    def __init__(self, shapes, device, dtype=torch.float32):
-        """shapes: {reference parameter name: shape}.  The flat buffer holds the tensors grouped by bucket (names sorted inside)."""
+    def __init__(self, shapes, device, dtype=torch.float32, conv_meta=None):
+        """shapes: {reference parameter name: shape of its slot}.  The flat buffer holds the tensors grouped by bucket (names sorted
+        inside).  conv_meta {name: (cout, cin, kh, kw)}: these slots hold the gradient in the kernels' PACKED layout
+        (cout, kh*kw*cin_pad) -- the layout the weight-gradient kernels write and AdamW steps the packed weights in, so that neither
+        the hand-over nor the optimiser needs a permuting copy per tensor; an element-wise all-reduce does not care."""
+        self.conv_meta = dict(conv_meta or {})
         order = {b: i for i, b in enumerate(BUCKETS)}
         self.names = sorted(shapes, key=lambda k: (order[bucket_of(k)], k))
         sizes = [int(torch.Size(shapes[k]).numel()) for k in self.names]
@@ -58,12 +62,28 @@ class GradBuckets:
         self._work, self._flushed = [], set()
 
     def put(self, grads):
-        """copy a group of finished gradients into their slots of the flat buffer: one multi-tensor copy, not one launch per tensor"""
+        """copy a group of finished gradients into their slots of the flat buffer.  torch._foreach_copy_ is ONE multi-tensor launch
+        only while every tensor of the list is contiguous (a single strided source sends the whole list down the per-tensor path:
+        569 copy launches per step, measured) -- convolution gradients therefore travel in the packed layout their kernels produced
+        (`packed_grad`, attached by train_blocks._unpack_grad to the reference-layout view it returns)."""
         if not grads:
             return
-        dst = [self.view[k] for k in grads]
-        src = [g.reshape(self.view[k].shape) for k, g in grads.items()]
-        torch._foreach_copy_(dst, src)
+        dst, src = [], []
+        for k, g in grads.items():
+            slot = self.view[k]
+            pk = getattr(g, 'packed_grad', None)
+            if pk is not None and pk.shape == slot.shape:
+                g = pk
+            elif g.shape != slot.shape and k in self.conv_meta:       # a reference-layout gradient from elsewhere: one strided copy
+                cout, cin, kh, kw = self.conv_meta[k]
+                slot.view(cout, kh, kw, -1)[..., :cin].copy_(g.reshape(cout, cin, kh, kw).permute(0, 2, 3, 1))
+                continue
+            else:
+                g = g.reshape(slot.shape)
+            dst.append(slot)
+            src.append(g if g.is_contiguous() else g.contiguous())
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def flush(self, bucket):
         """the gradients of `bucket` are final on this rank: start its all-reduce (sum) without waiting for it"""

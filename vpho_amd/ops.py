@@ -1097,6 +1097,9 @@ class AdamWList:
     def step(self, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
         _call('vpho_adamw_multi_f32', _ptr(self.table, torch.int64), I(self.n), LL(self.blocks), F(lr), F(beta1), F(beta2), F(eps), F(weight_decay),
               I(step), F(grad_scale))
+        # the kernel wrote through raw pointers: tell torch, so that everything cached per weight VERSION (the Winograd transforms of
+        # winograd_weights_device, the bf16 planes) is rebuilt -- no launch, a counter per tensor
+        torch.autograd.graph.increment_version([q[0] for q in self.keep])
 
 
 # ----------------------------------------------------------------------------------------------- physics branch (training)

@@ -66,9 +66,12 @@ def _bn_params(sd, key, dev):
 
 
 def _unpack_grad(gp, cout, cin, kh, kw):
-    """packed (Cout, kh*kw*cin_pad) gradient -> the reference's (Cout, Cin, kh, kw), as a VIEW: the one copy it needs is the one
-    into the flat gradient buffer (grad_buckets.GradBuckets.put)"""
-    return gp.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2)
+    """packed (Cout, kh*kw*cin_pad) gradient -> the reference's (Cout, Cin, kh, kw), as a VIEW (what callers and the module path read);
+    the packed tensor rides along as ``packed_grad``: the flat gradient buffer and AdamW keep convolution weights in the packed layout
+    (grad_buckets.GradBuckets.put)"""
+    view = gp.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2)
+    view.packed_grad = gp
+    return view
 
 
 class FPNTrain:
@@ -154,6 +157,8 @@ class FPNTrain:
             for gk, gv in g.items():
                 if gk in ('conv1', 'conv2', 'conv3', 'down'):
                     key = f'{k}.{"downsample.0" if gk == "down" else gk}.weight'
+                    if key in grads:                                      # layer4's second call: summed in the packed layout
+                        gv = grads.pop(key).packed_grad + gv
                     val = _unpack_grad(gv, *self.shapes[key])
                 else:
                     bn, which = gk.split('.')

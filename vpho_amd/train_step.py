@@ -49,10 +49,16 @@ class DiffusionTrainStep:
         self.w.update(loss_weights or {})
         self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay)
         self.steps = 0
-        # optimiser state: master copies in the reference's state_dict layout (what AdamW updates), re-packed into the kernels'
-        # layouts after each step.  Vectors and the denoisers' tensors already are in that layout: the live tensor is the master.
-        self.master, self._repack = {}, {}
+        # optimiser state: AdamW (element-wise) steps every tensor in the layout the kernels read it in -- the live tensor IS the master.
+        # Convolution weights stay packed (cout, kh*kw*cin_pad; padded input channels are zero and stay zero: zero gradient, decoupled
+        # decay of zero), their gradients arrive packed from the weight-gradient kernels, and the reference's (cout, cin, kh, kw) is
+        # produced only where it is asked for (state_dict / load_params / the gradients handed to callers).  Round 3 kept masters in
+        # the reference layout and re-packed 155 tensors after every step (one strided copy launch each).  Only the two ConvTranspose
+        # weights keep a reference-layout master (four phase kernels are cut from it).
+        self.master, self._repack, self._conv_meta = {}, {}, {}
         self._register()
+        from .conv_backward import DgradWeightCache
+        self.dgrad_weights = DgradWeightCache()          # the input-gradient layouts of every convolution weight, rebuilt once per step
 
     # ------------------------------------------------------------------------------------------------------------------
     def _register(self):
@@ -61,10 +67,9 @@ class DiffusionTrainStep:
             self._repack[name] = repack
 
         def conv(name, live, shape, cin_pad=None):
-            cout, cin, kh, kw = shape
-            master = live.view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2).contiguous()
-            # re-pack = ONE strided copy into the packed layout (the padded channels of the stem / encoder inputs stay zero)
-            add(name, master, lambda w, view=live.view(cout, kh, kw, -1)[..., :cin]: view.copy_(w.permute(0, 2, 3, 1)))
+            assert live.is_contiguous() and live.shape[0] == shape[0] and live.shape[1] % (shape[2] * shape[3]) == 0, (name, live.shape, shape)
+            self._conv_meta[name] = tuple(shape)
+            add(name, live, None)
 
         def vec(name, live):
             add(name, live, None)
@@ -137,7 +142,7 @@ class DiffusionTrainStep:
         # ONE flat gradient buffer, laid out in the order in which the backward finishes the modules and cut into buckets whose
         # all-reduce overlaps the rest of the backward (grad_buckets.py)
         from .grad_buckets import GradBuckets
-        self.buckets = GradBuckets({k: tuple(v.shape) for k, v in self.master.items()}, self.dev)
+        self.buckets = GradBuckets({k: tuple(v.shape) for k, v in self.master.items()}, self.dev, conv_meta=self._conv_meta)
         self.names = self.buckets.names
         self.flat_grad, self.grad_view = self.buckets.flat, self.buckets.view
         self.m = {k: torch.zeros_like(v) for k, v in self.master.items()}
@@ -156,7 +161,7 @@ class DiffusionTrainStep:
         bb_h, bb_o, bb_hr, bb_or = (f32(data[k]) for k in ('bbox_hand', 'bbox_obj', 'bbox_hand_rect', 'bbox_obj_rect'))
         left = (~data['is_right'].bool()).to(torch.uint8).contiguous()
         eh, eo = self.enc['h'], self.enc['o']
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), self.dgrad_weights:
             # ---- forward (VPHO.py:115-150)
             # The FPN outputs are read only through the RoIAligns below (VPHO.py:126-129), so the two smoothing convolutions -- forward,
             # input gradient and weight gradient, the largest launches of the step -- work on the RoI windows only (window = every pixel
@@ -265,11 +270,21 @@ class DiffusionTrainStep:
         """refresh every trained tensor (masters + the kernels' packed copies) and the BatchNorm running statistics from a state_dict
         in the reference's layout -- used by vpho_net.forward(mode='train') when an external optimiser has updated the module"""
         for k in self.names:
-            self.master[k].copy_(state_dict[k].to(self.dev).reshape(self.master[k].shape))
+            src = state_dict[k].to(self.dev)
+            if k in self._conv_meta:
+                self._ref_view(k).copy_(src.reshape(self._conv_meta[k]))
+                continue
+            self.master[k].copy_(src.reshape(self.master[k].shape))
             if self._repack[k] is not None:
                 self._repack[k](self.master[k])
         for k, v in self._running_stats().items():
             v.copy_(state_dict[k].to(self.dev))
+        self.dgrad_weights.refresh()
+
+    def _ref_view(self, name):
+        """the packed convolution weight `name` seen in the reference's (cout, cin, kh, kw) layout (a strided view of the live tensor)"""
+        cout, cin, kh, kw = self._conv_meta[name]
+        return self.master[name].view(cout, kh, kw, -1)[..., :cin].permute(0, 3, 1, 2)
 
     def _running_stats(self):
         """{reference name: live running_mean / running_var tensor}"""
@@ -335,11 +350,12 @@ class DiffusionTrainStep:
             for k in live:
                 if self._repack[k] is not None:
                     self._repack[k](self.master[k])
+            self.dgrad_weights.refresh()
         return losses
 
     def state_dict(self):
         """trained tensors + BatchNorm running statistics under the reference's names"""
-        out = {k: v.clone() for k, v in self.master.items()}
+        out = {k: (self._ref_view(k).clone(memory_format=torch.contiguous_format) if k in self._conv_meta else v.clone()) for k, v in self.master.items()}
         for tr in self.score.values():
             out[f'{tr.prefix}.t_encoder.0.W'] = tr.fourier_W.clone()
 
