@@ -169,9 +169,78 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     return dx
 
 
+class WgradStream:
+    """Weight gradients on a stream of their own.  A layer's weight gradient needs only dY and the saved input and nothing of the
+    backward waits for it before the optimiser, while the chain dY -> BatchNorm backward -> input gradient -> next layer is strictly
+    sequential: many of its launches (partial-sum reductions, finishing kernels, the short tails of small layers) leave most of the
+    chip idle.  Inside ``with WgradStream(device):`` conv2d_wgrad queues its kernels on a second HIP stream behind everything the main
+    stream has queued so far (so dY is complete), and ``join()`` makes the main stream wait for them -- called before gradients are
+    handed on.  Every kernel is the same and deterministic; only the overlap changes.  Tensors crossing streams are registered with
+    the caching allocator (record_stream) so that their memory is not reused while the other stream still works on it."""
+    _streams = {}
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        key = (self.dev.type, self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        if key not in WgradStream._streams:
+            WgradStream._streams[key] = torch.cuda.Stream(self.dev)
+        self.side = WgradStream._streams[key]
+        self.pending = False
+
+    def __enter__(self):
+        global _WGRAD_STREAM
+        self._outer = _WGRAD_STREAM
+        if os.environ.get('VPHO_WGRAD_STREAM', '1') != '0':        # 0: everything on the main stream (A/B aid)
+            _WGRAD_STREAM = self
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_STREAM
+        self.join()
+        _WGRAD_STREAM = self._outer
+
+    def run(self, fn, inputs):
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in inputs:
+            if t is not None:
+                t.record_stream(self.side)
+        out.record_stream(main)                             # consumed on the main stream after join()
+        self.pending = True
+        return out
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self.pending = False
+
+
+_WGRAD_STREAM = None
+
+
+def wgrad_join():
+    if _WGRAD_STREAM is not None:
+        _WGRAD_STREAM.join()
+
+
+def on_wgrad_stream(fn, inputs):
+    """fn() on the weight-gradient stream when one is active (see WgradStream), else right here"""
+    return fn() if _WGRAD_STREAM is None else _WGRAD_STREAM.run(fn, inputs)
+
+
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None, groups=None):
     """x (N,H,W,ld), dy (N,OH,OW,Cout) -> dW (Cout, kh*kw*Cin) in the packed layout of the forward weights.
     ``groups`` (ops.window_groups of the output map): dy is zero outside those 32-pixel groups -- only they are reduced."""
+    if _WGRAD_STREAM is not None and not getattr(_WGRAD_STREAM, '_inside', False):
+        ws = _WGRAD_STREAM
+        ws._inside = True
+        try:
+            extra = [] if groups is None else [t for t in (groups if isinstance(groups, (tuple, list)) else (groups,)) if torch.is_tensor(t)]
+            return ws.run(lambda: conv2d_wgrad(x, dy, kh, kw, stride, pad, cin, pad_y, pad_x, groups), [x, dy] + extra)
+        finally:
+            ws._inside = False
     N, OH, OW, cout = dy.shape
     c_in = x.shape[-1] if cin is None else cin
     small = x.numel() * 4 < 3.9e9 and dy.numel() * 4 < 3.9e9          # the TN kernel addresses its operands by 32-bit byte offsets

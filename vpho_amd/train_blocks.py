@@ -158,7 +158,8 @@ class FPNTrain:
                 if gk in ('conv1', 'conv2', 'conv3', 'down'):
                     key = f'{k}.{"downsample.0" if gk == "down" else gk}.weight'
                     if key in grads:                                      # layer4's second call: summed in the packed layout
-                        gv = grads.pop(key).packed_grad + gv
+                        prev = grads.pop(key).packed_grad                 # (on the stream that produced both terms)
+                        gv = CB.on_wgrad_stream(lambda a=prev, b=gv: a + b, [prev, gv])
                     val = _unpack_grad(gv, *self.shapes[key])
                 else:
                     bn, which = gk.split('.')
@@ -359,6 +360,7 @@ class HeatmapHeadTrain:
         for (py, px), (wp, pady, padx) in self.deconv.items():
             dph = dup[:, py::2, px::2, :].contiguous()                               # this parity's outputs (N,H,W,co)
             g = CB.conv2d_wgrad(S['a1'], dph, 2, 2, 1, pad_y=pady, pad_x=padx).view(co, 2, 2, cin)
+            CB.wgrad_join()                                                          # the taps are copied out on this stream
             for dy_ in (0, 1):
                 for dx_ in (0, 1):
                     dwt[:, :, self.TAP[py][dy_], self.TAP[px][dx_]] = g[:, dy_, dx_, :].t()

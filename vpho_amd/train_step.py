@@ -161,7 +161,8 @@ class DiffusionTrainStep:
         bb_h, bb_o, bb_hr, bb_or = (f32(data[k]) for k in ('bbox_hand', 'bbox_obj', 'bbox_hand_rect', 'bbox_obj_rect'))
         left = (~data['is_right'].bool()).to(torch.uint8).contiguous()
         eh, eo = self.enc['h'], self.enc['o']
-        with torch.cuda.device(self.dev), self.dgrad_weights:
+        from .conv_backward import WgradStream
+        with torch.cuda.device(self.dev), self.dgrad_weights, WgradStream(self.dev) as wstream:
             # ---- forward (VPHO.py:115-150)
             # The FPN outputs are read only through the RoIAligns below (VPHO.py:126-129), so the two smoothing convolutions -- forward,
             # input gradient and weight gradient, the largest launches of the step -- work on the RoI windows only (window = every pixel
@@ -220,6 +221,7 @@ class DiffusionTrainStep:
             if gp is not None:
                 G.update(gp)
             if sink is not None:
+                wstream.join()                                 # weight gradients come from their own stream
                 sink.put(G)
                 sink.flush('heads')
             for br, long_, enc, head, d_enc, d_hm_loss, w_diff, box_rect, box_head, box_tight, flip in (
@@ -241,12 +243,14 @@ class DiffusionTrainStep:
                 G.update({f'head_hm_{long_}.{k}': v for k, v in gh.items()})
                 dfeat[br] = ops.roi_align_bwd(d_head_in, box_head, (H, W), 256, 0.25, into=df)
                 if sink is not None:
+                    wstream.join()
                     sink.put({f'encoder_{long_}.{k}': v for k, v in g.items()})
                     sink.put({f'head_hm_{long_}.{k}': v for k, v in gh.items()})
                     sink.flush('branch_hand' if br == 'h' else 'branch_obj')
 
             def fpn_ready(part, milestone):                    # FPNTrain.backward reports its three milestones
                 if sink is not None:
+                    wstream.join()
                     sink.put({f'feature_extractor.{k}': v for k, v in part.items()})
                     sink.flush(milestone)
             # the FPN outputs are read only through the RoIAligns above, so their gradients live in the RoI windows: the weight gradients
