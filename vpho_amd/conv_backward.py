@@ -244,6 +244,11 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=Non
     N, OH, OW, cout = dy.shape
     c_in = x.shape[-1] if cin is None else cin
     small = x.numel() * 4 < 3.9e9 and dy.numel() * 4 < 3.9e9          # the TN kernel addresses its operands by 32-bit byte offsets
+    if USE_TN_WGRAD and small and cout % 4 and c_in % 4 == 0 and x.shape[-1] % 4 == 0 and groups is None:
+        # 21 / 27 output channels (the heat-map heads): zero channels up to a multiple of 4 and the TN kernel, instead of the explicit
+        # transpose + im2col path (0.22 -> 0.05 ms per head); the rows of the padding channels are dropped
+        dyp = torch.nn.functional.pad(dy, (0, 4 - cout % 4))
+        return conv2d_wgrad(x, dyp, kh, kw, stride, pad, cin, pad_y, pad_x)[:cout]
     if USE_TN_WGRAD and small and c_in % 4 == 0 and cout % 4 == 0 and x.shape[-1] % 4 == 0:
         return ops.conv2d_wgrad_nhwc(x, dy.contiguous(), kh, kw, stride, pad if pad_y is None else pad_y, pad if pad_x is None else pad_x, cin=cin,
                                      groups=groups)

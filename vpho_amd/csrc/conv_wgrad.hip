@@ -8,7 +8,7 @@
 // 16-byte-chunked channel run moved by `buffer_load_dwordx4 ... lds` (out-of-image taps, pixel and channel tails carry an
 // out-of-range offset: the hardware writes zeros).  The MFMA fragments are then single dwords at [k][lane & 31]: half-wave-contiguous ds_read_b32, conflict-free
 // without padding or swizzle.  A workgroup owns one (Cout tile, tile of the flattened (tap, ci) axis) for one slice of the pixel
-// range (split-K over blockIdx.y); a 16-byte chunk never straddles taps (Cin % 4 == 0), so the tap is a per-lane constant and
+// range (split-K; see the kernel for which workgroup takes which slice); a 16-byte chunk never straddles taps (Cin % 4 == 0), so the tap is a per-lane constant and
 // narrow inputs (the 4-channel stem: 16 taps per 64-column tile) take the same path.  Slices are summed in a fixed order by a
 // second kernel.  No im2col / transposed copies are materialised.
 #include "common.h"
@@ -24,10 +24,10 @@ constexpr int BK = 32;
 struct WgArgs {
     const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
     int N, H, W, Cin, x_ld, OH, OW, Cout, dy_ld, KH, KW, stride, pad_y, pad_x;
-    int M, K, tiles_n, ntiles, m_chunk;
+    int M, K, tiles_n, ntiles, m_chunk, splits;
     // optional: the reduction runs over the LISTED groups of BK consecutive pixels only (ascending; vpho_window_groups_i32) -- dY is
     // known to be zero everywhere else (the gradient of a map that is read through RoIAlign lives in the RoI windows).  Needs
-    // OW % BK == 0 (a group never leaves its pixel row).  The slices of blockIdx.y then cut the LIST, m_chunk / BK entries each.
+    // OW % BK == 0 (a group never leaves its pixel row).  The slices then cut the LIST, m_chunk / BK entries each.
     const int* glist; const int* gcount;
 };
 
@@ -43,17 +43,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     constexpr int TILE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
 
-    const int per_xcd = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);          // consecutive column tiles of one Cout tile share an XCD's L2
-    if (lb >= a.ntiles) return;
+    // Workgroup -> (pixel slice, tile).  Workgroups go to the 8 XCDs round-robin, each XCD has its own L2: XCD x takes the slices
+    // s = x, x + 8, ... and runs ALL tiles of a slice one after the other, so both operands of a slice (its dY rows, its x rows) are
+    // fetched from HBM by one XCD once and shared through its L2 by the slice's tiles.  (Round 3 gave every XCD a range of tiles
+    // for all slices: an operand shared by tiles of different ranges was fetched once per XCD -- 64 -> 256 channels on 64 x 64 x 64
+    // pixels moved 536 MB instead of 335 and ran at 37 TF/s.)
+    // With fewer than 8 slices that would leave XCDs idle: then every XCD takes a range of tiles of every slice (consecutive column
+    // tiles of one Cout tile on one XCD share dY), the order of round 3.
+    int slice, lb;
+    if (a.splits >= 8) {
+        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        slice = (seq / a.ntiles) * 8 + xcd; lb = seq % a.ntiles;
+    } else {
+        const int gx = (a.ntiles + 7) / 8 * 8, bx = blockIdx.x % gx;
+        slice = blockIdx.x / gx; lb = (bx & 7) * (gx >> 3) + (bx >> 3);
+    }
+    if (slice >= a.splits || lb >= a.ntiles) return;
     const int tile_n = lb % a.tiles_n, tile_m = lb / a.tiles_n;
     const int co0 = tile_m * BM, c0 = tile_n * BN;                          // c0: column of the flattened (tap, ci) axis
     const bool listed = a.glist != nullptr;
     const int s_per = a.m_chunk / BK;                                       // listed: list entries per slice
-    const int s_begin = blockIdx.y * s_per;
+    const int s_begin = slice * s_per;
     int s_end = 0;
     if (listed) { const int total = *a.gcount; s_end = s_begin + s_per < total ? s_begin + s_per : total; }
-    const int m_begin = listed ? 0 : blockIdx.y * a.m_chunk;
+    const int m_begin = listed ? 0 : slice * a.m_chunk;
     const int m_end = listed ? a.M : (m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
         VPHO_SYNC_LDS_DMA();
     }
 
-    float* out = a.out + (long long)blockIdx.y * a.Cout * a.K;
+    float* out = a.out + (long long)slice * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = c0 + wn * (BN / WN) + j * 32 + li;
@@ -237,12 +250,19 @@ WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     p.tiles_m = (Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
-    // enough workgroups for 256 CUs (2 x 128x128 or 4 x 64x64 tiles fit a CU's LDS), at least 8 stages of 32 pixels per slice
+    // Workgroups for 256 CUs (2 x 128x128 or 4 x 64x64 tiles fit a CU's LDS): about two rounds of them, but no slices shorter than
+    // 16 stages of 32 pixels (8 on the smallest maps, where nothing else fills the chip) -- a slice pays its prologue, its 16 KB
+    // (64 KB) of partial sums and their reduction whatever its length.  Swept over the training step's 47 shapes
+    // (scripts/r04_wgrad_want.sh, r04_wgrad_stages.sh): the 3x3 layers want ~2 000 workgroups, the 1x1 layers on 32 x 32 maps ~500
+    // (8 tiles x 64 slices of 1 024 pixels); a fixed target of 1 536 with 8-stage slices cost 1.5 ms per step more.
     static const int want_env = getenv("VPHO_WGRAD_WANT") ? atoi(getenv("VPHO_WGRAD_WANT")) : 0;      // tuning aid
-    const long long want = want_env > 0 ? (big ? want_env : 2 * want_env) : 1536;
+    static const int stages_env = getenv("VPHO_WGRAD_STAGES") ? atoi(getenv("VPHO_WGRAD_STAGES")) : 0;
+    const long long want = want_env > 0 ? (big ? want_env : 2 * want_env) : (big ? 1024 : 2048);
+    const long long min_stages = stages_env > 0 ? stages_env : (M < 8192 ? 8 : 16);
     long long splits = std::max<long long>(1, (want + tiles - 1) / tiles);
-    splits = std::min<long long>(splits, std::max<long long>(1, M / (8 * BK)));
+    splits = std::min<long long>(splits, std::max<long long>(1, M / (min_stages * BK)));
     splits = std::min<long long>(splits, 256);
+    if (splits >= 8) splits = std::max<long long>(8, (splits + 4) / 8 * 8);          // slices go to the 8 XCDs round-robin (see the kernel)
     long long chunk = (M + splits - 1) / splits;
     chunk = (chunk + BK - 1) / BK * BK;
     p.m_chunk = (int)chunk;
@@ -299,9 +319,10 @@ static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, 
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_ld = dy_ld;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (int)M; a.K = taps * Cin; a.tiles_n = p.tiles_n; a.ntiles = p.tiles_m * p.tiles_n; a.m_chunk = p.m_chunk;
-    a.glist = glist; a.gcount = gcount;
+    a.glist = glist; a.gcount = gcount; a.splits = p.splits;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((a.ntiles + 7) / 8 * 8, p.splits);
+    // see the kernel: XCD = blockIdx.x & 7
+    const dim3 grid(p.splits >= 8 ? 8u * (unsigned)a.ntiles * (unsigned)((p.splits + 7) / 8) : (unsigned)((a.ntiles + 7) / 8 * 8) * (unsigned)p.splits);
     // dW[Cout][taps * Cin] = dY^T (M x Cout) . im2col(x) (M x taps * Cin): 2 M Cout K flop; operands read once + dW written once
     // (a launch on a pixel-group list reduces only over the live groups -- device data --: it is timed with its full-size count and
     // reported as an upper bound by its own class id would mislead, so group launches are left out of the classes)
