@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 VPHO_API const char* vpho_last_error(void);
-VPHO_API int vpho_abi_version(void);   /* 8 */
+VPHO_API int vpho_abi_version(void);   /* 9 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -129,6 +129,11 @@ VPHO_API int vpho_conv3x3_winograd_scatter_nhwc_f32(const float* x, const float*
  * of the convolution fuses the backward of the LeakyReLU that produced the convolution's input (torch autograd of nn.LeakyReLU in
  * Bottleneck / Residual, backbone_FPN_HFL.py:326, encoding.py:21-36): y = gate > 0 ? y : gate_slope * y, gate laid out like y. */
 VPHO_API int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream);
+/* the same for a list of weight tensors in one launch (ABI version 9).  segments: device array of n_segments records
+ * { const float* w_packed; float* u; int32 Cout, Cin, for_input_gradient, first_block; } (32 bytes) with first_block = running sum of
+ * ceil(Cout * Cin / 256) over the preceding records, total_blocks = that sum over all records; every record as for the single call
+ * (the convolution's input channels a multiple of 16) -- not checked on the device. */
+VPHO_API int vpho_winograd_weights_multi_f32(const void* segments, int n_segments, long long total_blocks, void* stream);
 VPHO_API int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
                                         int x_ld, int Cout, float* y, int y_ld, void* stream);
 VPHO_API int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,

@@ -32,10 +32,13 @@ def main():
     data.update(synthetic_mano_targets(step.mano_head.mano, gt_h, (torch.randn(bs, 10, generator=g) * 0.5).to(dev), data['is_right']))
     data['force_local'] = (torch.randn(bs, 32, 3, generator=g) * 0.1).to(dev)
     seen = collections.Counter()
+    grouped_calls = []
     orig = CB.conv2d_wgrad
 
     def rec(x, dy, kh, kw, stride=1, pad=0, cin=None, pad_y=None, pad_x=None, groups=None):
         seen[(tuple(x.shape), tuple(dy.shape), kh, kw, stride, pad, cin, pad_y, pad_x, groups is not None)] += 1
+        if groups is not None:
+            grouped_calls.append((x, dy, kh, kw, stride, pad, groups))
         return orig(x, dy, kh, kw, stride, pad, cin, pad_y, pad_x, groups)
     CB.conv2d_wgrad = rec
     step.step(data, gt_h, gt_o, repeat_num=20)
@@ -57,6 +60,20 @@ def main():
         c_in = xs[-1] if cin is None else cin
         fl = 2.0 * ys[0] * ys[1] * ys[2] * ys[3] * c_in * kh * kw
         rows.append((n * ms, n, ms, fl / ms / 1e9, xs, ys[-1], kh, stride))
+    for x, dy, kh, kw, stride, pad, groups in grouped_calls:       # the window launches: the step's own tensors and pixel-group lists
+        live = int(groups[1].item()) * 32 / (dy.shape[0] * dy.shape[1] * dy.shape[2])
+        for tag, gr in (('window list', groups), ('dense', None)):
+            f = lambda: orig(x, dy, kh, kw, stride, pad, groups=gr)
+            f(); f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                f()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            fl = 2.0 * dy.numel() * x.shape[-1] * kh * kw
+            print(f'# window launch {tuple(x.shape)} -> {dy.shape[-1]}, k{kh}: {tag}: {ms:.3f} ms; live pixel groups {live:.3f} of the map; '
+                  f'{fl * (live if gr is not None else 1.0) / ms / 1e9:.1f} TF/s on the pixels it reduces')
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
     print(f'# weight gradients of one 64-image training step by shape (window launches left out): {tot:.2f} ms per step, {sum(r[1] for r in rows)} launches')

@@ -366,3 +366,26 @@ def test_weight_gradient_over_roi_window_groups():
         full = CB.conv2d_wgrad(x, dy, k, k, 1, pad)
         part = CB.conv2d_wgrad(x, dy, k, k, 1, pad, groups=(lst, cnt))
         assert float((full - part).abs().max()) < 2e-5 * float(full.abs().max()), k
+
+
+def test_winograd_weight_batch_equals_the_single_transforms():
+    """ops.WinogradWeightBatch.refresh(): one launch for the forward AND input-gradient transforms of several 3x3 weights == the
+    per-tensor launches, bit for bit, after the weights changed in place without torch noticing (a kernel wrote through raw pointers)."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(12)
+    ws = [torch.randn(co, 9 * ci, generator=g).cuda() for co, ci in ((64, 64), (128, 32), (32, 128), (256, 16))]
+    batch = ops.WinogradWeightBatch()
+    with batch:
+        us = [(ops.winograd_weights_device(w, False), ops.winograd_weights_device(w, True)) for w in ws]
+    assert len(batch.items) == 8
+    fresh = [torch.randn(w.shape, generator=g).cuda() for w in ws]
+    for w, f in zip(ws, fresh):
+        w.copy_(f)                                                  # new values in place
+    want = [(ops.winograd_weights_device(f, False).clone(), ops.winograd_weights_device(f, True).clone()) for f in fresh]
+    for (uf, ub), (wf, wb) in zip(us, want):
+        ub.zero_(); uf.zero_()
+    batch.refresh()
+    torch.cuda.synchronize()
+    for w, (uf, ub), (wf, wb) in zip(ws, us, want):
+        assert torch.equal(uf, wf) and torch.equal(ub, wb)
+        assert ops.winograd_weights_device(w, True) is ub           # marked current: no further launch

@@ -518,9 +518,8 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
 // convolution the result is for.  mode 0: that convolution is the forward one (w packed as [Cout][(r*3+s)*Cin + ci]); mode 1: its
 // input-gradient convolution = a 3x3 convolution of dY with the spatially flipped, channel-transposed weights (Cin outputs, Cout
 // inputs).  Written straight into the stage-tiled layout of pack.winograd_weights (same slots, same channel order).
-__global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ u) {
+__device__ __forceinline__ void wino_weights_item(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ u, const long long i) {
     const int OUT = mode ? Cin : Cout, IN = mode ? Cout : Cin;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)OUT * IN) return;
     // forward: neighbouring threads = neighbouring ci (contiguous reads); transposed: neighbouring threads = neighbouring OUT = ci as well
     const int o = mode ? (int)(i % OUT) : (int)(i / IN), c = mode ? (int)(i / OUT) : (int)(i % IN);
@@ -542,6 +541,22 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C
 #pragma unroll
         for (int fx = 0; fx < 4; ++fx) u[(((long long)kc * 16 + fy * 4 + fx) * OUT + o) * 8 + j] = (float)v[fx];
     }
+}
+__global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ u) {
+    wino_weights_item(w, Cout, Cin, mode, u, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// the same for a LIST of weight tensors in one launch (training: every 3x3 weight changes in the optimiser step, its forward and its
+// input-gradient transform are both due -- 81 launches of ~6 us per step otherwise); a workgroup finds its record by its first block
+struct WinoWSeg { const float* w; float* u; int Cout, Cin, mode, blk0; };
+__global__ __launch_bounds__(256) void wino_weights_multi_kernel(const WinoWSeg* __restrict__ segs, int nseg) {
+    int lo = 0, hi = nseg - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                   // last record with blk0 <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const WinoWSeg sg = segs[lo];
+    wino_weights_item(sg.w, sg.Cout, sg.Cin, sg.mode, sg.u, (long long)(b - sg.blk0) * 256 + threadIdx.x);
 }
 
 extern "C" int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream) {
@@ -580,6 +595,13 @@ extern "C" int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Ci
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, Cout, Cin, for_input_gradient ? 1 : 0, u);
     return vpho::check_launch("wino_weights_kernel");
+}
+
+extern "C" int vpho_winograd_weights_multi_f32(const void* segments, int n_segments, long long total_blocks, void* stream) {
+    VPHO_REQUIRE(segments && n_segments > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "vpho_winograd_weights_multi_f32: bad argument");
+    static_assert(sizeof(WinoWSeg) == 32, "record = 2 pointers + 4 int32");
+    hipLaunchKernelGGL(wino_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const WinoWSeg*)segments, n_segments);
+    return vpho::check_launch("wino_weights_multi_kernel");
 }
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,

@@ -76,21 +76,43 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
     const float* v = q + 2 * E;
     const float* go = dout + (long long)b * E + h * hd;
     const float scl = 1.0f / sqrtf((float)hd);
-    for (int idx = tid; idx < S * S; idx += 256) {
-        const int i = idx / S, j = idx % S;
-        const float* qi = q + i * rs;
-        const float* kj = k + j * rs;
-        const float* gi = go + i * ro;
-        const float* vj = v + j * rs;
-        float a = 0.f, d = 0.f;
-        for (int c = 0; c < hd; c += 4) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qi + c), k4 = *reinterpret_cast<const f32x4*>(kj + c);
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gi + c), v4 = *reinterpret_cast<const f32x4*>(vj + c);
+    // scores q k^T / sqrt(hd) and dP = dO V^T, both 64 x 64 x hd: the four operands pass through LDS in chunks of 16 feature columns
+    // (coalesced 64-byte row pieces; round 3 let every thread walk whole rows of q, k, dO, v straight from global memory: 16 MB of
+    // 16-byte loads per workgroup at a row stride of B*3E floats, 600 us per launch), a thread accumulates the 4 x 4 block
+    // (ti + 16 u, tj + 16 w) in registers.  Same products in the same order (columns ascending): the same bits as before.
+    {
+        __shared__ float Qc[MB_S][17], Kc[MB_S][17], Gc[MB_S][17], Vc[MB_S][17];
+        const int ti = tid >> 4, tj = tid & 15, lr = tid >> 2, lc = (tid & 3) * 4;
+        float accA[4][4], accD[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a += (q4[u] * scl) * k4[u]; d += g4[u] * v4[u]; }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { accA[u][w] = 0.f; accD[u][w] = 0.f; }
+        for (int c0 = 0; c0 < hd; c0 += 16) {
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, g4 = q4, v4 = q4;
+            if (lr < S && c0 + lc < hd) {                                     // hd % 4 == 0: a chunk of 4 columns is in or out as a whole
+                q4 = *reinterpret_cast<const f32x4*>(q + lr * rs + c0 + lc); k4 = *reinterpret_cast<const f32x4*>(k + lr * rs + c0 + lc);
+                g4 = *reinterpret_cast<const f32x4*>(go + lr * ro + c0 + lc); v4 = *reinterpret_cast<const f32x4*>(v + lr * rs + c0 + lc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { Qc[lr][lc + u] = q4[u] * scl; Kc[lr][lc + u] = k4[u]; Gc[lr][lc + u] = g4[u]; Vc[lr][lc + u] = v4[u]; }
+            __syncthreads();
+            const int nc = hd - c0 < 16 ? hd - c0 : 16;
+            for (int c = 0; c < nc; ++c) {
+                float qv[4], kv[4], gv[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { qv[u] = Qc[ti + 16 * u][c]; gv[u] = Gc[ti + 16 * u][c]; kv[u] = Kc[tj + 16 * u][c]; vv[u] = Vc[tj + 16 * u][c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { accA[u][w] += qv[u] * kv[w]; accD[u][w] += gv[u] * vv[w]; }
+            }
+            __syncthreads();
         }
-        P[i][j] = a;
-        dS[i][j] = d;                                  // dP
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { P[ti + 16 * u][tj + 16 * w] = accA[u][w]; dS[ti + 16 * u][tj + 16 * w] = accD[u][w]; }      // dS holds dP for now
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;

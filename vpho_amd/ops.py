@@ -240,7 +240,54 @@ def winograd_weights_device(w, for_input_gradient=False):
         _call('vpho_winograd_weights_f32', _f32(w), I(cout), I(cin), I(1 if for_input_gradient else 0), _f32(u))
         c = (w._version, u)
         setattr(w, key, c)
+        if _WINO_BATCH is not None:
+            _WINO_BATCH.add(w, key, 1 if for_input_gradient else 0, u)
     return c[1]
+
+
+class WinogradWeightBatch:
+    """Every transform requested inside ``with batch:`` is remembered; ``refresh()`` (after the optimiser step) redoes ALL of them with one
+    launch (vpho_winograd_weights_multi_f32) and marks them current, so the step's convolutions find them ready -- instead of one small
+    launch in front of each of the step's 81 Winograd convolutions."""
+
+    def __init__(self):
+        self.items, self.table, self.blocks = {}, None, 0
+
+    def __enter__(self):
+        global _WINO_BATCH
+        self._outer, _WINO_BATCH = _WINO_BATCH, self
+        return self
+
+    def __exit__(self, *exc):
+        global _WINO_BATCH
+        _WINO_BATCH = self._outer
+
+    def add(self, w, key, mode, u):
+        k = (w.data_ptr(), key)
+        if k not in self.items:
+            self.items[k] = (w, key, mode, u)              # keeps w alive: its address stays its own
+            self.table = None
+
+    def refresh(self):
+        if not self.items:
+            return
+        if self.table is None:
+            import numpy as np
+            rec = np.zeros(len(self.items), dtype=[('w', '<u8'), ('u', '<u8'), ('cout', '<i4'), ('cin', '<i4'), ('mode', '<i4'), ('blk0', '<i4')])
+            blk = 0
+            for n, (w, key, mode, u) in enumerate(self.items.values()):
+                cout, cin = w.shape[0], w.shape[1] // 9
+                _ptr(w, torch.float32), _ptr(u, torch.float32)
+                rec[n] = (w.data_ptr(), u.data_ptr(), cout, cin, mode, blk)
+                blk += (cout * cin + 255) // 256
+            dev = next(iter(self.items.values()))[0].device
+            self.table, self.blocks = torch.from_numpy(rec.view(np.uint8).copy()).to(dev), blk
+        _call('vpho_winograd_weights_multi_f32', _ptr(self.table, torch.uint8), I(len(self.items)), LL(self.blocks))
+        for w, key, mode, u in self.items.values():
+            setattr(w, key, (w._version, u))
+
+
+_WINO_BATCH = None
 
 
 def winograd_ok(H, W, cin, cout, x_ld):

@@ -59,6 +59,7 @@ class DiffusionTrainStep:
         self._register()
         from .conv_backward import DgradWeightCache
         self.dgrad_weights = DgradWeightCache()          # the input-gradient layouts of every convolution weight, rebuilt once per step
+        self.wino_weights = ops.WinogradWeightBatch()    # ... and the Winograd transforms of the 3x3 weights (forward + input gradient)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _register(self):
@@ -162,7 +163,7 @@ class DiffusionTrainStep:
         left = (~data['is_right'].bool()).to(torch.uint8).contiguous()
         eh, eo = self.enc['h'], self.enc['o']
         from .conv_backward import WgradStream
-        with torch.cuda.device(self.dev), self.dgrad_weights, WgradStream(self.dev) as wstream:
+        with torch.cuda.device(self.dev), self.dgrad_weights, self.wino_weights, WgradStream(self.dev) as wstream:
             # ---- forward (VPHO.py:115-150)
             # The FPN outputs are read only through the RoIAligns below (VPHO.py:126-129), so the two smoothing convolutions -- forward,
             # input gradient and weight gradient, the largest launches of the step -- work on the RoI windows only (window = every pixel
@@ -284,6 +285,7 @@ class DiffusionTrainStep:
         for k, v in self._running_stats().items():
             v.copy_(state_dict[k].to(self.dev))
         self.dgrad_weights.refresh()
+        self.wino_weights.refresh()
 
     def _ref_view(self, name):
         """the packed convolution weight `name` seen in the reference's (cout, cin, kh, kw) layout (a strided view of the live tensor)"""
@@ -355,6 +357,7 @@ class DiffusionTrainStep:
                 if self._repack[k] is not None:
                     self._repack[k](self.master[k])
             self.dgrad_weights.refresh()
+            self.wino_weights.refresh()
         return losses
 
     def state_dict(self):
