@@ -484,11 +484,14 @@ __device__ inline void lin_src_t(int dst, float scale, int in_size, int& i0, int
 }
 // F.interpolate(mode='bilinear', align_corners=False) backward as a gather: dx[iy, ix] = sum over the outputs whose two source
 // rows / columns include (iy, ix) of their weights * dy, outputs visited in ascending order (deterministic)
+// a thread owns V consecutive channels of one input pixel: the candidate range and the weights are per pixel, the loads 4 V bytes
+template <int V>
 __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, int N, int OH, int OW, int C, int H, int W, float* __restrict__ dx) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)N * H * W * C) return;
-    const int c = (int)(i % C);
-    long long p = i / C;
+    const int cq = C / V;
+    if (i >= (long long)N * H * W * cq) return;
+    const int c = (int)(i % cq) * V;
+    long long p = i / cq;
     const int ix = (int)(p % W); p /= W;
     const int iy = (int)(p % H);
     const long long n = p / H;
@@ -496,7 +499,9 @@ __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, int N, 
     // outputs whose source position lies in (iy - 1, iy + 1): a conservative index range, exact weights recomputed inside
     const int oy_lo = max(0, (int)floorf(((float)iy - 1.f + 0.5f) / sy - 0.5f) - 1), oy_hi = min(OH - 1, (int)ceilf(((float)iy + 1.f + 0.5f) / sy - 0.5f) + 1);
     const int ox_lo = max(0, (int)floorf(((float)ix - 1.f + 0.5f) / sx - 0.5f) - 1), ox_hi = min(OW - 1, (int)ceilf(((float)ix + 1.f + 0.5f) / sx - 0.5f) + 1);
-    float g = 0.f;
+    float g[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) g[v] = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         int y0, y1; float ly;
         lin_src_t(oy, sy, H, y0, y1, ly);
@@ -507,10 +512,14 @@ __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, int N, 
             lin_src_t(ox, sx, W, x0, x1, lx);
             const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
             if (wx == 0.f) continue;
-            g += wy * wx * dy[((n * OH + oy) * OW + ox) * (long long)C + c];
+            float d[V];
+            ldv<V>(dy + ((n * OH + oy) * OW + ox) * (long long)C + c, d);
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[v] += wgt * d[v];
         }
     }
-    dx[i] = g;
+    stv<V>(dx + ((n * H + iy) * W + ix) * (long long)C + c, g);
 }
 
 // torchvision roi_align backward (aligned=False, adaptive sampling; one RoI per image): every sample of every bin adds its four
@@ -994,7 +1003,10 @@ extern "C" int vpho_maxpool_bwd_nhwc_f32(const float* x, const float* dy, int N,
 
 extern "C" int vpho_resize_bilinear_bwd_nhwc_f32(const float* dy, int N, int OH, int OW, int C, int H, int W, float* dx, void* stream) {
     VPHO_REQUIRE(dy && dx && N > 0 && OH > 0 && OW > 0 && C > 0 && H > 0 && W > 0, "vpho_resize_bilinear_bwd_nhwc_f32: bad argument");
-    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, N, OH, OW, C, H, W, dx);
+    if (C % 4 == 0 && aligned16(dy) && aligned16(dx))
+        hipLaunchKernelGGL(resize_bilinear_bwd_kernel<4>, dim3(nblk((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, N, OH, OW, C, H, W, dx);
+    else
+        hipLaunchKernelGGL(resize_bilinear_bwd_kernel<1>, dim3(nblk((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, N, OH, OW, C, H, W, dx);
     return vpho::check_launch("resize_bilinear_bwd_kernel");
 }
 
