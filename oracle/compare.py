@@ -238,7 +238,11 @@ def parity_summary(out, ref, gd, od, S, bound=TIE_REL):
     res = dict(images=int(hand_clean.shape[0]), images_all_selections_identical=int(all_clean.sum()),
                images_hand_selection_identical=int(hand_clean.sum()), images_object_selection_identical=int(obj_clean.sum()),
                images_first_difference_is_a_tie=int(((~all_clean) & (pg <= TIE_REL)).sum()),
-               images_with_wrong_selection=int((pg > TIE_REL).sum()),
+               # first difference with a relative score gap above the bound.  Given identical candidates the bound is 1e-6 -- BELOW the fp32
+               # rounding noise of the scores themselves (hand_level3: 1e-5 of the score scale) --, so a count here is
+               # not a wrong pick: whether a pick lies within the scores' own noise is what the fp64 referee decides (oracle/referee.py,
+               # tests/test_gpu_referee.py).  (Named images_with_wrong_selection until round 4.)
+               images_with_gap_above_tie_bound=int((pg > TIE_REL).sum()),
                max_rel_score_gap_at_first_differences=float(pg.max()), tie_bound=TIE_REL, per_stage=rep['detail'])
     for k in ('guaranteed_lists', 'guaranteed_images', 'guaranteed_but_different'):
         if k in rep:

@@ -78,7 +78,7 @@ def compare(out, gd, upstream_tol, nfev=None, agg_tol=2e-4, min_identical=None, 
         assert tuple(nfev) == (len(R['tcalls_hand']), len(R['tcalls_obj'])), (nfev, len(R['tcalls_hand']), len(R['tcalls_obj']))
     ref = {k: t(R[k]) for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_hand_mano', 'agg_obj_6d')}
     res, rep = parity_summary(out, ref, gd, reference_dbg(), S, bound=bound)
-    assert res['images_with_wrong_selection'] == 0 and res['max_rel_score_gap_at_first_differences'] <= bound, res
+    assert res['images_with_gap_above_tie_bound'] == 0 and res['max_rel_score_gap_at_first_differences'] <= bound, res
     if min_identical is not None:
         assert res['images_all_selections_identical'] >= min_identical, res
     for k in ('agg_hand_joint', 'agg_hand_vert', 'agg_hand_mano', 'agg_obj_6d'):
