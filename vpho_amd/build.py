@@ -42,15 +42,23 @@ def build_extension(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src) + '.o')
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
-            cmd = [cc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
-            jobs.append(cmd)
+        # every kernel's register / LDS / scratch use is kept next to its object (-Rpass-analysis=kernel-resource-usage): an edit that
+        # pushes a kernel over its register budget compiles without a word and costs its occupancy -- tests/test_kernel_resources.py reads these
+        usage = obj[:-2] + '.usage.txt' if src.endswith('.hip') else None
+        stale = not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr) or (usage is not None and not os.path.exists(usage))
+        if force or stale:
+            cmd = [cc] + FLAGS + (['-x', 'hip', '-Rpass-analysis=kernel-resource-usage'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
+            jobs.append((cmd, usage))
 
-    def run(cmd):
+    def run(job):
+        cmd, usage = job if isinstance(job, tuple) else (job, None)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
-        if verbose and r.stderr:
+        if usage is not None:
+            with open(usage, 'w') as f:
+                f.write(''.join(l + '\n' for l in r.stderr.splitlines() if 'kernel-resource-usage' in l))
+        elif verbose and r.stderr:
             sys.stderr.write(r.stderr)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
