@@ -152,7 +152,8 @@ def gather_rows(rows):
     """All ranks' rows, concatenated in rank order.  Ranks may hold different numbers of rows (a data loader's ragged last batches, like
     accelerate's ``gather_for_metrics``, train_diff_hand_obj.py:333-335): the counts travel first (one all-gather of a single integer per
     rank), the rows padded to the largest count, the padding dropped again.  No-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    from .launch import group_active
+    if not group_active():
         return rows
     world = dist.get_world_size()
     try:

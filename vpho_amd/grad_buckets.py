@@ -89,7 +89,8 @@ class GradBuckets:
         """the gradients of `bucket` are final on this rank: start its all-reduce (sum) without waiting for it"""
         assert bucket not in self._flushed, bucket
         self._flushed.add(bucket)
-        if bucket not in self.range or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        from .launch import group_active
+        if bucket not in self.range or not group_active():
             return
         lo, hi = self.range[bucket]
         seg = self.flat[lo:hi]

@@ -101,9 +101,14 @@ def init_process_group(dev=None, timeout_s=None):
     import torch
     import torch.distributed as dist
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
-    if world <= 1:
+    if world <= 1 and not force_group():
         return 'none'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world <= 1:                     # VPHO_FORCE_NCCL=1 without a launcher: a ONE-rank communicator is still a real RCCL communicator
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('LOCAL_RANK', '0')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     rehearse = os.environ.get('VPHO_REHEARSE_ONE_GPU') == '1'
     backend = 'gloo' if (rehearse or dev is None) else 'nccl'
@@ -128,6 +133,19 @@ def init_process_group(dev=None, timeout_s=None):
         print(f'[vpho_amd] process group up: {world} ranks, backend {dist.get_backend()}' + (' (one-GPU rehearsal)' if rehearse else ''),
               file=sys.stderr, flush=True)
     return backend
+
+
+def force_group():
+    """VPHO_FORCE_NCCL=1: build the process group and take every collective's call site also at world size 1 (a one-rank 'nccl' group is
+    a real RCCL communicator: it loads the library, binds the device and runs the collectives) -- how the RCCL branches are executed
+    on a one-GPU box (tests/test_gpu_rccl.py)."""
+    return os.environ.get('VPHO_FORCE_NCCL') == '1'
+
+
+def group_active():
+    """True where the collectives' call sites must run: a process group exists and spans more than one rank (or VPHO_FORCE_NCCL=1)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_group())
 
 
 def world_from_env(gpus):

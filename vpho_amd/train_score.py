@@ -25,7 +25,8 @@ SUFFIXES = ('t_encoder.1.weight', 't_encoder.1.bias', 'pose_encoder.0.weight', '
 def allreduce_mean_scale(flat_grad):
     """DDP gradient averaging: SUM all-reduce of the flat buffer (RCCL under backend 'nccl'), the 1/world factor is returned
     and folded into the optimiser kernel.  No-op (scale 1) without a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    from .launch import group_active
+    if group_active():
         if dist.get_backend() == 'gloo' and flat_grad.is_cuda:      # one-GPU rehearsal backend: through host memory
             host = flat_grad.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
