@@ -254,7 +254,8 @@ def main():
         head_peak = FP32_MFMA_PEAK_TFLOPS if score_mfma == 'f32' else BF16_MFMA_PEAK_TFLOPS / int(score_mfma[-1])
         conv_peak = FP32_MFMA_PEAK_TFLOPS if conv_mfma == 'f32' else BF16_MFMA_PEAK_TFLOPS / int(conv_mfma[-1])
         result = {
-            'metric': 'eval images/sec (bs=64, sample_num=100, steps=50); MPJPE delta vs ref',
+            # BASELINE.json's metric string at the default arguments; another --bs / --sample_num / --sampling_steps names itself
+            'metric': f'eval images/sec (bs={args.bs}, sample_num={args.sample_num}, steps={args.sampling_steps}); MPJPE delta vs ref',
             'value': images / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32' if (score_mfma, conv_mfma) == ('f32', 'f32') else f'f32 storage and accumulation; products as split-bf16 (score head {score_mfma}, convolutions {conv_mfma}; opt-in, NOT the default)',
@@ -369,7 +370,7 @@ def opt_in_leg(args, model, batches, E, post):
                                      '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`'}}
 
 
-PMC_ROUNDS = ('r04', 'r03', 'r02', 'r01')
+PMC_ROUNDS = ('r05', 'r04', 'r03', 'r02', 'r01')
 
 
 def pmc_traffic(kernel, per_kernel=False):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ inline float rnd(unsigned s) {
     s ^= s << 13; s ^= s >> 17; s ^= s << 5; s *= 2654435761u; s ^= s >> 15;
@@ -29,21 +30,29 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
     if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 int main() {
+    // MI355X_MICROARCH.md, DVFS item 6: the clock is read after >= 2 s of back-to-back launches, median over workgroups
     const int blocks = 256 * 2, iters = 12500;
     float* out; unsigned long long* clk;
     hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int zero = 1; zero >= 0; --zero)
-        for (int rep = 0; rep < 4; ++rep) {
+    for (int zero = 1; zero >= 0; --zero) {
+        double elapsed = 0; float ms = 0; int launches = 0;
+        while (elapsed < 2500.0) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, iters, clk, zero);
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, iters, clk, zero);
             hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            std::vector<unsigned long long> h(blocks * 2);
-            hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
-            double flop = (double)blocks * 4 * iters * 16.0 * 32 * 32 * 2 * 2;
-            printf("%s operands, rep %d: %.2f ms  %.1f TFLOP/s  in-kernel clock %.3f GHz\n", zero ? "zero  " : "random", rep, ms, flop / ms / 1e9,
-                   (double)h[0] / h[1] * 0.1);
+            hipEventElapsedTime(&ms, e0, e1);
+            elapsed += ms; launches += 20;
         }
+        std::vector<unsigned long long> h(blocks * 2);
+        hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
+        std::vector<double> c;
+        for (int b = 0; b < blocks; ++b) if (h[2 * b + 1]) c.push_back((double)h[2 * b] / h[2 * b + 1] * 0.1);
+        std::sort(c.begin(), c.end());
+        double flop = (double)blocks * 4 * iters * 16.0 * 32 * 32 * 2 * 2;
+        printf("bare v_mfma_f32_32x32x2_f32 loop, %s operands: after %.1f s of back-to-back launches (%d): %.3f ms/launch  %.1f TFLOP/s  in-kernel clock "
+               "median %.3f GHz (min %.3f, max %.3f over %zu workgroups)\n", zero ? "zero  " : "random", elapsed * 1e-3, launches, ms / 20, flop / (ms / 20) / 1e9,
+               c[c.size() / 2], c.front(), c.back(), c.size());
+    }
     return 0;
 }

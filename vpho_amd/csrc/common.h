@@ -47,6 +47,37 @@ __device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& 
     l1 = s - (float)i0;
 }
 
+// In-kernel clock stamps (MI355X_MICROARCH.md, DVFS item 6): DIAGNOSTIC builds only (scripts/build_stamps.sh compiles the chip-filling
+// kernels with -DVPHO_CLOCK_STAMPS into scripts/_ab/libvpho_hip_stamps.so; the product library never defines the macro and contains
+// no stamp -- tests/test_abi.py).  A workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once in front of and once
+// behind its main loop; the differences go to a buffer of their own that nothing else reads.  clock = d memtime / d memrealtime x 100 MHz.
+#ifdef VPHO_CLOCK_STAMPS
+#define VPHO_STAMP_SLOTS 65536
+#define VPHO_STAMP_DECL(name)                                                                                                      \
+    __device__ unsigned long long name##_stamps[2 * VPHO_STAMP_SLOTS];                                                             \
+    extern "C" __attribute__((visibility("default"))) int vpho_diag_stamps_##name(unsigned long long* host, int slots, int clear) { \
+        if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(name##_stamps), (size_t)slots * 16) != hipSuccess) return 1;               \
+        if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(name##_stamps)) != hipSuccess || hipMemset(p, 0, sizeof(name##_stamps)) != hipSuccess) return 2; } \
+        return 0;                                                                                                                  \
+    }
+#define VPHO_STAMP_BEGIN()                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    const unsigned long long st_t0_ = __builtin_amdgcn_s_memtime(), st_r0_ = __builtin_amdgcn_s_memrealtime();                     \
+    __builtin_amdgcn_sched_barrier(0)
+#define VPHO_STAMP_END(name, slot)                                                                                                 \
+    do {                                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        const unsigned long long st_t1_ = __builtin_amdgcn_s_memtime(), st_r1_ = __builtin_amdgcn_s_memrealtime();                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        if (threadIdx.x == 0) { const unsigned sl_ = (unsigned)(slot) & (VPHO_STAMP_SLOTS - 1);                                    \
+                                name##_stamps[2 * sl_] = st_t1_ - st_t0_; name##_stamps[2 * sl_ + 1] = st_r1_ - st_r0_; }         \
+    } while (0)
+#else
+#define VPHO_STAMP_DECL(name)
+#define VPHO_STAMP_BEGIN() do {} while (0)
+#define VPHO_STAMP_END(name, slot) do {} while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -14,6 +14,8 @@
 #include "../../include/vpho_hip.h"
 #include <cstdlib>
 
+VPHO_STAMP_DECL(conv)
+
 namespace {
 
 constexpr int BK = 32;
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
     };
+    VPHO_STAMP_BEGIN();
     for (int kt = 0; kt + 1 < nk; ++kt) {
         if (kt > 0 || (g.dbg & 16)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
         compute(kt);
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     if (res_early) { if (d.res_up) load_res_up(); else load_res(); __builtin_amdgcn_sched_barrier(0); }
     compute(nk - 1);
     VPHO_SYNC_LDS_DMA();
+    VPHO_STAMP_END(conv, blockIdx.x);
 
     if (g.vec_epilogue) {
         constexpr int C_LD = BN;                                    // ds_write_b32 halves are separate bank groups: no pad needed

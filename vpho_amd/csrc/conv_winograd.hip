@@ -16,6 +16,8 @@
 #include "../../include/vpho_hip.h"
 #include <cstdlib>
 
+VPHO_STAMP_DECL(wino)
+
 namespace {
 
 #ifndef WINO_ABLATE
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             else VPHO_SYNC_LDS_DMA();
         }
     };
+    VPHO_STAMP_BEGIN();
     for (int ss = 0; ss < nss; ++ss) {
         const int ssn = ss + 1 < nss ? ss + 1 : ss;
         stage(2 * ss, 0, ssn);
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
     }
+    VPHO_STAMP_END(wino, blockIdx.x);
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
     const int co = c0 + wc * 32 + li;

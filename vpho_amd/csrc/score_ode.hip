@@ -22,6 +22,8 @@
 #include <unordered_map>
 #include <algorithm>
 
+VPHO_STAMP_DECL(head)
+
 namespace {
 
 constexpr int HB_K = 16;
@@ -514,6 +516,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     fill(0, 0);
     VPHO_SYNC_LDS_DMA();
     fill(1, 1);
+    VPHO_STAMP_BEGIN();
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
@@ -540,6 +543,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         mfmas();
     }
     __syncthreads();
+    if (TI == 4) VPHO_STAMP_END(head, blockIdx.x);
 
     // epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
     const int lrow_out = rg * 32 + li;
