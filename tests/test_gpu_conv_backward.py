@@ -41,6 +41,32 @@ def test_dgrad_and_wgrad_match_autograd(N, H, W, cin, cout, k, stride, pad):
     np.testing.assert_allclose(db.numpy(), dy.sum(dim=(0, 2, 3)).numpy(), atol=1e-4 * float(dy.abs().sum(dim=(0, 2, 3)).max()), rtol=1e-4)
 
 
+def test_dgrad_through_the_weight_cache_follows_an_in_place_weight_write():
+    """inside ``with DgradWeightCache():`` the input gradients read derived weight layouts.  A conv weight mutated in place with
+    nobody calling refresh() must give the input gradient of the NEW weights (1x1 stride 1, 3x3 stride 2 phases), bit for bit the
+    uncached path's."""
+    from vpho_amd import conv_backward as CB
+    g = torch.Generator().manual_seed(11)
+    cache = CB.DgradWeightCache()
+    cases = []
+    for (cin, cout, k, stride, pad) in ((32, 64, 1, 1, 0), (32, 48, 3, 2, 1), (16, 32, 1, 2, 0)):
+        w = (torch.randn(cout, k * k * cin, generator=g) * 0.1).cuda()
+        dy = torch.randn(2, 8 // stride, 8 // stride, cout, generator=g).cuda()
+        cases.append((w, dy, k, stride, pad))
+    with cache:
+        for w, dy, k, stride, pad in cases:
+            CB.conv2d_dgrad(dy, w, (8, 8), k, k, stride, pad)
+    cache.refresh()
+    for w, *_ in cases:
+        w.mul_(-0.5).add_(0.03)                              # an in-place write nobody announces
+    with cache:
+        got = [CB.conv2d_dgrad(dy, w, (8, 8), k, k, stride, pad) for w, dy, k, stride, pad in cases]
+    assert cache.rebuilds >= 1
+    want = [CB.conv2d_dgrad(dy, w, (8, 8), k, k, stride, pad) for w, dy, k, stride, pad in cases]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('N,H,W,C,slope', [(2, 8, 8, 16, 1.0), (4, 16, 12, 33, 0.01), (64, 32, 32, 64, 0.01), (3, 1, 1, 8, 0.0)])
 def test_batchnorm_training_mode_matches_autograd(N, H, W, C, slope):
     """nn.BatchNorm2d.train() (+ LeakyReLU) forward, running statistics and backward vs torch autograd"""

@@ -44,6 +44,37 @@ def test_dgrad_weight_cache_rebuilds_every_layout_with_one_gather():
     assert cache.map is m and float(cache.get(*want[0]).abs().max()) == 0.0
 
 
+def test_dgrad_weight_cache_notices_an_unannounced_in_place_write():
+    """a weight written in place WITHOUT refresh() (another optimiser, a finite-difference probe) must not leave the input
+    gradients on the old layouts: get() compares the tensor's version counter with the one its layouts were built from and rebuilds."""
+    from vpho_amd import conv_backward as CB
+    g = torch.Generator().manual_seed(5)
+    cache = CB.DgradWeightCache()
+    w1, w2 = torch.randn(8, 9 * 4, generator=g), torch.randn(8, 12, generator=g)
+    b1 = _builders(8, 4, 3, 3, 1)
+    b2 = _builders(8, 12, 1, 1, 0)
+    for w, bs in ((w1, b1), (w2, b2)):
+        for key, b in bs.items():
+            cache.get(w, key, b)
+    cache.refresh()
+    assert cache.rebuilds == 0
+    w1.add_(1.0)                                            # nobody calls refresh()
+    key, b = next(iter(b1.items()))
+    assert torch.equal(cache.get(w1, key, b), b(w1)) and cache.rebuilds == 1
+    for key, b in b1.items():                               # the one rebuild served every layout of every weight
+        assert torch.equal(cache.get(w1, key, b), b(w1))
+    assert cache.rebuilds == 1
+    w2.mul_(2.0)
+    key, b = next(iter(b2.items()))
+    assert torch.equal(cache.get(w2, key, b), b(w2)) and cache.rebuilds == 2
+    # a layout registered for the FIRST time after an unannounced write of an already known weight
+    w1.sub_(0.25)
+    extra = lambda w: CB._pad_rows4(w).clone()
+    assert torch.equal(cache.get(w1, ('extra',), extra), extra(w1))
+    key, b = next(iter(b1.items()))
+    assert torch.equal(cache.get(w1, key, b), b(w1))
+
+
 def test_cache_is_only_consulted_inside_its_context():
     from vpho_amd import conv_backward as CB
     w = torch.randn(4, 8)

@@ -70,11 +70,17 @@ class DgradWeightCache:
     convolution, zeros + tap copies per phase).  They only change when the weights do, i.e. once per optimiser step: this cache keeps
     every derived tensor in ONE flat buffer together with an index map into the concatenated packed weights (the layout recipe run once
     on an index tensor instead of on values; index 0 = a constant zero), and ``refresh()`` rebuilds all of them with one concatenation
-    and one gather.  Owned by a DiffusionTrainStep and active only inside its backward (``with cache:``); everything else builds per call."""
+    and one gather.  Owned by a DiffusionTrainStep and active only inside its backward (``with cache:``); everything else builds per call.
+    Staleness is checked, not assumed: the version counter of every registered weight is recorded when its layouts are built, and a
+    ``get`` that meets another version (an in-place write nobody announced: an optimiser other than the step's own, a finite-difference
+    probe, ``load_state_dict``) rebuilds before it answers -- ``refresh()`` after the optimiser step is a batching optimisation, not a
+    correctness requirement (the kernels' raw-pointer writes bump the counters themselves, ``ops.AdamWList.step``)."""
 
     def __init__(self):
         self.entries, self.weights, self.offset = {}, [], {}
         self.total, self.dirty, self.flat, self.map = 0, False, None, None
+        self.versions = {}                                 # (data_ptr, shape) -> tensor._version the derived layouts were built from
+        self.rebuilds = 0                                  # refreshes triggered by a version mismatch (tests)
 
     def __enter__(self):
         global _ACTIVE
@@ -86,15 +92,23 @@ class DgradWeightCache:
         _ACTIVE = self._outer
 
     def get(self, w_packed, key, builder):
-        k = (w_packed.data_ptr(), tuple(w_packed.shape), key)
+        wk = (w_packed.data_ptr(), tuple(w_packed.shape))
+        k = wk + (key,)
         e = self.entries.get(k)
+        if e is not None and self.versions.get(wk) != w_packed._version:
+            self.rebuilds += 1
+            self.refresh()                                 # somebody wrote the weights in place since the layouts were built
+            e = self.entries[k]
         if e is None:
             assert w_packed.is_contiguous()
-            wk = (w_packed.data_ptr(), tuple(w_packed.shape))
             if wk not in self.offset:                      # the list keeps the tensor alive: its address cannot be handed out again
                 self.offset[wk] = self.total
                 self.weights.append(w_packed)
                 self.total += w_packed.numel()
+                self.versions[wk] = w_packed._version
+            elif self.versions.get(wk) != w_packed._version:      # a second layout of a weight that changed since its first one was built
+                self.rebuilds += 1
+                self.refresh()
             off = self.offset[wk]
             idx = torch.arange(off + 1, off + 1 + w_packed.numel(), device=w_packed.device, dtype=torch.int64).view(w_packed.shape)
             m = builder(idx)
@@ -119,6 +133,8 @@ class DgradWeightCache:
             self.dirty = False
         src = torch.cat([self._zero] + [w.reshape(-1) for w in self.weights])
         torch.index_select(src, 0, self.map, out=self.flat)
+        for w in self.weights:
+            self.versions[(w.data_ptr(), tuple(w.shape))] = w._version
 
 
 _ACTIVE = None
