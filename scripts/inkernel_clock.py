@@ -26,16 +26,59 @@ SECONDS = 2.5
 PEAK = 157.3
 
 
+WORDS = 10
+
+
 def stamps(name, slots):
     fn = getattr(ops.lib, f'vpho_diag_stamps_{name}')
     fn.restype = C.c_int
-    buf = np.zeros(2 * slots, dtype=np.uint64)
+    buf = np.zeros(WORDS * slots, dtype=np.uint64)
     torch.cuda.synchronize()
     assert fn(buf.ctypes.data_as(C.c_void_p), C.c_int(slots), C.c_int(1)) == 0
-    b = buf.reshape(slots, 2)
-    b = b[b[:, 1] > 0]
-    clk = b[:, 0].astype(np.float64) / b[:, 1].astype(np.float64) * 0.1
-    return clk, b
+    b = buf.reshape(slots, WORDS)
+    return b[b[:, 7] > 0]
+
+
+def timeline(b, clock_ghz):
+    """the launch as its workgroups saw it: phases of a workgroup's life, and -- from the chip-wide 100 MHz counter -- how the workgroups of
+    one CU follow each other and how much of the launch's wall time a CU has 0 / 1 / 2 workgroups inside their main loops"""
+    t = b[:, :6].astype(np.float64)
+    cyc_us = 1e-3 / clock_ghz                                       # microseconds per shader cycle
+    ph = {'entry -> first fills requested': (t[:, 1] - t[:, 0]) * cyc_us, 'first fill wait': (t[:, 2] - t[:, 1]) * cyc_us,
+          'main loop': (t[:, 3] - t[:, 2]) * cyc_us, 'epilogue': (t[:, 4] - t[:, 3]) * cyc_us}
+    r0, r1 = b[:, 6].astype(np.int64), b[:, 7].astype(np.int64)
+    rb = b[:, 9].astype(np.int64)
+    re = rb + (b[:, 8] >> np.uint64(32)).astype(np.int64)
+    cu = ((b[:, 8] >> np.uint64(8)) & np.uint64(0xFFF)).astype(np.int64)        # xcc id (4 bits) | se / sh / cu id of HW_ID
+    start = r0.min()
+    wall = (r1.max() - start) / 100.0
+    life = (r1 - r0) / 100.0
+    out = [f'    workgroup life {np.median(life):.1f} us median (p05 {np.percentile(life, 5):.1f}, p95 {np.percentile(life, 95):.1f}); launch in-kernel wall (first entry -> last exit) {wall:.1f} us; '
+           f'{len(np.unique(cu))} CUs seen']
+    out.append('    phases of a workgroup (median / p95, us): ' + '; '.join(f'{k} {np.median(v):.2f} / {np.percentile(v, 95):.2f}' for k, v in ph.items()))
+    gaps, cover = [], np.zeros(4)
+    first_entry = []
+    for c in np.unique(cu):
+        m = cu == c
+        o = np.argsort(r0[m])
+        s0, s1 = r0[m][o], r1[m][o]
+        first_entry.append((s0[0] - start) / 100.0)
+        for i in range(len(s0)):
+            ended = s1[:i][s1[:i] <= s0[i]]
+            if len(ended) and i >= 2:
+                gaps.append((s0[i] - ended.max()) / 100.0)
+        ev = sorted([(x, 1) for x in rb[m]] + [(x, -1) for x in re[m]])
+        depth, last = 0, start
+        for x, d in ev:
+            cover[min(depth, 3)] += x - last
+            depth += d
+            last = x
+        cover[0] += r1.max() - last
+    cover = cover / cover.sum()
+    out.append(f'    first workgroup of a CU enters {np.median(first_entry):.2f} us after the launch\'s first (p95 {np.percentile(first_entry, 95):.2f}); '
+               + (f'slot turnover (a workgroup exits -> the next one\'s first instruction on that CU) {np.median(gaps):.2f} us median, p95 {np.percentile(gaps, 95):.2f} ({len(gaps)} hand-overs)' if gaps else 'one round: no slot turnover'))
+    out.append(f'    share of the launch\'s in-kernel wall a CU has 0 / 1 / 2 / >2 workgroups inside their main loops: {cover[0]:.3f} / {cover[1]:.3f} / {cover[2]:.3f} / {cover[3]:.3f}')
+    return '\n'.join(out)
 
 
 def run(label, name, fn, flop, slots):
@@ -55,13 +98,15 @@ def run(label, name, fn, flop, slots):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 50
         n += 50
-    clk, raw = stamps(name, slots)
+    b = stamps(name, slots)
+    loop_real = (b[:, 8] >> np.uint64(32)).astype(np.float64)
+    ok = loop_real > 0
+    clk = (b[ok, 3] - b[ok, 2]).astype(np.float64) / loop_real[ok] * 0.1
     med = float(np.median(clk))
     tf = flop / ms / 1e9
-    loop_us = float(np.median(raw[:, 1])) / 100.0
     print(f'{label}\n    {n} back-to-back launches in {time.perf_counter() - t0:.1f} s; steady state {ms * 1e3:.1f} us/launch = {tf:.1f} TFLOP/s = {tf / PEAK:.3f} of the '
-          f'2.4 GHz peak, {tf / (PEAK * med / 2.4):.3f} of the peak at the measured clock\n    in-kernel clock: median {med:.3f} GHz  (p05 {np.percentile(clk, 5):.3f}, '
-          f'p95 {np.percentile(clk, 95):.3f}; {len(clk)} workgroups stamped, main loop median {loop_us:.1f} us of realtime)', flush=True)
+          f'2.4 GHz peak, {tf / (PEAK * med / 2.4):.3f} of the peak at the measured clock\n    in-kernel clock over the main loop: median {med:.3f} GHz  (p05 {np.percentile(clk, 5):.3f}, '
+          f'p95 {np.percentile(clk, 95):.3f}; {len(clk)} workgroups stamped)\n' + timeline(b, med), flush=True)
     return med
 
 

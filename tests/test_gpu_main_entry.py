@@ -100,7 +100,18 @@ def test_trainer_eval_consumes_any_iterable_of_batch_dicts(assets):
             b['gt_joint'], b['gt_hand_vert'] = gt_j.clone(), gt_v.clone()
         torch.manual_seed(11)
         got = t.eval(loader=iter(batches))                     # a one-shot iterator, tensors on the host
-        assert torch.equal(got, want)
+        assert torch.equal(got[:, 1:], want[:, 1:])
+        # column 0 without an `index` column in the batches: rank-unique negative ids -(rank + world * running count) - 1
+        assert got[:, 0].tolist() == [-1.0, -2.0, -3.0, -4.0, -5.0, -6.0]
+        for i, b in enumerate(batches):                        # with the data set's own index column (a run): that index
+            b['index'] = torch.arange(100 + 2 * i, 102 + 2 * i)
+        torch.manual_seed(11)
+        got = t.eval(loader=iter(batches))
+        assert got[:, 0].tolist() == [100.0, 101.0, 102.0, 103.0, 104.0, 105.0] and torch.equal(got[:, 1:], want[:, 1:])
+        for b in batches:
+            del b['index']
+        with pytest.raises(ValueError, match='no batch on any rank'):
+            t.eval(loader=[])
         # ragged last batch: one image
         last = {k: (v[:1] if torch.is_tensor(v) else v[:1]) for k, v in batches[2].items()}
         rows = t.eval(loader=[batches[0], batches[1], last])

@@ -47,35 +47,52 @@ __device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& 
     l1 = s - (float)i0;
 }
 
-// In-kernel clock stamps (MI355X_MICROARCH.md, DVFS item 6): DIAGNOSTIC builds only (scripts/build_stamps.sh compiles the chip-filling
-// kernels with -DVPHO_CLOCK_STAMPS into scripts/_ab/libvpho_hip_stamps.so; the product library never defines the macro and contains
-// no stamp -- tests/test_abi.py).  A workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once in front of and once
-// behind its main loop; the differences go to a buffer of their own that nothing else reads.  clock = d memtime / d memrealtime x 100 MHz.
+// In-kernel stamps (MI355X_MICROARCH.md, DVFS item 6; cdna_hip_programming.md 7, "In-kernel stamps"): DIAGNOSTIC builds only
+// (scripts/build_stamps.sh compiles the chip-filling kernels with -DVPHO_CLOCK_STAMPS into scripts/_ab/libvpho_hip_stamps.so; the
+// product library never defines the macro and contains no stamp -- tests/test_abi.py).  A workgroup reads s_memtime (shader cycles) at
+// up to six points of its life -- [0] entry, [1] set-up done / first fills requested, [2] main loop begins (first stage landed),
+// [3] main loop ends, [4] epilogue done (stores issued), [5] free -- and s_memrealtime (100 MHz, one counter for the whole chip) at
+// entry and exit, plus the CU it ran on; the record goes to a buffer of its own that nothing else reads.
+//   clock = ([3] - [2]) / (realtime over the same span) is reported from [0]..[4] / realtime entry..exit;  the realtime stamps of all
+//   workgroups of a launch give the launch's timeline per CU (scripts/inkernel_clock.py).
 #ifdef VPHO_CLOCK_STAMPS
 #define VPHO_STAMP_SLOTS 65536
+#define VPHO_STAMP_WORDS 10
 #define VPHO_STAMP_DECL(name)                                                                                                      \
-    __device__ unsigned long long name##_stamps[2 * VPHO_STAMP_SLOTS];                                                             \
+    __device__ unsigned long long name##_stamps[VPHO_STAMP_WORDS * VPHO_STAMP_SLOTS];                                              \
     extern "C" __attribute__((visibility("default"))) int vpho_diag_stamps_##name(unsigned long long* host, int slots, int clear) { \
-        if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(name##_stamps), (size_t)slots * 16) != hipSuccess) return 1;               \
+        if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(name##_stamps), (size_t)slots * VPHO_STAMP_WORDS * 8) != hipSuccess) return 1; \
         if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(name##_stamps)) != hipSuccess || hipMemset(p, 0, sizeof(name##_stamps)) != hipSuccess) return 2; } \
         return 0;                                                                                                                  \
     }
-#define VPHO_STAMP_BEGIN()                                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                                             \
-    const unsigned long long st_t0_ = __builtin_amdgcn_s_memtime(), st_r0_ = __builtin_amdgcn_s_memrealtime();                     \
+#define VPHO_STAMP_INIT()                                                                                                          \
+    unsigned long long st_t_[6] = {0, 0, 0, 0, 0, 0};                                                                              \
+    const unsigned long long st_r0_ = __builtin_amdgcn_s_memrealtime();                                                            \
+    unsigned long long st_rb_ = 0, st_re_ = 0;                                                                                     \
+    st_t_[0] = __builtin_amdgcn_s_memtime();                                                                                       \
     __builtin_amdgcn_sched_barrier(0)
-#define VPHO_STAMP_END(name, slot)                                                                                                 \
+#define VPHO_STAMP_AT(k)                                                                                                           \
+    do { __builtin_amdgcn_sched_barrier(0); st_t_[k] = __builtin_amdgcn_s_memtime();                                               \
+         if ((k) == 2) st_rb_ = __builtin_amdgcn_s_memrealtime();                                                                  \
+         if ((k) == 3) st_re_ = __builtin_amdgcn_s_memrealtime();                                                                  \
+         __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VPHO_STAMP_WRITE(name, slot)                                                                                               \
     do {                                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        const unsigned long long st_t1_ = __builtin_amdgcn_s_memtime(), st_r1_ = __builtin_amdgcn_s_memrealtime();                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        if (threadIdx.x == 0) { const unsigned sl_ = (unsigned)(slot) & (VPHO_STAMP_SLOTS - 1);                                    \
-                                name##_stamps[2 * sl_] = st_t1_ - st_t0_; name##_stamps[2 * sl_ + 1] = st_r1_ - st_r0_; }         \
+        const unsigned long long st_r1_ = __builtin_amdgcn_s_memrealtime();                                                        \
+        if (threadIdx.x == 0) {                                                                                                    \
+            unsigned long long* q_ = name##_stamps + (size_t)((unsigned)(slot) & (VPHO_STAMP_SLOTS - 1)) * VPHO_STAMP_WORDS;       \
+            for (int i_ = 0; i_ < 6; ++i_) q_[i_] = st_t_[i_];                                                                     \
+            q_[6] = st_r0_; q_[7] = st_r1_;                                                                                        \
+            q_[8] = ((unsigned long long)(st_re_ - st_rb_) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 16) | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFF); \
+            q_[9] = st_rb_;                                                                                                        \
+        }                                                                                                                          \
     } while (0)
 #else
 #define VPHO_STAMP_DECL(name)
-#define VPHO_STAMP_BEGIN() do {} while (0)
-#define VPHO_STAMP_END(name, slot) do {} while (0)
+#define VPHO_STAMP_INIT() do {} while (0)
+#define VPHO_STAMP_AT(k) do {} while (0)
+#define VPHO_STAMP_WRITE(name, slot) do {} while (0)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

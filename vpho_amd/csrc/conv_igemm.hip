@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     // before it reads the current one
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE + (PRE ? 2 * GLDS_PRE_MAX : 0)];
     float* const pre_tab = smem + 2 * TILE;
+    VPHO_STAMP_INIT();
 
     vpho_conv_desc d = g.d;
     d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     // the first TWO stages are requested back to back and only the first is waited for (counted vmcnt: fills complete in issue order):
     // a short-K tile (K = 64: two stages in all) pays one memory round trip at its start, not one and a half
     if (UNI) fill_uni(0, 0); else fill(0);
+    VPHO_STAMP_AT(1);
     if (nk > 1 && !(g.dbg & 16)) {
         if (UNI) fill_uni(1, 1); else fill(1);
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
     };
-    VPHO_STAMP_BEGIN();
+    VPHO_STAMP_AT(2);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         if (kt > 0 || (g.dbg & 16)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
         compute(kt);
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     if (res_early) { if (d.res_up) load_res_up(); else load_res(); __builtin_amdgcn_sched_barrier(0); }
     compute(nk - 1);
     VPHO_SYNC_LDS_DMA();
-    VPHO_STAMP_END(conv, blockIdx.x);
+    VPHO_STAMP_AT(3);
 
     if (g.vec_epilogue) {
         constexpr int C_LD = BN;                                    // ds_write_b32 halves are separate bank groups: no pad needed
@@ -645,6 +647,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
             }
             *reinterpret_cast<f32x4*>(d.y + yoff) = o;
         }
+        VPHO_STAMP_AT(4);
+        VPHO_STAMP_WRITE(conv, blockIdx.x);
         return;
     }
     const int row_base = m0 + wm * (BM / WM) + 4 * lh, col_base = n0 + wn * (BN / WN) + li;

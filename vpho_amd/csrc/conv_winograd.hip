@@ -63,6 +63,7 @@ __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int&
 
 __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
+    VPHO_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int wt = wave & 1, wc = wave >> 1;
     // XCD-aware block order: workgroup i runs on XCD i % 8, and every XCD has its own L2.  All tile blocks that share an output-channel
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     const int fsw = (li >> 3) & 1;
     load_patch(pc, 0);
     fill_u(0, 0);
+    VPHO_STAMP_AT(1);
     row_transform(pc, 0);
 #pragma unroll
     for (int fy = 0; fy < 4; ++fy) store_v_row(0, fy);
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             else VPHO_SYNC_LDS_DMA();
         }
     };
-    VPHO_STAMP_BEGIN();
+    VPHO_STAMP_AT(2);
     for (int ss = 0; ss < nss; ++ss) {
         const int ssn = ss + 1 < nss ? ss + 1 : ss;
         stage(2 * ss, 0, ssn);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
     }
-    VPHO_STAMP_END(wino, blockIdx.x);
+    VPHO_STAMP_AT(3);
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
     const int co = c0 + wc * 32 + li;
@@ -280,6 +282,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             }
         }
     }
+    VPHO_STAMP_AT(4);
+    VPHO_STAMP_WRITE(wino, blockIdx.x);
 }
 
 

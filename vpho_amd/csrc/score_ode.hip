@@ -460,6 +460,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
     constexpr int STAGE = (256 + 128) * HB_K;
     float* Eb = smem + 2 * STAGE;
+    VPHO_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;   // hidden base of the wave = 32*TI*hh
     // one wave instruction fills 64 x 16 B = RPW whole tile rows; chunk swizzle f(row) = (row >> SW_SHIFT) & (CPR-1) keeps
@@ -514,9 +515,10 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
     // load has a whole k-tile of MFMA time to land before the next barrier needs it.
     fill(0, 0);
+    VPHO_STAMP_AT(1);
     VPHO_SYNC_LDS_DMA();
     fill(1, 1);
-    VPHO_STAMP_BEGIN();
+    VPHO_STAMP_AT(2);
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
@@ -543,7 +545,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         mfmas();
     }
     __syncthreads();
-    if (TI == 4) VPHO_STAMP_END(head, blockIdx.x);
+    VPHO_STAMP_AT(3);
 
     // epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
     const int lrow_out = rg * 32 + li;
@@ -604,6 +606,8 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
             if (nans) atomicAdd(a.nan_count, nans);
         }
     }
+    VPHO_STAMP_AT(4);
+    VPHO_STAMP_WRITE(head, blockIdx.x);
 }
 
 __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {

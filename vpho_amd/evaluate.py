@@ -58,7 +58,10 @@ def metric_rows(out, data, gt_joint, gt_vert, first_index, assets=None):
     pp = postprocess(out, data['root_joint'], data['is_right'])
     bs = gt_joint.shape[0]
     rows = torch.empty((bs, ROW), device=gt_joint.device, dtype=torch.float32)
-    rows[:, 0] = torch.arange(first_index, first_index + bs, device=rows.device, dtype=torch.float32)
+    if torch.is_tensor(first_index):                 # per-image ids (a loader batch that is not a run of the data set)
+        rows[:, 0] = first_index.to(device=rows.device, dtype=torch.float32).reshape(bs)
+    else:
+        rows[:, 0] = torch.arange(first_index, first_index + bs, device=rows.device, dtype=torch.float32)
     rows[:, 1] = mje_mm(pp['reg_hand_joint'], gt_joint)
     rows[:, 2] = mje_mm(pp['first_hand_joint'], gt_joint)
     rows[:, 3] = mje_mm(pp['agg_hand_joint'], gt_joint)

@@ -189,6 +189,14 @@ class Trainer:
             return
         seen = 0
         for b in loader:
+            # column 0 of the metric rows, decided on the HOST batch (a device tensor here would cost two syncs per batch inside the
+            # three-deep pipeline): the data set's own index where the batch is a run of it, else rank-unique NEGATIVE ids
+            # -(rank + world * running count) - 1 per image -- they can collide neither with another rank's fallback nor with a real data-set index
+            idx = b.get('index')
+            if torch.is_tensor(idx) and idx.numel() and loader_indices_are_consecutive(idx.cpu() if idx.is_cuda else idx):
+                first = int(idx.reshape(-1)[0])
+            else:
+                first = None
             b = self._to_device(b)
             missing = [k for k in ('gt_joint', 'gt_hand_vert') if k not in b]
             if missing:
@@ -197,9 +205,7 @@ class Trainer:
                 from . import ops
                 b['gt_obj_rt'] = ops.obj_9d_to_rt(b['gt_obj'].double().contiguous(), b['root_joint'].float().contiguous()).float()
             n = b['rgb'].shape[0]
-            # column 0 of the metric rows: the data set's own index where the batch is a run of it, else the rank's running count
-            first = int(b['index'].reshape(-1)[0]) if torch.is_tensor(b.get('index')) and loader_indices_are_consecutive(b['index']) else seen
-            yield b, (b['gt_joint'].float(), b['gt_hand_vert'].float()), first
+            yield b, (b['gt_joint'].float(), b['gt_hand_vert'].float()), (first if first is not None else -(self.rank + self.world * (seen + torch.arange(n))) - 1)
             seen += n
 
     @torch.no_grad()
@@ -227,9 +233,12 @@ class Trainer:
             pass
         rows += [f.result() for f in futs]
         pipe.close()
-        if not rows:
-            raise ValueError('Trainer.eval: the loader yielded no batch')
-        rows = E.gather_rows(torch.cat(rows, 0))
+        # a rank whose shard is empty still takes part in the collective (with zero rows: the ragged gather carries the counts first);
+        # raising here would leave the other ranks blocked in their all-gather.  Only an evaluation without ANY image is an error
+        mine = torch.cat(rows, 0) if rows else torch.zeros((0, E.ROW), device=self.device, dtype=torch.float32)
+        rows = E.gather_rows(mine)
+        if rows.shape[0] == 0:
+            raise ValueError('Trainer.eval: the loader yielded no batch on any rank')
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if self.rank == 0:
