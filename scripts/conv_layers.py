@@ -72,6 +72,14 @@ def main():
         rows_obj = kw.get('rows')
         live = 1.0
         npix_out = y.numel() / cout
+        if kw.get('out_view') is not None or kw.get('out_hw') is not None:
+            # the launch writes INTO a larger view (the four phase convolutions of the transposed convolution each fill a quarter of the
+            # 64 x 64 map): count the pixels the launch computes, not the pixels of the tensor it returns (370 "TFLOP/s")
+            st_, pd_ = kw.get('stride', 1), kw.get('pad', 0)
+            py_ = kw.get('pad_y') if kw.get('pad_y') is not None else pd_
+            px_ = kw.get('pad_x') if kw.get('pad_x') is not None else pd_
+            oh, ow = kw['out_hw'] if kw.get('out_hw') is not None else ((H + 2 * py_ - kh) // st_ + 1, (W + 2 * px_ - kwd) // st_ + 1)
+            npix_out = N * oh * ow
         if rows_obj is not None:
             live = float(rows_obj.count.item()) / (rows_obj.shape[0] * rows_obj.shape[1] * rows_obj.shape[2])
             npix_out = rows_obj.shape[0] * rows_obj.shape[1] * rows_obj.shape[2] * live

@@ -41,6 +41,28 @@ def test_library_exports_nothing_but_the_header():
     assert hdr.count('VPHO_API ') - 1 == len(exported)            # every declaration carries the export attribute (+ the #define)
 
 
+def test_product_library_carries_no_ablation_or_stamp_code():
+    """Switches that make a kernel produce WRONG results (timing ablations: skipped loads / barriers / stores) and the in-kernel clock
+    stamps exist only as compile-time macros of diagnostic builds (scripts/kernel_ablate.sh, scripts/build_stamps.sh): the product
+    library reads no such environment variable, exports no diagnostic entry point, and its build defines none of the macros
+    (VPHO_CONV_DBG bits 1 / 2 / 4 and VPHO_WINO_ABL used to be one stray environment variable away)."""
+    import subprocess
+    import __graft_entry__ as g
+    from vpho_amd import build as B
+    g.build()
+    lib = os.path.join(ROOT, 'vpho_amd', 'libvpho_hip.so')
+    strs = subprocess.run(['strings', '-n', '6', lib], capture_output=True, text=True, check=True).stdout
+    env = sorted(set(re.findall(r'VPHO_[A-Z0-9_]+', strs)))
+    assert 'VPHO_WINO_ABL' not in env and not [e for e in env if 'ABL' in e or 'STAMP' in e], env
+    assert 'vpho_diag_' not in strs
+    macros = ('CONV_ABLATE', 'WINO_ABLATE', 'WINO8_ABLATE', 'FK_ABLATE', 'VPHO_CLOCK_STAMPS')
+    assert not [f for f in B.FLAGS if any(m in f for m in macros)], B.FLAGS
+    src = open(os.path.join(ROOT, 'vpho_amd', 'csrc', 'conv_igemm.hip')).read()
+    # the run-time VPHO_CONV_DBG keeps only its two bit-identical A/B orders
+    assert re.search(r'g\.dbg\s*=\s*dbg_env \? \(atoi\(dbg_env\) & \(8 \| 16\)\)', src), 'VPHO_CONV_DBG must be masked to its bit-identical bits'
+    assert not re.search(r'g\.dbg & (1|2|4)\b', src)
+
+
 def test_state_dict_layout_matches_reference_contract(model_cpu):
     sd = model_cpu.state_dict()
     assert len([k for k in sd if k.startswith('feature_extractor.')]) == 530

@@ -55,6 +55,26 @@ def test_register_ring_pose_encoder_is_bit_identical_to_the_lds_ring_kernel(nets
     assert res['0'][3] == res['1'][3] and torch.equal(res['0'][1], res['1'][1]) and torch.equal(res['0'][2], res['1'][2])
 
 
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+@pytest.mark.parametrize('bs,S', [(64, 100), (5, 64), (3, 2129), (2, 600)])
+def test_score_head_per_image_terms_from_lds_are_bit_identical_to_the_global_loads(nets, name, D, bs, S):
+    """round 5: the epilogue's per-image terms (cimg) come from an LDS copy of the <= 3 images a 128-row tile spans (sample_num >= 64)
+    instead of 64 global loads per lane; VPHO_HEAD_CB=0 keeps the global loads.  Same values, same order of additions: every score
+    bit-identical -- README batch (tiles straddling two and three images, tail tiles), sample_num 64 (the smallest that takes the LDS
+    path: 3 images per tile), ragged last tiles."""
+    import os
+    feat, x = seeded((bs, 1024), 70, 0.3).cuda(), seeded((bs * S, D), 71, 1.5).cuda()
+    res = {}
+    for cb in ('0', '1'):
+        os.environ['VPHO_HEAD_CB'] = cb
+        try:
+            res[cb] = nets[name].score(feat, x, 0.3, S).clone()
+        finally:
+            os.environ.pop('VPHO_HEAD_CB', None)
+    assert torch.isfinite(res['1']).all() and float(res['1'].abs().max()) > 0
+    assert torch.equal(res['0'], res['1'])
+
+
 def test_score_tail_tiles_match_oracle(sd, nets):
     """6 387 rows x 32 heads = 1 600 tiles on 512 workgroup slots: the launch runs 48 ordinary tiles per head and the remaining 243
     rows as 32-row tail tiles (the last one ragged).  Rows of every kind of tile against the oracle, and BIT-IDENTICAL to a launch of

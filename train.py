@@ -11,6 +11,7 @@ all-reduces of the flat gradient buffer (RCCL) overlapped with it under data par
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -28,6 +29,7 @@ def main():
     ap.add_argument('--repeat_num', type=int, default=20)
     ap.add_argument('--breakdown', action='store_true', help='also time forward+backward and the optimiser separately')
     ap.add_argument('--seed', type=int, default=206)
+    ap.add_argument('--no_roofline', action='store_true', help='skip the instrumented repeat that feeds the roofline block (profiler passes)')
     args = ap.parse_args()
     from vpho_amd.launch import maybe_spawn, world_from_env
     maybe_spawn(args.gpus)             # N > 1 from a bare shell: start the N rank processes (before any GPU call)
@@ -82,9 +84,10 @@ def main():
     res = {'metric': 'end-to-end training images/s (all 13 losses of vpho_net.forward(mode=train), every module trained)',
            'value': world * args.steps * bs / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
            'dtype': 'f32', 'config': {'per_gpu_batch': bs, 'repeat_num': args.repeat_num, 'patch': 256},
-           'trained_tensors': len(step.names), 'trained_parameters': int(step.flat_grad.numel()),
+           # parameters as the reference counts them: convolution weights by their (cout, cin, kh, kw) shape, not by the packed layout's padded channels
+           'trained_tensors': len(step.names), 'trained_parameters': int(sum((math.prod(step._conv_meta[k]) if k in step._conv_meta else step.master[k].numel()) for k in step.names)),
            'loss_first': first, 'loss_last': {k: float(v) for k, v in L.items()}}
-    if True:
+    if not args.no_roofline:
         # roofline of the step's dominant kernel, measured live: HIP events around every weight-gradient launch (conv_wgrad.hip) in a
         # separate instrumented repeat of the step (the events serialise nothing, but they are kept out of the timed region).  EVERY rank
         # runs the repeat -- the step's gradient exchange is collective --, rank 0 reports its own kernels.  In the timed step the weight
@@ -92,7 +95,7 @@ def main():
         # span the other stream's kernels, so the instrumented repeat keeps everything on one stream -- EXCLUSIVE durations
         from vpho_amd import ops
         ws_before = os.environ.get('VPHO_WGRAD_STREAM')
-        os.environ['VPHO_WGRAD_STREAM'] = '0'
+        os.environ['VPHO_WGRAD_STREAM'] = '0'                       # read by WgradStream.__enter__ on the Python side, once per step
         names = ('conv_wgrad_64x64', 'conv_wgrad_128x128')
         for nm in names:
             ops.prof_enable(nm, True)
@@ -111,11 +114,15 @@ def main():
         for nm, r in prof.items():
             if r['launches']:
                 blk[nm] = {'TFLOP/s': r['flops'] / r['total_ms'] / 1e9, 'frac': r['flops'] / r['total_ms'] / 1e9 / PEAK, 'launches_per_step': r['launches'] / n_prof,
-                           'kernel_ms_per_step': r['total_ms'] / n_prof, 'avg_launch_us': 1e3 * r['total_ms'] / r['launches'], 'flop_per_launch_avg': r['flops'] / r['launches']}
-        dom = max(blk, key=lambda k: blk[k]['kernel_ms_per_step'])
-        res['roofline'] = {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2>'}[dom]
+                           'kernel_ms_per_step': r['total_ms'] / n_prof, 'avg_launch_us': 1e3 * r['total_ms'] / r['launches'], 'flop_per_launch_avg': r['flops'] / r['launches'],
+                           'bytes_per_launch_avg': r.get('bytes', 0.0) / r['launches']}
+        dom = max(blk, key=lambda k: blk[k]['kernel_ms_per_step']) if blk else None
+        kname = {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64, 64, 2, 2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128, 128, 4, 2>'}
+        res['roofline'] = None if dom is None else {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2>'}[dom]
                            + ' (weight gradient dW = dY^T . im2col(x) as an implicit TN GEMM on fp32 MFMA)',
-                           'achieved': blk[dom]['TFLOP/s'], 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': blk[dom]['frac'], 'traffic': None,
+                           'achieved': blk[dom]['TFLOP/s'], 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': blk[dom]['frac'],
+                           'traffic': pmc_traffic(kname[dom]), 'traffic_source': pmc_traffic(kname[dom], source=True),
+                           'algorithmic_bytes_per_launch': blk[dom].get('bytes_per_launch_avg'),
                            'share_of_step': blk[dom]['kernel_ms_per_step'] / res['ms_per_step'],
                            'timing': 'HIP events around every launch on the launch stream, in an instrumented repeat of the step with the weight gradients kept on '
                                      'the main stream (exclusive durations; the timed steps overlap them with the rest of the backward)', 'classes': blk}
@@ -143,6 +150,26 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, source=False):
+    """HBM bytes per launch of `kernel` (launch-weighted over its instantiations' rows) from the newest committed rocprofv3 --pmc summary of
+    the training step (profiles/r0N_train_pmc_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, scripts/profile_round.sh PART=train); None when absent"""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rnd in ('r05', 'r04'):
+        path = os.path.join(root, 'profiles', f'{rnd}_train_pmc_hbm_traffic.json')
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except Exception:
+            continue
+        hit = {n: v for n, v in tab.items() if kernel.replace(' ', '') in n.replace(' ', '')}
+        if hit:
+            if source:
+                return os.path.relpath(path, root)
+            n = sum(v['launches'] for v in hit.values())
+            return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit.values()) / max(n, 1)
+    return None
 
 
 if __name__ == '__main__':

@@ -18,6 +18,9 @@ VPHO_STAMP_DECL(conv)
 
 namespace {
 
+#ifndef CONV_ABLATE
+#define CONV_ABLATE 0                          // timing experiments only (scripts/kernel_ablate.sh conv_igemm CONV_ABLATE 1 2 4): 1 no global loads, 2 no in-loop
+#endif                                         // barriers, 4 no LDS stores in conv_igemm_kernel -- wrong results, never in the product build
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 constexpr int GLDS_PRE_MAX = 512;     // most input channels of a pre-activation 1x1 convolution on the direct-to-LDS kernel
@@ -29,9 +32,10 @@ struct Geo {
     long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions; 0 for ordinary launches)
     int y_linear, r_linear, vec_epilogue;
     int uni;   // Cin % 32 == 0: wave-uniform taps (direct-to-LDS kernel)
-    int dbg;   // ablation switches for tuning (VPHO_CONV_DBG): 1 = skip global loads, 2 = skip in-loop barriers, 4 = skip LDS stores,
-               // 8 = residual tile requested in the epilogue (round 3) instead of in front of the last k stage, 16 = second stage requested
-               // after the first has landed (round 3) (A/B measurements, read per call)
+    int dbg;   // A/B switches whose results are bit-identical (VPHO_CONV_DBG, read per call): 8 = residual tile requested in the epilogue
+               // (round 3) instead of in front of the last k stage, 16 = second stage requested after the first has landed (round 3).
+               // The timing ablations that produce WRONG results (skip global loads / barriers / LDS stores) are compile-time only:
+               // -DCONV_ABLATE=<mask> in a diagnostic build (scripts/kernel_ablate.sh), never in the product library
 };
 
 // VEC = number of consecutive 16-byte pieces (of one tile row) a thread moves per pass: 2 halves the per-K-step address
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     const int nk = (g.K + BK - 1) / BK;
     auto step = [&](int kt, f32x4 (&ld_a)[A_LD * VEC], f32x4 (&ld_b)[B_LD * VEC], const f32x4 (&st_a)[A_LD * VEC], const f32x4 (&st_b)[B_LD * VEC]) {
         const int buf = kt & 1;
-        if (kt + 2 < nk && !(g.dbg & 1)) load_next(ld_a, ld_b);
+        if (kt + 2 < nk && !(CONV_ABLATE & 1)) load_next(ld_a, ld_b);
         const float* As = smem + buf * (BM + BN) * LDS_LD + (wm * (BM / WM) + li) * LDS_LD + 4 * lh;
         const float* Bs = smem + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * (BN / WN) + li) * LDS_LD + 4 * lh;
         // fragment double buffer: the LDS reads of k-group kk+1 are in flight while the MFMAs of group kk issue
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i][q], b[kk & 1][j][q], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk && !(g.dbg & 4)) store_tiles(buf ^ 1, st_a, st_b);
-        if (!(g.dbg & 2)) __syncthreads();
+        if (kt + 1 < nk && !(CONV_ABLATE & 4)) store_tiles(buf ^ 1, st_a, st_b);
+        if (!(CONV_ABLATE & 2)) __syncthreads();
     };
     load_next(ra0, rb0);
     store_tiles(0, ra0, rb0);
@@ -950,7 +954,7 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                       (!d.gate || al16(d.gate)) &&
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
     const char* dbg_env = getenv("VPHO_CONV_DBG");
-    g.dbg = dbg_env ? atoi(dbg_env) : 0;
+    g.dbg = dbg_env ? (atoi(dbg_env) & (8 | 16)) : 0;          // only the bit-identical A/B orders exist at run time
     if (d.x2) {
         // second input concatenated along the channels (projection shortcut merged into conv3): direct-to-LDS kernels, wave-uniform taps
         VPHO_REQUIRE(d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin % BK == 0 && d.Cin2 > 0 && d.Cin2 % BK == 0 && d.x2_ld % 4 == 0 &&

@@ -20,6 +20,9 @@ VPHO_STAMP_DECL(wino)
 
 namespace {
 
+#ifndef WINO8_ABLATE
+#define WINO8_ABLATE 0                         // the same for conv_winograd8_kernel (scripts/kernel_ablate.sh conv_winograd WINO8_ABLATE ...): 1 no transform / V
+#endif                                         // stores, 2 no patch loads, 4 no U fill, 16 no stage barrier -- wrong results, compile-time only
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh): 1 no patch loads, 2 no U fill, 4 no transform /
 #endif                                         // V stores, 8 no stage barrier, 16 no fragment reads -- wrong results, never in the product build
@@ -38,7 +41,6 @@ struct WinoArgs {
     const int* wins;                           // [N][5] = (first row, y0, x0, w, h) or NULL
     const int* tile_base;                      // [N + 1] first tile of every image; [N] = live tiles (vpho_winograd_window_tiles_i32)
     int scatter;                               // with wins: 1 = y is the ordinary (N,H,W,y_ld) map, window pixels written in place, the rest untouched
-    int abl;                                   // timing ablations of conv_winograd8_kernel (VPHO_WINO_ABL; wrong results): 1 no transform / V stores, 2 no patch loads, 4 no U fill, 8 no exchange epilogue, 16 no stage barrier
 };
 
 // tile t -> image n, tile coordinates (ty, tx) on the image's even grid; false past the last live tile
@@ -414,11 +416,11 @@ __global__ __launch_bounds__(512) void conv_winograd8_kernel(const WinoArgs a) {
         // transform phases FIRST consume their patches (landed two stages ago) and only then request U: vector-memory operations complete
         // in order, so a wait for a patch register behind a freshly issued fill would wait for the fill; the request phase issues the
         // fill first, so that its stage-end wait (vmcnt(16)) covers the fill and lets the 16 patch loads fly
-        const bool loads = ph == 1 && (kc + 3) / 2 < nss && !(a.abl & 2);
-        if (ph == 3) { if ((kc + 1) / 2 < nss && !(a.abl & 1)) produce(0, buf ^ 1); }            // V of stage kc + 1 = 2 ss
-        else if (ph == 0 && !(a.abl & 1)) produce(1, buf ^ 1);                                    // V of stage kc + 1 = 2 ss + 1
+        const bool loads = ph == 1 && (kc + 3) / 2 < nss && !(WINO8_ABLATE & 2);
+        if (ph == 3) { if ((kc + 1) / 2 < nss && !(WINO8_ABLATE & 1)) produce(0, buf ^ 1); }            // V of stage kc + 1 = 2 ss
+        else if (ph == 0 && !(WINO8_ABLATE & 1)) produce(1, buf ^ 1);                                    // V of stage kc + 1 = 2 ss + 1
         __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nst && !(a.abl & 4)) fill_u(buf ^ 1, kc + 1);
+        if (kc + 1 < nst && !(WINO8_ABLATE & 4)) fill_u(buf ^ 1, kc + 1);
         if (loads) load_patch((kc + 3) / 2);
         __builtin_amdgcn_sched_barrier(0);
         const float* V = smem + buf * W_STAGE + ((fh * 8) * 64 + wt * 32 + li) * WK + ((lh ^ fsw) * 4);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(512) void conv_winograd8_kernel(const WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // U of the next stage must have landed; patches requested in this stage (after the fills) may stay in flight
-        if (a.abl & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (WINO8_ABLATE & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         else if (loads) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
         else VPHO_SYNC_LDS_DMA();
     }
@@ -624,7 +626,6 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_ld = x_ld; a.Cout = Cout; a.y_ld = y_ld;
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
     a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope; a.scatter = scatter;
-    { const char* ab = getenv("VPHO_WINO_ABL"); a.abl = ab ? atoi(ab) : 0; }
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {

@@ -13,6 +13,7 @@
 // The RK stage algebra (fp64 state, fp32 stage derivatives exactly as numpy stores them), the error norm and the dense
 // output run as elementwise / two-pass-reduction kernels; only the 8-byte error norm crosses PCIe per attempted step.
 #include "common.h"
+#include <type_traits>
 #include "../../include/vpho_hip.h"
 #include <cmath>
 #include <cstdlib>
@@ -455,7 +456,7 @@ struct HeadArgs {
 // A launch whose tile count is not a multiple of the chip's workgroup slots ends in a round that keeps a few CUs busy for a whole
 // tile time (6 400 rows x 32 heads = 1 600 tiles on 512 slots: 3.125 rounds cost 4).  The launch therefore cuts the rows beyond the
 // last full round into quarter tiles that all CUs share: 1 536 ordinary tiles = 3 rounds exactly, then 256 tail tiles, one per CU.
-template <int TI>
+template <int TI, bool CB>
 __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
     constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
     constexpr int STAGE = (256 + 128) * HB_K;
@@ -472,12 +473,26 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     const int kq = (lane % CPR) ^ ((lrow >> SW_SHIFT) & (CPR - 1));      // logical 16-B chunk this lane fetches
     const float* Wg = a.w1p + (long long)n * 256 * 256;
 
+    // Per-image terms of the epilogue (cimg: the encoding's share of the first layer, one 256-vector per image and head).  A tile's rows
+    // span a few images (128 rows of sample_num 100: at most 3): their vectors are staged in LDS next to the epilogue table, slot stride
+    // 257 floats so that the lanes of a half-wave -- same hidden unit, neighbouring images -- hit different banks.  Round 4 read them
+    // with 64 global loads per lane in the epilogue: 16 waves x 64 dword loads through the CU's one texture-address path = ~7 us of a
+    // 62-us tile life with the matrix pipe idle (profiles/r05_inkernel_clock.txt: epilogue 13.6 us median).  Same values, same order of
+    // additions: bit-identical.  CB = sample_num >= 64 (chosen by the host: a 128-row tile then spans at most 3 images); smaller
+    // sample_num (a 128-row tile of sample_num 4 spans 33 images -- and is a tiny launch) keeps the global loads.
+    constexpr int CB_LD = 257;
+    float* Cb = Eb + 256 * 4;                                       // [3][CB_LD] <= the 1024 floats behind the table
+    const int img0 = r0 / a.S;
+    const int img_last = (min(r0 + ROWS, a.R) - 1) / a.S;
     if (tid < 256) {   // epilogue table
         f32x4 e;
         e[0] = a.ct[n * 256 + tid];
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(a.w2 + (long long)(n * 256 + tid) * 4);
         e[1] = w2[0]; e[2] = w2[1]; e[3] = w2[2];
         *reinterpret_cast<f32x4*>(Eb + tid * 4) = e;
+    } else if (CB) {
+        const int j = tid - 256;
+        for (int sl = 0; sl <= img_last - img0; ++sl) Cb[sl * CB_LD + j] = a.cimg[(long long)(img0 + sl) * a.NH + n * 256 + j];
     }
 
     // tiles through buffer resources: per-lane byte offsets are loop constants, the k advance is the instruction's scalar offset;
@@ -552,6 +567,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     const int row = r0 + lrow_out;
     const bool live = row < a.R;
     const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + n * 256;
+    const float* cbl = Cb + (live ? row / a.S - img0 : 0) * CB_LD;  // this lane's image in the LDS copy (CB)
     // The 256 hidden units of a row are summed as EIGHT partial sums of 32 (hidden 32 p .. 32 p + 31 = one 32 x 32 accumulator tile: two
     // 16-term lane sums added), combined in ascending p -- in an ordinary 128-row tile (a wave holds four of the eight) exactly as in a
     // 32-row tail tile (a wave holds one).  Round 3 let an ordinary tile sum 2 x 128: which rows of a launch fall into tail tiles
@@ -565,7 +581,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         for (int e = 0; e < 16; ++e) {
             const int j = 32 * TI * hh + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
             const f32x4 t = *reinterpret_cast<const f32x4*>(Eb + j * 4);
-            float h = acc[i][e] + cim[j] + t[0];
+            float h = acc[i][e] + (CB ? cbl[j] : cim[j]) + t[0];
             h = h > 0.f ? h : 0.f;
             o0 += h * t[1]; o1 += h * t[2]; o2 += h * t[3];
         }
@@ -610,6 +626,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     VPHO_STAMP_WRITE(head, blockIdx.x);
 }
 
+template <bool CB>
 __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     // [2] stages x ([256][HB_K] weights | [128][HB_K] activations), unpadded rows filled by global_load_lds with the 16-B chunk
@@ -619,10 +636,10 @@ __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     // tail tiles, 231 us -- a tail tile is bound by its chain of 16 barrier-separated weight stages, not by where the weights are)
     const int b = blockIdx.x, n_full = a.nheads * a.full_tiles;
     if (b < n_full) {
-        head_tile<4>(a, smem, b / a.full_tiles, (b % a.full_tiles) * 128);
+        head_tile<4, CB>(a, smem, b / a.full_tiles, (b % a.full_tiles) * 128);
     } else {
         const int q = b - n_full;
-        head_tile<1>(a, smem, q / a.tail_tiles, a.full_tiles * 128 + (q % a.tail_tiles) * 32);
+        head_tile<1, CB>(a, smem, q / a.tail_tiles, a.full_tiles * 128 + (q % a.tail_tiles) * 32);
     }
 }
 
@@ -1225,7 +1242,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_opt_in = true;
     }
     // Tile plan: 128-row tiles; when the last round of the launch would be less than half full, the rows beyond the last full round
@@ -1264,7 +1282,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     }
     {
         vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
-        hipLaunchKernelGGL(score_head_kernel, dim3((unsigned)(nheads * (a.full_tiles + a.tail_tiles))), dim3(512), lds, c.s, a);
+        // per-image epilogue terms from an LDS copy when a 128-row tile spans at most 3 images (sample_num >= 64; VPHO_HEAD_CB=0: global loads, A/B aid -- same bits)
+        const char* cb_s = getenv("VPHO_HEAD_CB");
+        const int cb_env = cb_s ? atoi(cb_s) : 1;
+        const dim3 grid((unsigned)(nheads * (a.full_tiles + a.tail_tiles)));
+        if (c.S >= 64 && cb_env) hipLaunchKernelGGL(score_head_kernel<true>, grid, dim3(512), lds, c.s, a);
+        else                     hipLaunchKernelGGL(score_head_kernel<false>, grid, dim3(512), lds, c.s, a);
     }
     return vpho::check_launch("score_head_kernel");
 }
