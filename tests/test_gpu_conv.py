@@ -269,3 +269,61 @@ def test_second_input_of_a_1x1_convolution_is_the_merged_projection_shortcut(N, 
     r = ops.conv2d_nhwc(xg, pack_conv(wd).cuda(), bd.cuda(), stride=stride2)
     two = ops.conv2d_nhwc(yg, pack_conv(w3).cuda(), b3.cuda(), res=r, out_slope=0.01)
     assert float((got - two).abs().max()) <= 4e-6 * max(1.0, float(two.abs().max()))
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,res,bias,x2', [
+    (64, 32, 128, 512, True, True, 0),       # 2048 tiles on 512 slots: four tiles per workgroup, residual (conv3 of a bottleneck)
+    (64, 16, 256, 1024, True, True, 0),      # two tiles per workgroup
+    (64, 32, 128, 512, False, True, 256),    # merged projection shortcut (second input, strided)
+    (33, 31, 64, 256, True, False, 0),       # ragged pixel tail (31713 pixels), no bias, two k stages
+    (40, 32, 32, 256, False, False, 0),      # ONE k stage per tile
+    (17, 16, 96, 128, True, True, 0),        # a single column of tiles, three k stages, ragged tail, at most one round (VPHO_CONV_PERS=2)
+    (64, 32, 512, 128, False, True, 0),      # exactly one round of 512 tiles
+])
+def test_persistent_multi_tile_convolution_is_bit_identical_to_the_one_tile_kernel(N, H, Cin, Cout, res, bias, x2):
+    """round 5 (conv_igemm_pers_kernel): a workgroup walks several 128 x 128 tiles, requests the next tile's first two k stages behind
+    the current tile's last one and runs its epilogue through a wave-private LDS slice while they land; stores / residual loads through
+    buffer resources.  The k order of every output element is conv_igemm_glds_kernel's: VPHO_CONV_PERS=0 (round 4's kernel) and = 2
+    (the persistent kernel for every launch it serves) must agree bit for bit; and both agree with torch."""
+    import os
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + Cin)
+    x = torch.randn(N, H, H, Cin, generator=g).cuda()
+    kw = {}
+    K = Cin
+    if x2:
+        kw = dict(x2=torch.randn(N, 2 * H, 2 * H, x2, generator=g).cuda(), stride2=2)
+        K = Cin + x2
+    w = (torch.randn(Cout, K, generator=g) * (1.0 / K) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() if bias else None
+    r = torch.randn(N, H, H, Cout, generator=g).cuda() if res else None
+    out = {}
+    for mode in ('0', '2'):
+        os.environ['VPHO_CONV_PERS'] = mode
+        try:
+            out[mode] = ops.conv2d_nhwc(x, w, b, out_slope=0.01, res=r, **kw).clone()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('VPHO_CONV_PERS', None)
+    assert torch.isfinite(out['2']).all() and float(out['2'].abs().max()) > 0
+    assert torch.equal(out['0'], out['2']), float((out['0'] - out['2']).abs().max())
+    # against an fp64 product of the same operands
+    xs = x.reshape(-1, Cin).double()
+    ref = xs @ w[:, :Cin].double().t()
+    if x2:
+        ref = ref + kw['x2'][:, ::2, ::2][:, :H, :H].reshape(-1, x2).double() @ w[:, Cin:].double().t()
+    if bias:
+        ref = ref + b.double()
+    if res:
+        ref = ref + r.reshape(-1, Cout).double()
+    ref = torch.where(ref > 0, ref, 0.01 * ref)
+    assert float((out['2'].reshape(-1, Cout).double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # into a channel slice of a wider buffer (y_sx != Cout: concatenation targets), written in place
+    wide = torch.full((N, H, H, Cout + 64), 7.0, device='cuda')
+    os.environ['VPHO_CONV_PERS'] = '2'
+    try:
+        ld = Cout + 64
+        ops.conv2d_nhwc(x, w, b, out_slope=0.01, res=r, out_view=(wide, H * H * ld, H * ld, ld, 32), **kw)
+    finally:
+        os.environ.pop('VPHO_CONV_PERS', None)
+    assert torch.equal(wide[..., 32:32 + Cout], out['0']) and float(wide[..., :32].min()) == 7.0 and float(wide[..., 32 + Cout:].max()) == 7.0

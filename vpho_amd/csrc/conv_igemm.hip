@@ -13,6 +13,7 @@
 #include "common.h"
 #include "../../include/vpho_hip.h"
 #include <cstdlib>
+#include <algorithm>
 
 VPHO_STAMP_DECL(conv)
 
@@ -680,6 +681,246 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Persistent multi-tile variant of the direct-to-LDS kernel for 1x1 convolutions whose launch has MORE tiles than the chip has workgroup
+// slots (round 5).  The in-kernel stamps of profiles/r05_inkernel_clock.txt say where a short-K tile's life goes: 128 -> 512 on 32 x 32
+// maps (4 k stages): entry -> first fills requested 2.1 us, first fill wait 2.0, main loop 16.1, epilogue 5.9, slot turnover 1.1 -- and for
+// 45 % of the launch a CU has ONE workgroup in its main loop, for 22 % none.  Here a workgroup walks its share of the tiles and
+//   * requests the NEXT tile's first two k stages right behind the current tile's last stage, so they land under the epilogue
+//     (both stage buffers are free then: the epilogue no longer stages through them);
+//   * stages its accumulators through a WAVE-PRIVATE 1 KB LDS slice (8 rows x 32 columns per pass, LDS operations of one wave execute
+//     in order): no workgroup barrier in the epilogue, whole 128-byte lines on 16-byte accesses; the bias of a tile arrives in LDS with
+//     the tile's first stage (one more LDS-DMA per wave), so the epilogue consumes no register-returning load that was issued behind
+//     the next tile's fills (its wait would wait for them as well);
+//   * stores / residual loads go through buffer resources with an out-of-range offset for dead items: every wave issues EXACTLY NIT
+//     stores per tile, so the counted wait for the next tile's first stage (vmcnt = the younger operations) is exact.
+// The k order of every output element is that of conv_igemm_glds_kernel: bit-identical results (tests/test_gpu_conv.py).
+// Served: Cin % 32 == 0, 1x1, unpadded, 16-byte epilogue, optional bias / residual / second input (x2); no pixel list, no up-sampled
+// residual, no gate, no splits, no prologue -- everything else stays on conv_igemm_glds_kernel.
+#define VPHO_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const Geo g) {
+    constexpr int NT = 64 * WM * WN, NW = WM * WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int ROWS = NT / 8;
+    constexpr int A_LD = BM / ROWS, B_LD = BN / ROWS, NF = A_LD + B_LD;      // LDS-DMA instructions per stage and wave
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && ROWS % 16 == 0 && BN / WN <= 64, "tile/wave layout");
+    constexpr int TILE = (BM + BN) * BK;
+    constexpr int EPI = 8 * 32;                       // floats of a wave's staging slice: 8 rows x 32 columns (one pass)
+    constexpr int NIT = TM * 4 * TN;                  // passes = epilogue items (= stores) per lane and tile
+    // [2] stages | [NW] staging slices | [2][BN] bias of the current / the next tile
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE + NW * EPI + 2 * BN];
+    VPHO_STAMP_INIT();
+
+    const vpho_conv_desc& d = g.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = wave * 8 + (lane >> 3);
+    const int kq = (lane & 7) ^ ((lrow >> 1) & 7);
+    const int ohw = d.OH * d.OW;
+    const __amdgpu_buffer_rsrc_t xu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x2 ? d.x2 : d.x), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(d.y, 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res ? d.res : d.y), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : d.w), 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // ---- tile schedule: XCD x (hardware workgroup b runs on XCD b % 8) owns the contiguous run [x * per_xcd, (x + 1) * per_xcd) of the
+    // logical tiles (consecutive tiles = the N-tiles of one M-tile: its A rows stay in that XCD's L2); slot s of the XCD's gridDim.x / 8
+    // workgroups takes tiles s, s + nslot, s + 2 nslot, ... of the run
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3, per_xcd = (g.ntiles + 7) >> 3;
+    int lt = blockIdx.x >> 3;
+    auto tile_at = [&](int t, int& m0, int& n0) -> bool {
+        const int lb = xcd * per_xcd + t;
+        if (t >= per_xcd || lb >= g.ntiles) return false;
+        const int tile_m = lb / g.tiles_n, tile_n = lb - tile_m * g.tiles_n;
+        m0 = tile_m * BM; n0 = tile_n * BN;
+        return true;
+    };
+    int m0, n0;
+    if (!tile_at(lt, m0, n0)) return;
+
+    int u_voff[A_LD], u_boff[B_LD], u_voff2[A_LD], bias_off;
+    auto setup = [&](int m0_, int n0_) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int m = m0_ + lrow + ROWS * j;
+            u_voff[j] = -1; u_voff2[j] = -1;
+            if (m < g.M) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int oy = rem / d.OW, ox = rem - oy * d.OW;
+                u_voff[j] = (int)((((long long)(n * d.H + oy * d.stride) * d.W + ox * d.stride) * d.x_ld) * 4 + 16 * kq);
+                if (d.x2) u_voff2[j] = (int)((((long long)(n * d.H2 + oy * d.stride2) * d.W2 + ox * d.stride2) * d.x2_ld) * 4 + 16 * kq);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int n = n0_ + lrow + ROWS * j;
+            u_boff[j] = n < d.Cout ? (int)(((long long)n * g.w_ld + 4 * kq) * 4) : -1;
+        }
+        const int bc = n0_ + wn * (BN / WN) + lane;                // this lane's bias element of the wave's BN / WN columns
+        bias_off = (d.bias && lane < BN / WN && bc < d.Cout) ? bc * 4 : -1;
+    };
+    // stage fill; stage 0 of a tile also brings the tile's bias (one dword per lane, straight into LDS: out-of-range = zeros) --
+    // NF + 1 operations; the waves of one column block write the same values to the same slots
+    auto fill = [&](int buf, int kt, int tp) {
+        float* As = smem + buf * TILE + wave * 8 * BK;
+        float* Bs = smem + buf * TILE + BM * BK + wave * 8 * BK;
+        if (d.x2 && kt * BK >= d.Cin) {
+            const int c2 = (kt * BK - d.Cin) * 4;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int vo = u_voff2[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x2r, (lds_ptr)(As + ROWS * j * BK), 16, vo, c2, 0, 0);
+            }
+        } else {
+            const int c1 = kt * BK * 4;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int vo = u_voff[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xu, (lds_ptr)(As + ROWS * j * BK), 16, vo, c1, 0, 0);
+            }
+        }
+        const int koff = kt * BK * 4;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int bo = u_boff[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Bs + ROWS * j * BK), 16, bo, koff, 0, 0);
+        }
+        if (kt == 0) {
+            const int bo = bias_off;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_ptr)(smem + 2 * TILE + NW * EPI + tp * BN + wn * (BN / WN)), 4, bo, 0, 0, 0);
+        }
+    };
+
+    const int nk = (g.K + BK - 1) / BK;
+    const int sw = (li >> 1) & 7;
+    f32x16 acc[TM][TN];
+    auto compute = [&](int kt) {
+        const int buf = kt & 1;
+        const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * BK;
+        const float* Bs = smem + buf * TILE + BM * BK + (wn * (BN / WN) + li) * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int ch = ((2 * kk + lh) ^ sw) * 4;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + ch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + ch);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- epilogue items of this lane: pass (i, gq, j) moves rows i * 32 + 8 gq .. + 7, columns 32 j .. + 31 of the wave's block; the
+    // lane's 16-byte piece of a pass = row lane / 8, columns 4 (lane % 8) .. + 3
+    float* Cw = smem + 2 * TILE + wave * EPI;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    auto item_off = [&](int m0_, int n0_, int i, int gq, int j, int& yo, int& ro) {
+        const int row = m0_ + wm * (BM / WM) + i * 32 + 8 * gq + er, col = n0_ + wn * (BN / WN) + j * 32 + ec;
+        yo = ro = -1;                                               // out of the buffer's range: loads return zeros, stores are dropped
+        if (row < g.M && col < d.Cout) {
+            long long y_, r_;
+            if (g.y_linear && g.r_linear) { y_ = (long long)row * d.y_sx; r_ = (long long)row * d.r_sx; }
+            else {
+                const int n = row / ohw, rem = row - n * ohw;
+                const int oy = rem / d.OW, ox = rem - oy * d.OW;
+                y_ = n * d.y_sn + oy * d.y_sy + ox * d.y_sx; r_ = n * d.r_sn + oy * d.r_sy + ox * d.r_sx;
+            }
+            yo = (int)((y_ + col) * 4);
+            if (d.res) ro = (int)((r_ + col) * 4);
+        }
+    };
+
+    int tp = 0;                                                     // bias slot of the current tile
+    setup(m0, n0);
+    fill(0, 0, tp);
+    if (nk > 1) fill(1, 1, tp);
+    VPHO_STAMP_AT(1);
+    bool first = true;
+    while (true) {
+        // ---- the tile's first stage (and its bias) has landed?  Operations complete in issue order; younger than stage 0 are stage 1
+        // (NF) and, from the second tile on, the previous tile's NIT stores
+        if (nk > 1) { if (first) VPHO_WAIT_VM(NF); else VPHO_WAIT_VM(NF + NIT); }
+        else        { if (first) VPHO_WAIT_VM(0);  else VPHO_WAIT_VM(NIT); }
+        __syncthreads();
+        if (first) VPHO_STAMP_AT(2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            if (kt > 0) fill((kt & 1) ^ 1, kt + 1, tp);             // stage 1 is already on its way
+            compute(kt);
+            VPHO_SYNC_LDS_DMA();
+        }
+        // ---- last stage: the residual tile is requested here and lands under this stage's matrix work
+        f32x4 rv[NIT];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int yo, ro;
+                    item_off(m0, n0, i, gq, j, yo, ro);
+                    rv[(i * 4 + gq) * TN + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 0, 0));
+                }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(nk - 1);
+        VPHO_SYNC_LDS_DMA();                                        // every wave is done with both stage buffers; the residual has landed
+        // (the compiler does not see the wait inside the macro: a use of the residual registers HERE makes it place its own wait for them
+        // in front of the next tile's fills instead of in the epilogue, where it would wait for those fills too)
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) asm volatile("" :: "v"(rv[k]));
+        if (first) VPHO_STAMP_AT(3);
+        // ---- next tile: its first two stages are requested BEFORE this tile's epilogue
+        const int em0 = m0, en0 = n0, etp = tp;
+        lt += nslot;
+        const bool more = tile_at(lt, m0, n0);
+        if (more) {
+            tp ^= 1;
+            setup(m0, n0);
+            fill(0, 0, tp);
+            if (nk > 1) fill(1, 1, tp);
+        }
+        // ---- epilogue through the wave's own LDS slice: no workgroup barrier (the LDS operations of one wave execute in order)
+        const float* Bq = smem + 2 * TILE + NW * EPI + etp * BN + wn * (BN / WN) + ec;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) Cw[(e4 + 4 * lh) * 32 + li] = acc[i][j][4 * gq + e4];
+                    int yo, ro;
+                    item_off(em0, en0, i, gq, j, yo, ro);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Cw + er * 32 + ec);
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(Bq + j * 32);
+                    const f32x4 r = rv[(i * 4 + gq) * TN + j];
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float t = v[k] + bq[k] + r[k]; o[k] = t > 0.f ? t : t * d.out_slope; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yr, yo, 0, 0);
+                }
+        if (first) { VPHO_STAMP_AT(4); }
+        first = false;
+        if (!more) break;
+    }
+    VPHO_STAMP_WRITE(conv, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Opt-in split-bf16 variant of the direct-to-LDS kernel (vpho_conv_desc.w_planes / plane_terms; VPHO_CONV_MFMA=bf16x6|bf16x9 in the
 // Python plan; NOT the default -- see csrc/score_ode.hip::head_tile_split for the arithmetic and tests/test_gpu_split_head.py /
 // test_gpu_conv.py for the error study).  Weights arrive as three bf16 planes [3][Cout][K] that sum to the fp32 weights exactly;
@@ -1027,6 +1268,35 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                 break;
         }
         return vpho::check_launch("conv_igemm_split_kernel");
+    }
+    // persistent multi-tile kernel (round 5): 1x1 launches of the 128x128 class with more tiles than workgroup slots (two 80-KB workgroups
+    // per CU).  VPHO_CONV_PERS: 0 = never (round 4's kernel, A/B aid -- same bits), 1 = default, 2 = also launches of at most one round
+    {
+        const char* pe = getenv("VPHO_CONV_PERS");
+        const int pers = pe ? atoi(pe) : 1;
+        static int slots_of[64] = {0};
+        int dev = 0;
+        VPHO_HIP(hipGetDevice(&dev));
+        int& slots = slots_of[dev & 63];
+        if (!slots) {
+            hipDeviceProp_t prop;
+            VPHO_HIP(hipGetDeviceProperties(&prop, dev));
+            slots = 2 * prop.multiProcessorCount;
+        }
+        const double y_extent = 4.0 * ((double)(d.N - 1) * d.y_sn + (double)(d.OH - 1) * d.y_sy + (double)(d.OW - 1) * d.y_sx + d.Cout);
+        const double r_extent = d.res ? 4.0 * ((double)(d.N - 1) * d.r_sn + (double)(d.OH - 1) * d.r_sy + (double)(d.OW - 1) * d.r_sx + d.Cout) : 0.0;
+        const bool simple = d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0;
+        const bool ok = pers && variant == 1288 && glds && !pre_on_read && d.in_scale == nullptr && g.uni && simple && g.vec_epilogue && !d.row_map && !d.res_up &&
+                        !d.gate && splits == 1 && y_extent < 3.9e9 && r_extent < 3.9e9 && d.y_sn >= 0 && d.y_sy >= 0 && d.y_sx >= 0 &&
+                        (!d.x2 || 4.0 * d.N * d.H2 * d.W2 * (double)d.x2_ld < 3.9e9);
+        if (ok && (big_tiles > slots || pers >= 2)) {
+            vpho::ProfScope prof(vpho::PROF_CONV128, s, flops, bytes);
+            g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (d.Cout + 127) / 128;
+            g.ntiles = g.tiles_m * g.tiles_n;
+            const int grid = (int)std::min<long long>((g.ntiles + 7) / 8 * 8, slots / 8 * 8);
+            hipLaunchKernelGGL((conv_igemm_pers_kernel<128, 128, 4, 2>), dim3(grid), dim3(512), 0, s, g);
+            return vpho::check_launch("conv_igemm_pers_kernel");
+        }
     }
     switch (variant) {
         case 128:  launch(conv_igemm_kernel<128, 128, 2, 2, 1>, 128, 128, 256, vpho::PROF_CONV128); break;
