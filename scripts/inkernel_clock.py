@@ -46,6 +46,8 @@ def timeline(b, clock_ghz):
     cyc_us = 1e-3 / clock_ghz                                       # microseconds per shader cycle
     ph = {'entry -> first fills requested': (t[:, 1] - t[:, 0]) * cyc_us, 'first fill wait': (t[:, 2] - t[:, 1]) * cyc_us,
           'main loop': (t[:, 3] - t[:, 2]) * cyc_us, 'epilogue': (t[:, 4] - t[:, 3]) * cyc_us}
+    if (t[:, 5] > 0).all():                                         # an extra stamp inside the epilogue (score head: partial sums done, in front of the barrier)
+        ph['epilogue up to its stamp'] = (t[:, 5] - t[:, 3]) * cyc_us
     r0, r1 = b[:, 6].astype(np.int64), b[:, 7].astype(np.int64)
     rb = b[:, 9].astype(np.int64)
     re = rb + (b[:, 8] >> np.uint64(32)).astype(np.int64)
@@ -120,11 +122,12 @@ def main():
     if os.path.exists(exe):
         print(subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout.strip(), flush=True)
     # --- conv_igemm_glds_kernel<128,128,4,2,false>: three layers of the predict step
-    for (N, H, Cin, Cout, res) in ((64, 32, 512, 128, False), (64, 16, 1024, 256, False), (64, 32, 128, 512, True)):
+    for (N, H, Cin, Cout, res, pers) in ((64, 32, 512, 128, False, '0'), (64, 16, 1024, 256, False, '0'), (64, 32, 128, 512, True, '0'), (64, 32, 128, 512, True, '1'), (64, 16, 256, 1024, True, '1')):
+        os.environ['VPHO_CONV_PERS'] = pers
         x, w, b = rnd(N, H, H, Cin), rnd(Cout, Cin) * 0.05, rnd(Cout)
         r = rnd(N, H, H, Cout) if res else None
         tiles = (N * H * H // 128) * (Cout // 128)
-        run(f'conv_igemm_glds_kernel<128,128,4,2,false>: 1x1 {Cin} -> {Cout} on {N} x {H} x {H}{" + residual" if res else ""} ({Cin // 32} k stages per tile, {tiles} tiles)',
+        run(f'{"conv_igemm_pers_kernel<128,128,4,2> (stamps [1]..[4]: the FIRST tile of a workgroup; life: all its tiles)" if pers == "1" else "conv_igemm_glds_kernel<128,128,4,2,false>"}: 1x1 {Cin} -> {Cout} on {N} x {H} x {H}{" + residual" if res else ""} ({Cin // 32} k stages per tile, {tiles} tiles)',
             'conv', lambda: ops.conv2d_nhwc(x, w, b, out_slope=0.01, res=r), 2.0 * N * H * H * Cin * Cout, min(tiles, 65536))
     # --- conv_winograd_kernel
     for (N, H, Cc) in ((64, 64, 256), (64, 32, 128), (64, 16, 256)):

@@ -592,6 +592,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         }
         __builtin_amdgcn_sched_barrier(0);                          // one accumulator tile at a time: the four chains interleaved cost 130 more registers
     }
+    VPHO_STAMP_AT(5);
     __syncthreads();
     if (tid < ROWS) {
         const int orow = r0 + tid;
