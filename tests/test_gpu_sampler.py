@@ -56,23 +56,42 @@ def test_register_ring_pose_encoder_is_bit_identical_to_the_lds_ring_kernel(nets
 
 
 @pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
-@pytest.mark.parametrize('bs,S', [(64, 100), (5, 64), (3, 2129), (2, 600)])
-def test_score_head_per_image_terms_from_lds_are_bit_identical_to_the_global_loads(nets, name, D, bs, S):
-    """round 5: the epilogue's per-image terms (cimg) come from an LDS copy of the <= 3 images a 128-row tile spans (sample_num >= 64)
-    instead of 64 global loads per lane; VPHO_HEAD_CB=0 keeps the global loads.  Same values, same order of additions: every score
-    bit-identical -- README batch (tiles straddling two and three images, tail tiles), sample_num 64 (the smallest that takes the LDS
-    path: 3 images per tile), ragged last tiles."""
+@pytest.mark.parametrize('bs,S', [(64, 100), (5, 64), (3, 2129), (2, 600), (7, 40)])
+def test_persistent_score_head_is_bit_identical_to_the_one_tile_kernels(nets, name, D, bs, S):
+    """round 5: (a) the epilogue's per-image terms (cimg) come from an LDS copy of the <= 3 images a 128-row tile spans (sample_num >= 64)
+    instead of 64 global loads per lane (VPHO_HEAD_CB=0 keeps the global loads); (b) score_head_pers_kernel: a workgroup walks several
+    tiles, requests the next tile's first stages and tables behind the current tile's last barrier, one output per thread
+    (VPHO_HEAD_PERS=0: one workgroup per tile).  Same values, same order of additions: every score bit-identical -- README batch (tiles
+    straddling two and three images, tail tiles, 3.1 tiles per workgroup), sample_num 64 (the smallest that takes the LDS path), ragged
+    last tiles, sample_num 40 (global loads, one-tile kernel whatever the switches); and a whole ODE solve (controller mode)."""
     import os
     feat, x = seeded((bs, 1024), 70, 0.3).cuda(), seeded((bs * S, D), 71, 1.5).cuda()
     res = {}
-    for cb in ('0', '1'):
-        os.environ['VPHO_HEAD_CB'] = cb
+    for key, env in (('base', dict(VPHO_HEAD_CB='0', VPHO_HEAD_PERS='0')), ('cb', dict(VPHO_HEAD_PERS='0')), ('pers', {})):
+        os.environ.update(env)
         try:
-            res[cb] = nets[name].score(feat, x, 0.3, S).clone()
+            res[key] = nets[name].score(feat, x, 0.3, S).clone()
+            torch.cuda.synchronize()
         finally:
-            os.environ.pop('VPHO_HEAD_CB', None)
-    assert torch.isfinite(res['1']).all() and float(res['1'].abs().max()) > 0
-    assert torch.equal(res['0'], res['1'])
+            for k in env:
+                os.environ.pop(k, None)
+    assert torch.isfinite(res['pers']).all() and float(res['pers'].abs().max()) > 0
+    assert torch.equal(res['base'], res['cb']) and torch.equal(res['base'], res['pers'])
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_persistent_score_head_inside_an_ode_solve(nets, name, D):
+    import os
+    init, feat8 = seeded((8 * 100, D), 72, 20.0).cuda(), seeded((8, 1024), 73, 0.3).cuda()
+    res = {}
+    for pers in ('0', '1'):
+        os.environ['VPHO_HEAD_PERS'] = pers
+        try:
+            xs, xf, st = nets[name].sample(feat8, init, 100, 0.65, 12, xs_f64=True)
+            res[pers] = (xs.clone(), xf.clone(), st['nfev'])
+        finally:
+            os.environ.pop('VPHO_HEAD_PERS', None)
+    assert res['0'][2] == res['1'][2] and torch.equal(res['0'][0], res['1'][0]) and torch.equal(res['0'][1], res['1'][1])
 
 
 def test_score_tail_tiles_match_oracle(sd, nets):

@@ -37,6 +37,11 @@ struct ProfScope {
 // OWN outstanding fills.  __syncthreads() alone is not enough: the compiler places the vmcnt wait of an LDS-DMA by what the issuing
 // wave itself reads afterwards and may leave a barrier with the fill still in flight -- other waves then read the tile too early.
 #define VPHO_SYNC_LDS_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+// Workgroup barrier WITHOUT __syncthreads()' memory fence, for the persistent kernels: with global stores of the previous tile (or the next
+// tile's LDS-DMA fills) still in flight the fence makes the compiler put `s_waitcnt vmcnt(0)` in front of the barrier -- the wait the
+// counted vmcnt is there to avoid.  What the barrier has to publish here is LDS data only: this wave's LDS operations are complete
+// (lgkmcnt(0)), LDS-DMA tiles are covered by the caller's own counted vmcnt wait.  Global memory is NOT ordered by it.
+#define VPHO_BARRIER_LDS_ONLY() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // F.interpolate(mode='bilinear', align_corners=False): src = max((dst+0.5)*scale-0.5, 0), scale = in/out
 __device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         // (NF) and, from the second tile on, the previous tile's NIT stores
         if (nk > 1) { if (first) VPHO_WAIT_VM(NF); else VPHO_WAIT_VM(NF + NIT); }
         else        { if (first) VPHO_WAIT_VM(0);  else VPHO_WAIT_VM(NIT); }
-        __syncthreads();
+        VPHO_BARRIER_LDS_ONLY();                                    // (not __syncthreads(): its fence would wait for the previous tile's stores)
         if (first) VPHO_STAMP_AT(2);
 #pragma unroll
         for (int i = 0; i < TM; ++i)

@@ -644,6 +644,242 @@ __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------- persistent score head (round 5, default)
+// The in-kernel stamps of profiles/r05_inkernel_clock.txt: a 128-row tile lives 62 us -- entry 0.7, first fill wait 1.0, main loop 45,
+// epilogue 11 (partial sums 5.5, then a barrier and a combine that keeps 2 of the 8 waves busy for 5.7), slot turnover 0.8 -- and a CU has
+// two workgroups in their main loops for only 46 % of the launch.  Here a workgroup WALKS its tiles (b, b + grid, ...: 128-row tiles of
+// all heads first, then the 32-row tail tiles) and
+//   * requests the next tile's first two k stages -- and loads its epilogue tables into registers -- right behind the current tile's
+//     last barrier, so they land under the epilogue (the partial sums have an LDS region of their own: both stage buffers are free);
+//   * finishes a tile with ONE output per thread (384 threads instead of 128 x 3), written by a buffer store that every thread issues
+//     (an out-of-range offset for the idle ones): the counted wait for the next tile's first stage is exact;
+//   * counts NaNs in a register and adds them once per workgroup.
+// Arithmetic, k order, partial sums and their order are head_tile's: bit-identical scores (tests/test_gpu_sampler.py).
+#define VPHO_WAIT_VMH(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+template <bool CB>
+__global__ __launch_bounds__(512, 4) void score_head_pers_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    if (ctl_skip(a.ctl, a.ctl_mode)) return;
+    constexpr int STAGE = (256 + 128) * HB_K;
+    constexpr int CPR = HB_K / 4, RPW = 64 / CPR, RPP = 8 * RPW, SW_SHIFT = 2;
+    static_assert(HB_K == 16 && RPP == 128, "fill layout");
+    constexpr int NFW = 256 / RPP, NF = NFW + 1;                    // LDS-DMA instructions per stage and wave: weights + activations
+    constexpr int NK = 256 / HB_K, NKK = HB_K / 8;
+    constexpr int CB_LD = 257, B2_AT = 900;
+    float* Eb = smem + 2 * STAGE;                                    // [256][4] {ct, w2_0, w2_1, w2_2} of the tile's head
+    float* Cb = Eb + 256 * 4;                                        // [3][257] per-image terms of the tile's images | b2 of the head at [B2_AT..+2]
+    float* Ob = Cb + 1024;                                           // [8 parts][128 rows][4] partial outputs
+    VPHO_STAMP_INIT();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
+    const int n_full = a.nheads * a.full_tiles, total = n_full + a.nheads * a.tail_tiles, G = gridDim.x;
+    int b = blockIdx.x;
+    if (b >= total) return;
+    float inv_std = a.inv_std_den, coef = a.coef;
+    float* outp = a.out;
+    if (a.ctl && a.ctl_mode == 1) {
+        inv_std = a.ctl->inv_std[a.stage]; coef = a.ctl->coef[a.stage];
+        outp = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
+    }
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1p), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p2), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(outp, 0, 0xFFFFFFF0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int lrow = wave * RPW + lane / CPR;
+    const int kq = (lane % CPR) ^ ((lrow >> SW_SHIFT) & (CPR - 1));
+    int woff[NFW];
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) woff[j] = ((lrow + RPP * j) * 256 + 4 * kq) * 4;
+
+    // tile b -> head n, first row r0, rows (128 | 32)
+    auto tile_of = [&](int t, int& n, int& r0, int& rows) {
+        if (t < n_full) { n = t / a.full_tiles; r0 = (t - n * a.full_tiles) * 128; rows = 128; }
+        else { const int q = t - n_full; n = q / a.tail_tiles; r0 = a.full_tiles * 128 + (q - n * a.tail_tiles) * 32; rows = 32; }
+    };
+    int poff;                                                        // activation row of this lane in the tile being filled
+    auto set_poff = [&](int r0, int rows) {
+        const int r = r0 + lrow;
+        poff = (r < a.R && lrow < rows) ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
+    };
+    auto fill = [&](int buf, int kt, int n) {
+        float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
+        float* Ps = smem + buf * STAGE + 256 * HB_K + wave * RPW * HB_K;
+        const int koff = kt * HB_K * 4, wbase = n * (256 * 256 * 4) + koff;
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) {
+            const int wo = woff[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Ws + RPP * j * HB_K), 16, wo, wbase, 0, 0);
+        }
+        const int po = poff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)Ps, 16, po, koff, 0, 0);
+    };
+    // epilogue tables of a tile, into one f32x4 per thread: threads 0..255 the head's row {ct, w2}, threads 256..511 column j = tid - 256 of
+    // the per-image terms of the (at most 3) images the tile spans, and b2 of the head in the first three of them
+    // (tq: the thread index as an OPAQUE per-call value -- everything derived from a visible threadIdx.x is loop-invariant over the tiles,
+    // gets hoisted out of the tile loop and spilled; a scratch reload is a vector-memory operation whose wait also waits for the fills)
+    // Branch-free: four dword loads per thread from addresses chosen by selects -- a branch per table would end in a join where the
+    // compiler waits for the loads, in front of the fills that have to be requested next
+    auto load_tables = [&](int n, int r0, int rows) -> f32x4 {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const bool lo = tq < 256;
+        const int j = lo ? tq : tq - 256;
+        const int img0 = r0 / a.S, nimg = (min(r0 + rows, a.R) - 1) / a.S - img0;            // images beyond the first
+        const float* w2r = a.w2 + (long long)(n * 256 + j) * 4;
+        const float* cm = a.cimg + (long long)img0 * a.NH + n * 256 + j;
+        const float* p0 = lo ? a.ct + n * 256 + j : cm;
+        const float* p1 = lo ? w2r + 0 : cm + (nimg >= 1 ? a.NH : 0);
+        const float* p2 = lo ? w2r + 1 : cm + (nimg >= 2 ? 2 * a.NH : 0);
+        const float* p3 = lo ? w2r + 2 : a.b2 + n * 3 + min(j, 2);
+        f32x4 v;
+        v[0] = *p0; v[1] = *p1; v[2] = *p2; v[3] = *p3;
+        return v;
+    };
+    auto store_tables = [&](const f32x4& v) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        if (tq < 256) *reinterpret_cast<f32x4*>(Eb + tq * 4) = v;
+        else {
+            const int j = tq - 256;
+            if (CB) { Cb[j] = v[0]; Cb[CB_LD + j] = v[1]; Cb[2 * CB_LD + j] = v[2]; }
+            if (j < 3) Cb[B2_AT + j] = v[3];
+        }
+    };
+
+    int n, r0, rows, nans = 0;
+    tile_of(b, n, r0, rows);
+    {
+        const f32x4 tv = load_tables(n, r0, rows);
+        set_poff(r0, rows);
+        fill(0, 0, n);
+        fill(1, 1, n);
+        store_tables(tv);
+    }
+    VPHO_STAMP_AT(1);
+    const int sw = (li >> SW_SHIFT) & (CPR - 1);
+    bool first = true;
+
+    // one tile: TI = 4 (128 rows: wave = row group rg x hidden half hh) or TI = 1 (32 rows: wave = hidden slice)
+    auto tile = [&](auto ti_tag) -> bool {
+        constexpr int TI = decltype(ti_tag)::value;
+        const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;
+        f32x16 acc[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        // ---- stage 0 of this tile (and, behind the barrier, its tables) has landed?  Younger than it: stage 1 (NF) and, from the
+        // second tile on, the previous tile's output store (1)
+        if (first) VPHO_WAIT_VMH(NF); else VPHO_WAIT_VMH(NF + 1);
+        VPHO_BARRIER_LDS_ONLY();                                    // (not __syncthreads(): its fence would wait for the previous tile's store)
+        if (first) VPHO_STAMP_AT(2);
+        for (int kt = 0; kt < NK; ++kt) {
+            const int buf = kt & 1;
+            const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
+            const float* Bs = smem + buf * STAGE + 256 * HB_K + (rg * 32 + li) * HB_K;
+            f32x4 bq, av[TI];
+            auto frags = [&](int kk) {
+                const int ch = ((2 * kk + lh) ^ sw) * 4;
+                bq = *reinterpret_cast<const f32x4*>(Bs + ch);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) av[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * HB_K + ch);
+            };
+            auto mfmas = [&]() {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bq[q], acc[i], 0, 0, 0);
+            };
+#pragma unroll
+            for (int kk = 0; kk < NKK - 1; ++kk) { frags(kk); mfmas(); }
+            frags(NKK - 1);
+            if (kt + 1 < NK) {
+                VPHO_SYNC_LDS_DMA();                                // every wave has its fragments of stage `buf`; stage kt + 1 has landed
+                if (kt + 2 < NK) fill(buf, kt + 2, n);
+            }
+            mfmas();
+        }
+        __syncthreads();                                            // both stage buffers are free
+        if (first) VPHO_STAMP_AT(3);
+        // ---- next tile: tables into registers, then its first two stages, BEFORE this tile's epilogue
+        const int en = n, er0 = r0, erows = rows;
+        b += G;
+        const bool more = b < total;
+        f32x4 tvn = {0.f, 0.f, 0.f, 0.f};
+        if (more) {
+            tile_of(b, n, r0, rows);
+            tvn = load_tables(n, r0, rows);
+            set_poff(r0, rows);
+            fill(0, 0, n);
+            fill(1, 1, n);
+        }
+        // ---- epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane; a row's 256 hidden
+        // units are summed as EIGHT partial sums of 32 in ascending order, whatever the tile kind (see head_tile)
+        const int lrow_out = rg * 32 + li, row = er0 + lrow_out;
+        const bool live = row < a.R;
+        // (the lane's first hidden unit as an OPAQUE per-tile value: left visible, the compiler hoists the 64 loop-invariant LDS addresses
+        // of this epilogue out of the tile loop and spills them: 45 registers of scratch)
+        int j0 = 32 * TI * hh + 4 * lh;
+        asm volatile("" : "+v"(j0));
+        const float* cim = a.cimg + (long long)(live ? row / a.S : 0) * a.NH + en * 256 + j0;
+        const float* cbl = Cb + (live ? row / a.S - er0 / a.S : 0) * CB_LD + j0;
+        const float* ebl = Eb + j0 * 4;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = 32 * i + (e & 3) + 8 * (e >> 2);      // + j0
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ebl + j * 4);
+                float h = acc[i][e] + (CB ? cbl[j] : cim[j]) + t[0];
+                h = h > 0.f ? h : 0.f;
+                o0 += h * t[1]; o1 += h * t[2]; o2 += h * t[3];
+            }
+            o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+            if (lh == 0) {
+                float* ob = Ob + ((hh * TI + i) * 128 + lrow_out) * 4;
+                ob[0] = o0; ob[1] = o1; ob[2] = o2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (first) VPHO_STAMP_AT(5);
+        VPHO_BARRIER_LDS_ONLY();                                    // partial sums complete; Eb / Cb are no longer read (no fence: the next tile's fills are in flight)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const float b2v = tq < 3 * erows ? Cb[B2_AT + tq % 3] : 0.f;
+        VPHO_BARRIER_LDS_ONLY();                                    // ... b2 of THIS tile read before the tables of the next one overwrite it
+        if (more) store_tables(tvn);
+        // ---- one output per thread: thread t -> (row t / 3, component t % 3); every thread issues the store (out of range when idle)
+        {
+            const int rl = tq / 3, dd = tq - 3 * rl, orow = er0 + rl;
+            int off = -1;
+            float sv = 0.f;
+            if (rl < erows && orow < a.R) {
+                float acc2 = Ob[rl * 4 + dd];
+#pragma unroll
+                for (int part = 1; part < 8; ++part) acc2 += Ob[(part * 128 + rl) * 4 + dd];
+                sv = (acc2 + b2v) / inv_std;
+                if (a.rhs_mode) {
+                    // score_eval_wrapper's nan_to_num (score_based_model.py:65-72), entry by entry; see head_tile
+                    if (sv != sv) { sv = 0.f; ++nans; } else if (fabsf(sv) == INFINITY) sv = 0.f;
+                    sv = 0.f - coef * sv;
+                }
+                off = (int)(((long long)orow * a.D + en * 3 + dd) * 4);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv), orr, off, 0, 0);
+        }
+        if (first) VPHO_STAMP_AT(4);
+        first = false;
+        return more;
+    };
+    while (true) {
+        const bool more = rows == 128 ? tile(std::integral_constant<int, 4>{}) : tile(std::integral_constant<int, 1>{});
+        if (!more) break;
+    }
+    if (nans) atomicAdd(a.nan_count, nans);
+    VPHO_STAMP_WRITE(head, blockIdx.x);
+}
+
 // --------------------------------------------------------------------------------------------- score head, split-bf16 products (opt-in)
 // VPHO_SCORE_MFMA=bf16x6 | bf16x9 (not the default; the fp32-MFMA kernel above is the product path and the one every parity claim is
 // made on).  gfx950 multiplies bf16 on the matrix cores 16 x faster than fp32, and a product of two fp32 numbers can be assembled
@@ -1287,8 +1523,23 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         const char* cb_s = getenv("VPHO_HEAD_CB");
         const int cb_env = cb_s ? atoi(cb_s) : 1;
         const dim3 grid((unsigned)(nheads * (a.full_tiles + a.tail_tiles)));
-        if (c.S >= 64 && cb_env) hipLaunchKernelGGL(score_head_kernel<true>, grid, dim3(512), lds, c.s, a);
-        else                     hipLaunchKernelGGL(score_head_kernel<false>, grid, dim3(512), lds, c.s, a);
+        // persistent kernel (default): min(tiles, workgroup slots) workgroups walk the tiles; VPHO_HEAD_PERS=0: one workgroup per tile (round 4, same bits)
+        const char* pp = getenv("VPHO_HEAD_PERS");
+        const int pers = pp ? atoi(pp) : 1;
+        const bool cb = c.S >= 64 && cb_env;
+        if (pers && cb && (double)c.R * c.w->D * 4.0 < 3.9e9 && (double)c.w->nheads * 256 * 256 * 4.0 < 3.9e9) {
+            const size_t plds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 1024 + 8 * 128 * 4) * sizeof(float);     // 72 KB: two workgroups per CU
+            static bool pers_opt_in = false;
+            if (!pers_opt_in) {
+                VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                pers_opt_in = true;
+            }
+            const dim3 pgrid((unsigned)std::min<long long>((long long)grid.x, (long long)slots));
+            hipLaunchKernelGGL(score_head_pers_kernel<true>, pgrid, dim3(512), plds, c.s, a);       // sample_num >= 64 (the LDS copy of the per-image terms); smaller: the one-tile kernel
+            return vpho::check_launch("score_head_pers_kernel");
+        }
+        if (cb) hipLaunchKernelGGL(score_head_kernel<true>, grid, dim3(512), lds, c.s, a);
+        else    hipLaunchKernelGGL(score_head_kernel<false>, grid, dim3(512), lds, c.s, a);
     }
     return vpho::check_launch("score_head_kernel");
 }
