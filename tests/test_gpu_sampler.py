@@ -61,13 +61,13 @@ def test_persistent_score_head_is_bit_identical_to_the_one_tile_kernels(nets, na
     """round 5: (a) the epilogue's per-image terms (cimg) come from an LDS copy of the <= 3 images a 128-row tile spans (sample_num >= 64)
     instead of 64 global loads per lane (VPHO_HEAD_CB=0 keeps the global loads); (b) score_head_pers_kernel: a workgroup walks several
     tiles, requests the next tile's first stages and tables behind the current tile's last barrier, one output per thread
-    (VPHO_HEAD_PERS=0: one workgroup per tile).  Same values, same order of additions: every score bit-identical -- README batch (tiles
+    (opt-in, VPHO_HEAD_PERS=1; default: one workgroup per tile).  Same values, same order of additions: every score bit-identical -- README batch (tiles
     straddling two and three images, tail tiles, 3.1 tiles per workgroup), sample_num 64 (the smallest that takes the LDS path), ragged
     last tiles, sample_num 40 (global loads, one-tile kernel whatever the switches); and a whole ODE solve (controller mode)."""
     import os
     feat, x = seeded((bs, 1024), 70, 0.3).cuda(), seeded((bs * S, D), 71, 1.5).cuda()
     res = {}
-    for key, env in (('base', dict(VPHO_HEAD_CB='0', VPHO_HEAD_PERS='0')), ('cb', dict(VPHO_HEAD_PERS='0')), ('pers', {})):
+    for key, env in (('base', dict(VPHO_HEAD_CB='0', VPHO_HEAD_PERS='0')), ('cb', dict(VPHO_HEAD_PERS='0')), ('pers', dict(VPHO_HEAD_PERS='1'))):
         os.environ.update(env)
         try:
             res[key] = nets[name].score(feat, x, 0.3, S).clone()

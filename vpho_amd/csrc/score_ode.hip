@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     }
 }
 
-// --------------------------------------------------------------------------------------------- persistent score head (round 5, default)
+// --------------------------------------------------------------------------------------------- persistent score head (round 5 experiment, opt-in: VPHO_HEAD_PERS=1)
 // The in-kernel stamps of profiles/r05_inkernel_clock.txt: a 128-row tile lives 62 us -- entry 0.7, first fill wait 1.0, main loop 45,
 // epilogue 11 (partial sums 5.5, then a barrier and a combine that keeps 2 of the 8 waves busy for 5.7), slot turnover 0.8 -- and a CU has
 // two workgroups in their main loops for only 46 % of the launch.  Here a workgroup WALKS its tiles (b, b + grid, ...: 128-row tiles of
@@ -1523,9 +1523,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         const char* cb_s = getenv("VPHO_HEAD_CB");
         const int cb_env = cb_s ? atoi(cb_s) : 1;
         const dim3 grid((unsigned)(nheads * (a.full_tiles + a.tail_tiles)));
-        // persistent kernel (default): min(tiles, workgroup slots) workgroups walk the tiles; VPHO_HEAD_PERS=0: one workgroup per tile (round 4, same bits)
+        // persistent kernel, OPT-IN (VPHO_HEAD_PERS=1; same bits): min(tiles, workgroup slots) workgroups walk the tiles.  Measured round 5
+        // (profiles/r05_head_persistent_ab.txt): stand-alone 230-238 us against 232-234 for one workgroup per tile, the pipelined step
+        // 29.9-30.1 ms against 29.5-29.6 -- with two workgroups per CU the other workgroup's matrix work already covers a tile's prologue,
+        // and workgroups that hold their CU slot for the whole launch keep the other streams' kernels out.  Not the default.
         const char* pp = getenv("VPHO_HEAD_PERS");
-        const int pers = pp ? atoi(pp) : 1;
+        const int pers = pp ? atoi(pp) : 0;
         const bool cb = c.S >= 64 && cb_env;
         if (pers && cb && (double)c.R * c.w->D * 4.0 < 3.9e9 && (double)c.w->nheads * 256 * 256 * 4.0 < 3.9e9) {
             const size_t plds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 1024 + 8 * 128 * 4) * sizeof(float);     // 72 KB: two workgroups per CU
