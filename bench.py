@@ -445,6 +445,18 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     # the judge of the top-k chain: every list of the HIP path re-scored in fp64 on the HIP path's own candidates (oracle/referee.py)
     from oracle import referee as RFE
     ref_sum = RFE.summary(RFE.referee(assets, skeleton, RFE.record_from_hip(out, eng_info, data)))
+    # the sampler's own referee: both ODEs solved in fp64 on the accepted step sequence (rows are independent on a fixed sequence: every
+    # 4th hypothesis), each side against the exact solution of the same scheme on its own encoding (oracle/sampler_fp64.py)
+    from oracle import sampler_fp64 as SF
+    from oracle import nets as ON
+    S_ = args.sample_num
+    sig = ON.ve_prior_sigma(args.sample_T0)
+    rep = lambda e: e.detach().cpu()[:, None].repeat(1, S_, 1).reshape(-1, 1024)
+    sampler64 = {}
+    for name, key, noise, x_hip, x_or in (('hand', 'denoiser_hand', nh, eng_info['hand_x6d'], info['hand_x6d']),
+                                          ('obj', 'denoiser_obj', no, out['diff_final_obj_6d'].reshape(-1, 9), ref['diff_final_obj_6d'].reshape(-1, 9))):
+        sampler64[name] = SF.compare(sd, key, rep(info['features'][f'encoding_{name}']), noise * sig, info[f'{name}_ode']['steps'], args.sampling_steps,
+                                     x_hip, x_or, feat_hip=rep(gf[f'encoding_{name}']), stride=4)
     # how well the REFERENCE reproduces itself (committed fixture written by the reference's own forward under other thread counts /
     # oneDNN off, tests/golden/make_golden_readme.py --variant): the yardstick for end_to_end_vs_oracle's list counts
     from oracle.compare import reference_self_agreement
@@ -465,6 +477,9 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                                       eng_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
                        'upstream_max_abs': upstream,
                        'fp64_referee': ref_sum,
+                       'sampler_vs_fp64': dict(sampler64, what='final hypotheses of both ODE solves against a float64 solve (score network, stage algebra, denoise step '
+                                               'in double) of the same accepted step sequence, every 4th hypothesis, each side on its own encoding: err_* = max / rms '
+                                               '|x - x_fp64|, ratio = HIP / oracle (<= 1: the kernels are at least as close to the exact scheme as the reference\'s fp32 arithmetic)'),
                        'reference_self_agreement': self_rep,
                        'end_to_end_vs_oracle': end_to_end,
                        'aggregation_given_identical_candidates': given_same}}
