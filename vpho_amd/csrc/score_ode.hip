@@ -28,6 +28,7 @@ VPHO_STAMP_DECL(head)
 namespace {
 
 constexpr int HB_K = 16;
+constexpr int TAIL_RD = 4;            // LDS stages of a 32-row tail tile of the score head (prefetch distance TAIL_RD - 1)
 constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
 // --------------------------------------------------------------------------------------------- time embedding
@@ -460,7 +461,9 @@ template <int TI, bool CB>
 __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
     constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
     constexpr int STAGE = (256 + 128) * HB_K;
-    float* Eb = smem + 2 * STAGE;
+    // 32-row tail tiles: stages of 256 weight rows + 32 activation rows in a ring of TAIL_RD (see the main loop below)
+    constexpr int STG1 = (256 + 32) * HB_K;
+    float* Eb = smem + (TI == 4 ? 2 * STAGE : TAIL_RD * STG1);
     VPHO_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;   // hidden base of the wave = 32*TI*hh
@@ -508,6 +511,9 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         const int lr = lrow + RPP * j, r = r0 + lr;
         poff[j] = (r < a.R && lr < ROWS) ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
     }
+    // tail tile: every wave fetches the activation rows of wave (wave & 1): tile row lr1, with that row's chunk swizzle
+    const int lr1 = (wave & 1) * RPW + lane / CPR;
+    const int poff1 = (r0 + lr1 < a.R) ? (int)(((unsigned)(r0 + lr1) * 256u + 4u * (unsigned)((lane % CPR) ^ ((lr1 >> SW_SHIFT) & (CPR - 1)))) * 4u) : -1;
     auto fill = [&](int buf, int kt) {
         float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
         float* Ps = smem + buf * STAGE + 256 * HB_K + wave * RPW * HB_K;
@@ -526,6 +532,47 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
 
     const int sw = (li >> SW_SHIFT) & (CPR - 1);
     constexpr int NK = 256 / HB_K, NKK = HB_K / 8;
+    if constexpr (TI == 1) {
+        // Tail tile: a wave has ONE 32 x 32 accumulator tile, 8 MFMAs (512 cycles) per 16-k stage -- with two stages a tile was a chain of 16
+        // fill latencies (~1.5 us each: 256 tail tiles kept the chip at a quarter of its matrix rate for ~28 us of a 232-us launch,
+        // profiles/r05_inkernel_clock.txt).  Its stage is small (256 weight rows + 32 activation rows = 18 KB), so it rides a ring of
+        // TAIL_RD stages: the fill of stage kt + TAIL_RD - 1 is requested behind the barrier of stage kt; every wave issues exactly three
+        // LDS-DMA instructions per stage (two weight passes + the activation rows: waves 2..7 re-fetch the rows of wave & 1, the same
+        // bytes to the same slots), so the counted wait is one immediate for the whole workgroup.  Same k order: bit-identical.
+        auto fill1 = [&](int slot, int kt) {
+            float* Ws = smem + slot * STG1 + wave * RPW * HB_K;
+            float* Ps = smem + slot * STG1 + 256 * HB_K + (wave & 1) * RPW * HB_K;
+            const int koff = kt * HB_K * 4;
+#pragma unroll
+            for (int j = 0; j < 256 / RPP; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Ws + RPP * j * HB_K), 16, woff[j], koff, 0, 0);
+            const int po = poff1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)Ps, 16, po, koff, 0, 0);
+        };
+#pragma unroll
+        for (int st = 0; st < TAIL_RD - 1; ++st) fill1(st, st);
+        VPHO_STAMP_AT(1);
+        VPHO_STAMP_AT(2);
+        for (int kt = 0; kt < NK; ++kt) {
+            // stage kt has landed once at most the fills of the stages behind it are outstanding (3 instructions each)
+            const int younger = min(TAIL_RD - 2, NK - 1 - kt);
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                        // ... in every wave; and every wave is done with stage kt - 1
+            if (kt + TAIL_RD - 1 < NK) fill1((kt + TAIL_RD - 1) % TAIL_RD, kt + TAIL_RD - 1);
+            const float* As = smem + (kt % TAIL_RD) * STG1 + (hh * 32 + li) * HB_K;
+            const float* Bs = smem + (kt % TAIL_RD) * STG1 + 256 * HB_K + li * HB_K;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int ch = ((2 * kk + lh) ^ sw) * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + ch);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(As + ch);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b[q], acc[0], 0, 0, 0);
+            }
+        }
+    } else {
     // Two LDS stages.  The barrier of k-tile kt sits before its LAST 8-wide MFMA group: by then every wave has its
     // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
     // load has a whole k-tile of MFMA time to land before the next barrier needs it.
@@ -558,6 +605,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         VPHO_SYNC_LDS_DMA();
         if (kt + 2 < NK) fill(buf, kt + 2);
         mfmas();
+    }
     }
     __syncthreads();
     VPHO_STAMP_AT(3);
@@ -1212,10 +1260,18 @@ __global__ void denoise_kernel(const double* __restrict__ y, const float* __rest
 struct RkSetup { double T0, tf, rtol, atol, g_scale; int num_steps, log_cap; double *te, *dense_p, *log; };
 
 __device__ inline float dev_sigma_f32(float t) { return (float)SIGMA_MIN * powf((float)(SIGMA_MAX / SIGMA_MIN), t); }
+// Scalars of one RHS evaluation at time t.  Two sigmas, as in the reference (score_based_model.py:74-83, sde.py:15-24):
+//   * the score's own division uses std = ve_marginal_prob(time tensor): the time tensor is float32 (torch.ones(bs) * t), so
+//     sigma_min * (sigma_max / sigma_min) ** t is a FLOAT32 power;
+//   * the drift coefficient 0.5 g(t)^2 comes from sde_coeff(torch.tensor(t)) with t the solver's np.float64 time: a 0-d float64 tensor,
+//     sigma and g in FLOAT64, the product 0.5 g^2 cast to float32 once (numpy's value-based casting against the f32 score).
+// Rounds 1-4 took g from the float32 sigma as well: a relative error of ~3e-7 in every stage's coefficient -- what the fp64 sampler
+// referee (oracle/sampler_fp64.py, round 5) found as 2.1 x (max) / 3.6 x (rms) the reference arithmetic's distance from the exact scheme.
+// Only the solver's very first call hands the wrapper a Python float (-> float32 tensor): eval_rhs(..., first_call = true) on the host.
 __device__ inline void ctl_stage_scalars(RkCtl* c, int i, double t) {
     const float tf = (float)t;
     const float sg = dev_sigma_f32(tf);
-    const double g = (double)sg * c->g_scale;
+    const double g = SIGMA_MIN * pow(SIGMA_MAX / SIGMA_MIN, t) * c->g_scale;
     c->ts[i] = tf; c->inv_std[i] = sg + 1e-7f; c->coef[i] = (float)(0.5 * g * g);
 }
 
@@ -1475,7 +1531,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
     a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
     a.ctl = cc.mode ? c.ws.ctl : nullptr; a.ctl_mode = cc.mode; a.stage = cc.stage; a.out_slot = cc.out_slot; a.kbase = c.ws.K; a.n_el = c.n_el;
-    size_t lds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+    // [2] stages of a 128-row tile (or the TAIL_RD-stage ring of a 32-row tail tile) | [256][4] epilogue table | per-image terms
+    size_t lds = (size_t)(std::max(2 * (256 + 128) * HB_K, TAIL_RD * (256 + 32) * HB_K) + 256 * 4 + 2 * 128 * 4) * sizeof(float);
     if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
@@ -1493,7 +1550,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     if (!slots) {
         hipDeviceProp_t prop;
         VPHO_HIP(hipGetDeviceProperties(&prop, dev));
-        slots = 2 * prop.multiProcessorCount;               // two 57 KB workgroups per CU
+        slots = 2 * prop.multiProcessorCount;               // two workgroups per CU (80 KB each with the tail tiles' four-stage ring)
     }
     const int tiles = (int)((c.R + 127) / 128), nheads = c.w->nheads;
     a.nheads = nheads; a.full_tiles = tiles; a.tail_tiles = 0;
@@ -1548,10 +1605,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
 }
 
 // rhs(t, .) of the probability-flow ODE: 0 - f32(0.5 g(t)^2) * score     (score_based_model.py:74-83)
+// first_call: fun(t0, y0), the one evaluation whose t is a Python float in scipy (-> float32 sigma); every other t is np.float64 (see ctl_stage_scalars)
 int eval_rhs(Ctx& c, const float* X, double t, float* out, int ct_slot = -1, const LinComb* lc = nullptr,
-             const double* y = nullptr, double* ynew = nullptr, const KSlots* ks = nullptr) {
+             const double* y = nullptr, double* ynew = nullptr, const KSlots* ks = nullptr, bool first_call = false) {
     const float tf = (float)t;
-    const double g = (double)sigma_f32(tf) * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
+    const double sigma = first_call ? (double)sigma_f32(tf) : SIGMA_MIN * std::pow(SIGMA_MAX / SIGMA_MIN, t);
+    const double g = sigma * std::sqrt(2.0 * (std::log(SIGMA_MAX) - std::log(SIGMA_MIN)));
     const float coef = (float)(0.5 * g * g);
     return eval_net(c, X, tf, 1, coef, out, ct_slot, lc, y, ynew, ks);
 }
@@ -1662,7 +1721,7 @@ int ode_sample_host(Ctx& c, const float* feat_img, const float* init_x, double T
     };
 
     // f0 = fun(t0, y0); select_initial_step
-    if (int e = eval_rhs(c, c.ws.X, t, Kp(0))) return e;
+    if (int e = eval_rhs(c, c.ws.X, t, Kp(0), -1, nullptr, nullptr, nullptr, nullptr, true)) return e;
     ++st->nfev;
     double h_abs;
     {
@@ -1825,7 +1884,7 @@ int ode_sample_device(Ctx& c, const float* feat_img, const float* init_x, double
     hipLaunchKernelGGL(f32_to_state_kernel, dim3(nbX), dim3(256), 0, c.s, init_x, n_el, D, Dp, c.ws.y, c.ws.X);
 
     // select_initial_step: f0 = fun(t0, y0) (t0 is known here), d0, d1 -> h0 on the device -> probe evaluation -> d2 -> h_abs
-    if (int e = eval_rhs(c, c.ws.X, T0, c.ws.K)) return e;
+    if (int e = eval_rhs(c, c.ws.X, T0, c.ws.K, -1, nullptr, nullptr, nullptr, nullptr, true)) return e;
     {
         NormArgs na;
         memset(&na, 0, sizeof(na));
