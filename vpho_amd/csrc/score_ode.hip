@@ -1259,7 +1259,10 @@ __global__ void denoise_kernel(const double* __restrict__ y, const float* __rest
 // host's in the last bit.
 struct RkSetup { double T0, tf, rtol, atol, g_scale; int num_steps, log_cap; double *te, *dense_p, *log; };
 
-__device__ inline float dev_sigma_f32(float t) { return (float)SIGMA_MIN * powf((float)(SIGMA_MAX / SIGMA_MIN), t); }
+// float32 sigma of ve_marginal_prob on a float32 time (torch: 0.01 * 5000.0 ** t_f32, a float32 power then a float32 product).  The power
+// is taken in double and rounded once: the device library's powf is good to a few ulp only (a 2-4 ulp sigma = 2.4-5e-7 of every score,
+// the 2.1 x / 3.6 x of the fp64 sampler referee, round 5); the correctly rounded float32 power is what torch's CPU kernel returns.
+__device__ inline float dev_sigma_f32(float t) { return (float)SIGMA_MIN * (float)pow(SIGMA_MAX / SIGMA_MIN, (double)t); }
 // Scalars of one RHS evaluation at time t.  Two sigmas, as in the reference (score_based_model.py:74-83, sde.py:15-24):
 //   * the score's own division uses std = ve_marginal_prob(time tensor): the time tensor is float32 (torch.ones(bs) * t), so
 //     sigma_min * (sigma_max / sigma_min) ** t is a FLOAT32 power;
@@ -1458,7 +1461,7 @@ int linear(const float* x, int rows, int cin, const float* wt, const float* bias
     return vpho_conv2d_nhwc_f32(&d, s);
 }
 
-float sigma_f32(float t) { return (float)SIGMA_MIN * powf((float)(SIGMA_MAX / SIGMA_MIN), t); }
+float sigma_f32(float t) { return (float)SIGMA_MIN * (float)std::pow(SIGMA_MAX / SIGMA_MIN, (double)t); }      // see dev_sigma_f32
 
 struct Ctx {
     const vpho_score_weights* w; Workspace ws; int bs, S; long long R, n_el; int NH; hipStream_t s;
