@@ -456,7 +456,7 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     for name, key, noise, x_hip, x_or in (('hand', 'denoiser_hand', nh, eng_info['hand_x6d'], info['hand_x6d']),
                                           ('obj', 'denoiser_obj', no, out['diff_final_obj_6d'].reshape(-1, 9), ref['diff_final_obj_6d'].reshape(-1, 9))):
         sampler64[name] = SF.compare(sd, key, rep(info['features'][f'encoding_{name}']), noise * sig, info[f'{name}_ode']['steps'], args.sampling_steps,
-                                     x_hip, x_or, feat_hip=rep(gf[f'encoding_{name}']), stride=4)
+                                     x_hip, x_or, feat_hip=rep(gf[f'encoding_{name}']), steps_hip=eng_info[f'{name}_ode']['steps'], stride=4)
     # how well the REFERENCE reproduces itself (committed fixture written by the reference's own forward under other thread counts /
     # oneDNN off, tests/golden/make_golden_readme.py --variant): the yardstick for end_to_end_vs_oracle's list counts
     from oracle.compare import reference_self_agreement
@@ -478,7 +478,7 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                        'upstream_max_abs': upstream,
                        'fp64_referee': ref_sum,
                        'sampler_vs_fp64': dict(sampler64, what='final hypotheses of both ODE solves against a float64 solve (score network, stage algebra, denoise step '
-                                               'in double) of the same accepted step sequence, every 4th hypothesis, each side on its own encoding: err_* = max / rms '
+                                               'in double) of its OWN accepted step sequence (the controller turns 1e-7 of the stages into 2e-5 of the next step size: step_size_rel_diff_max), every 4th hypothesis, each side on its own encoding: err_* = max / rms '
                                                '|x - x_fp64|, ratio = HIP / oracle (<= 1: the kernels are at least as close to the exact scheme as the reference\'s fp32 arithmetic)'),
                        'reference_self_agreement': self_rep,
                        'end_to_end_vs_oracle': end_to_end,

@@ -230,8 +230,8 @@ def test_readme_config_bs64_parity_with_the_oracle(model_contrast_cpu, sd_contra
     from tests._referee import assert_hand_hypotheses_agree
     print('hand hypotheses: rot6d samples / post-processing on identical samples / axis-angle between the sides:',
           assert_hand_hypotheses_agree(out, gi, ref, info, gi['features']['mano_shape']))
-    # (A') the sampler against its own referee: both solves in float64 on the accepted step sequence, every 8th
-    # hypothesis, each side on its own encoding -- the HIP kernels' arithmetic error must not exceed 1.5 x the reference arithmetic's
+    # (A') the sampler against its own referee: both solves in float64, each on its side's own accepted step sequence and
+    # encoding, every 8th hypothesis -- the HIP kernels' arithmetic error must not exceed 1.5 x the reference arithmetic's
     from oracle import sampler_fp64 as SF
     from oracle import nets as ON
     sig = ON.ve_prior_sigma(T0)
@@ -239,7 +239,7 @@ def test_readme_config_bs64_parity_with_the_oracle(model_contrast_cpu, sd_contra
     for name, key, noise, x_hip, x_or in (('hand', 'denoiser_hand', nh, gi['hand_x6d'], info['hand_x6d']),
                                           ('obj', 'denoiser_obj', no, out['diff_final_obj_6d'].reshape(-1, 9), ref['diff_final_obj_6d'].reshape(-1, 9))):
         r = SF.compare(sd_contrast, key, rep(info['features'][f'encoding_{name}']), noise * sig, info[f'{name}_ode']['steps'], STEPS, x_hip, x_or,
-                       feat_hip=rep(gi['features'][f'encoding_{name}']), stride=8)
+                       feat_hip=rep(gi['features'][f'encoding_{name}']), steps_hip=gi[f'{name}_ode']['steps'], stride=8)
         print(f'sampler vs fp64 ({name}):', r)
         assert r['ratio_max'] <= 1.5 and r['ratio_rms'] <= 1.5, (name, r)
         assert r['err_hip_max'] <= 1e-4 * max(1.0, r['x_scale']), (name, r)
