@@ -28,7 +28,6 @@ VPHO_STAMP_DECL(head)
 namespace {
 
 constexpr int HB_K = 16;
-constexpr int TAIL_RD = 4;            // LDS stages of a 32-row tail tile of the score head (prefetch distance TAIL_RD - 1)
 constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
 // --------------------------------------------------------------------------------------------- time embedding
@@ -457,13 +456,15 @@ struct HeadArgs {
 // A launch whose tile count is not a multiple of the chip's workgroup slots ends in a round that keeps a few CUs busy for a whole
 // tile time (6 400 rows x 32 heads = 1 600 tiles on 512 slots: 3.125 rounds cost 4).  The launch therefore cuts the rows beyond the
 // last full round into quarter tiles that all CUs share: 1 536 ordinary tiles = 3 rounds exactly, then 256 tail tiles, one per CU.
+// (Round 5, in-kernel stamps: a tail tile lives 13 us, 10.7 of them in its 16 stages = 0.67 us per stage for 0.21 us of matrix work, and the
+// 256 of them add ~20 us to a 232-us launch.  A four-stage prefetch ring for them -- fills three stages ahead, 80 KB of LDS -- changed
+// nothing (233-235 us): the stage time is the 24 KB of weights a tail workgroup streams for 32 rows, ~70 GB/s per CU from L2, not a
+// latency.  Dropped.))
 template <int TI, bool CB>
 __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
     constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
     constexpr int STAGE = (256 + 128) * HB_K;
-    // 32-row tail tiles: stages of 256 weight rows + 32 activation rows in a ring of TAIL_RD (see the main loop below)
-    constexpr int STG1 = (256 + 32) * HB_K;
-    float* Eb = smem + (TI == 4 ? 2 * STAGE : TAIL_RD * STG1);
+    float* Eb = smem + 2 * STAGE;
     VPHO_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
     const int rg = TI == 4 ? (wave & 3) : 0, hh = TI == 4 ? (wave >> 2) : wave;   // hidden base of the wave = 32*TI*hh
@@ -511,9 +512,6 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         const int lr = lrow + RPP * j, r = r0 + lr;
         poff[j] = (r < a.R && lr < ROWS) ? (int)(((unsigned)r * 256u + 4u * (unsigned)kq) * 4u) : -1;
     }
-    // tail tile: every wave fetches the activation rows of wave (wave & 1): tile row lr1, with that row's chunk swizzle
-    const int lr1 = (wave & 1) * RPW + lane / CPR;
-    const int poff1 = (r0 + lr1 < a.R) ? (int)(((unsigned)(r0 + lr1) * 256u + 4u * (unsigned)((lane % CPR) ^ ((lr1 >> SW_SHIFT) & (CPR - 1)))) * 4u) : -1;
     auto fill = [&](int buf, int kt) {
         float* Ws = smem + buf * STAGE + wave * RPW * HB_K;
         float* Ps = smem + buf * STAGE + 256 * HB_K + wave * RPW * HB_K;
@@ -532,47 +530,6 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
 
     const int sw = (li >> SW_SHIFT) & (CPR - 1);
     constexpr int NK = 256 / HB_K, NKK = HB_K / 8;
-    if constexpr (TI == 1) {
-        // Tail tile: a wave has ONE 32 x 32 accumulator tile, 8 MFMAs (512 cycles) per 16-k stage -- with two stages a tile was a chain of 16
-        // fill latencies (~1.5 us each: 256 tail tiles kept the chip at a quarter of its matrix rate for ~28 us of a 232-us launch,
-        // profiles/r05_inkernel_clock.txt).  Its stage is small (256 weight rows + 32 activation rows = 18 KB), so it rides a ring of
-        // TAIL_RD stages: the fill of stage kt + TAIL_RD - 1 is requested behind the barrier of stage kt; every wave issues exactly three
-        // LDS-DMA instructions per stage (two weight passes + the activation rows: waves 2..7 re-fetch the rows of wave & 1, the same
-        // bytes to the same slots), so the counted wait is one immediate for the whole workgroup.  Same k order: bit-identical.
-        auto fill1 = [&](int slot, int kt) {
-            float* Ws = smem + slot * STG1 + wave * RPW * HB_K;
-            float* Ps = smem + slot * STG1 + 256 * HB_K + (wave & 1) * RPW * HB_K;
-            const int koff = kt * HB_K * 4;
-#pragma unroll
-            for (int j = 0; j < 256 / RPP; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(Ws + RPP * j * HB_K), 16, woff[j], koff, 0, 0);
-            const int po = poff1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_ptr)Ps, 16, po, koff, 0, 0);
-        };
-#pragma unroll
-        for (int st = 0; st < TAIL_RD - 1; ++st) fill1(st, st);
-        VPHO_STAMP_AT(1);
-        VPHO_STAMP_AT(2);
-        for (int kt = 0; kt < NK; ++kt) {
-            // stage kt has landed once at most the fills of the stages behind it are outstanding (3 instructions each)
-            const int younger = min(TAIL_RD - 2, NK - 1 - kt);
-            if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                        // ... in every wave; and every wave is done with stage kt - 1
-            if (kt + TAIL_RD - 1 < NK) fill1((kt + TAIL_RD - 1) % TAIL_RD, kt + TAIL_RD - 1);
-            const float* As = smem + (kt % TAIL_RD) * STG1 + (hh * 32 + li) * HB_K;
-            const float* Bs = smem + (kt % TAIL_RD) * STG1 + 256 * HB_K + li * HB_K;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const int ch = ((2 * kk + lh) ^ sw) * 4;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + ch);
-                const f32x4 av = *reinterpret_cast<const f32x4*>(As + ch);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b[q], acc[0], 0, 0, 0);
-            }
-        }
-    } else {
     // Two LDS stages.  The barrier of k-tile kt sits before its LAST 8-wide MFMA group: by then every wave has its
     // fragments of stage `buf` in registers, so the stage is refilled (k-tile kt+2) right behind the barrier and the
     // load has a whole k-tile of MFMA time to land before the next barrier needs it.
@@ -605,7 +562,6 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         VPHO_SYNC_LDS_DMA();
         if (kt + 2 < NK) fill(buf, kt + 2);
         mfmas();
-    }
     }
     __syncthreads();
     VPHO_STAMP_AT(3);
@@ -1534,8 +1490,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     a.out = out; a.nan_count = c.ws.nan_count; a.R = (int)c.R; a.S = c.S; a.NH = c.NH; a.D = c.w->D;
     a.inv_std_den = sigma_f32(t) + 1e-7f; a.coef = coef; a.rhs_mode = rhs_mode;
     a.ctl = cc.mode ? c.ws.ctl : nullptr; a.ctl_mode = cc.mode; a.stage = cc.stage; a.out_slot = cc.out_slot; a.kbase = c.ws.K; a.n_el = c.n_el;
-    // [2] stages of a 128-row tile (or the TAIL_RD-stage ring of a 32-row tail tile) | [256][4] epilogue table | per-image terms
-    size_t lds = (size_t)(std::max(2 * (256 + 128) * HB_K, TAIL_RD * (256 + 32) * HB_K) + 256 * 4 + 2 * 128 * 4) * sizeof(float);
+    // [2] stages | [256][4] epilogue table | per-image terms (3 x 257 of 1024 floats)
+    size_t lds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 2 * 128 * 4) * sizeof(float);
     if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
@@ -1553,7 +1509,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     if (!slots) {
         hipDeviceProp_t prop;
         VPHO_HIP(hipGetDeviceProperties(&prop, dev));
-        slots = 2 * prop.multiProcessorCount;               // two workgroups per CU (80 KB each with the tail tiles' four-stage ring)
+        slots = 2 * prop.multiProcessorCount;               // two 57 KB workgroups per CU
     }
     const int tiles = (int)((c.R + 127) / 128), nheads = c.w->nheads;
     a.nheads = nheads; a.full_tiles = tiles; a.tail_tiles = 0;
