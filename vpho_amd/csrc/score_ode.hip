@@ -459,7 +459,7 @@ struct HeadArgs {
 // (Round 5, in-kernel stamps: a tail tile lives 13 us, 10.7 of them in its 16 stages = 0.67 us per stage for 0.21 us of matrix work, and the
 // 256 of them add ~20 us to a 232-us launch.  A four-stage prefetch ring for them -- fills three stages ahead, 80 KB of LDS -- changed
 // nothing (233-235 us): the stage time is the 24 KB of weights a tail workgroup streams for 32 rows, ~70 GB/s per CU from L2, not a
-// latency.  Dropped.))
+// latency.  Dropped.)
 template <int TI, bool CB>
 __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const int n, const int r0) {
     constexpr int ROWS = TI == 4 ? 128 : 32, PARTS = 8;              // partial sums per row: one per 32 hidden units, whatever the tile kind
