@@ -457,6 +457,18 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                                           ('obj', 'denoiser_obj', no, out['diff_final_obj_6d'].reshape(-1, 9), ref['diff_final_obj_6d'].reshape(-1, 9))):
         sampler64[name] = SF.compare(sd, key, rep(info['features'][f'encoding_{name}']), noise * sig, info[f'{name}_ode']['steps'], args.sampling_steps,
                                      x_hip, x_or, feat_hip=rep(gf[f'encoding_{name}']), steps_hip=eng_info[f'{name}_ode']['steps'], stride=4)
+    # the feature path's own referee: the oracle's feature path in FLOAT64 on the first 8 images (heat-maps and encodings are per-image
+    # quantities: eval-mode BatchNorm, no batch coupling upstream of the cross modules), against which the HIP kernels and the oracle's fp32
+    # arithmetic are both held -- "close to the oracle" is not "close to the truth"
+    n64 = min(8, n)
+    dbl = lambda d_: {k: (v[:n64].double() if (torch.is_tensor(v) and v.is_floating_point()) else (v[:n64] if (torch.is_tensor(v) or isinstance(v, list)) else v)) for k, v in d_.items()}
+    f64 = OV.features({k: (v.double() if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in sd.items()}, assets, dbl(data))
+    feat64 = {}
+    for k in ('hand_heatmap', 'obj_heatmap', 'encoding_hand', 'encoding_obj'):
+        eh = (gf[k][:n64].detach().cpu().double() - f64[k]).abs()
+        eo = (info['features'][k][:n64].double() - f64[k]).abs()
+        feat64[k] = {'err_hip_max': float(eh.max()), 'err_oracle_max': float(eo.max()), 'err_hip_rms': float(eh.pow(2).mean().sqrt()),
+                     'err_oracle_rms': float(eo.pow(2).mean().sqrt()), 'scale': float(f64[k].abs().max())}
     # how well the REFERENCE reproduces itself (committed fixture written by the reference's own forward under other thread counts /
     # oneDNN off, tests/golden/make_golden_readme.py --variant): the yardstick for end_to_end_vs_oracle's list counts
     from oracle.compare import reference_self_agreement
@@ -477,6 +489,8 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                                       eng_info['obj_ode']['nfev'] == info['obj_ode']['nfev']],
                        'upstream_max_abs': upstream,
                        'fp64_referee': ref_sum,
+                       'features_vs_fp64': dict(feat64, what=f'heat-maps and encodings of the first {n64} images against the oracle\'s feature path run in float64: err_hip = HIP kernels '
+                                                '(fp32 MFMA, one accumulation chain per output, Winograd for the 3x3 / stride-1 layers), err_oracle = the reference arithmetic (torch CPU fp32, blocked sums)'),
                        'sampler_vs_fp64': dict(sampler64, what='final hypotheses of both ODE solves against a float64 solve (score network, stage algebra, denoise step '
                                                'in double) of its OWN accepted step sequence (the controller turns 1e-7 of the stages into 2e-5 of the next step size: step_size_rel_diff_max), every 4th hypothesis, each side on its own encoding: err_* = max / rms '
                                                '|x - x_fp64|, ratio = HIP / oracle (<= 1: the kernels are at least as close to the exact scheme as the reference\'s fp32 arithmetic)'),
