@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     if (a.wins && t0 >= a.tile_base[a.N]) return;      // the grid is sized for every tile of the full maps; uniform per workgroup
     // destination of every tile of this block (output transform): row of its top-left pixel in y, row pitch, which of the 4 pixels exist
     __shared__ int s_row[W_TB], s_pitch[W_TB];
+    __shared__ float s_bias[W_CB];                       // the block's 64 biases: loaded here, read in the epilogue (no global-load latency there)
+    if (tid >= 64 && tid < 64 + W_CB) s_bias[tid - 64] = (a.bias && c0 + tid - 64 < a.Cout) ? a.bias[c0 + tid - 64] : 0.f;
     if (tid < W_TB) {
         int n, ty, tx, row = 0, pitch = (a.W << 4);
         if (wino_tile(a, t0 + tid, n, ty, tx)) {
@@ -257,10 +259,17 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
     const int co = c0 + wc * 32 + li;
-    const float bias = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    const float bias = s_bias[wc * 32 + li];
+    // the 16 destination records of this lane's tile rows in ONE LDS round trip (the patch registers are dead by now): read one by one
+    // inside the loop each was a dependent LDS latency in front of its stores
+    int pm_e[16], row_e[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        pm_e[e] = s_pitch[trow]; row_e[e] = s_row[trow];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
         float s0[4], s1[4];
 #pragma unroll
         for (int fx = 0; fx < 4; ++fx) {
@@ -269,13 +278,13 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         }
         const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
         const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-        const int pm = s_pitch[trow];
+        const int pm = pm_e[e];
         if ((pm & 0xF) && co < a.Cout) {
             const int pitch = pm >> 4;
-            float* yp = a.y + (long long)s_row[trow] * a.y_ld + co;
+            float* yp = a.y + (long long)row_e[e] * a.y_ld + co;
             const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
             const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
-            const float* gp = a.gate ? a.gate + (long long)s_row[trow] * a.y_ld + co : nullptr;
+            const float* gp = a.gate ? a.gate + (long long)row_e[e] * a.y_ld + co : nullptr;
 #pragma unroll
             for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
                 float v = o[p];
