@@ -499,6 +499,15 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         for (int sl = 0; sl <= img_last - img0; ++sl) Cb[sl * CB_LD + j] = a.cimg[(long long)(img0 + sl) * a.NH + n * 256 + j];
     }
 
+    // scalars of the epilogue's last step, requested now (a dependent chain of global loads behind the tile's last barrier otherwise)
+    float hd_inv_std = a.inv_std_den, hd_coef = a.coef;
+    float* hd_out = a.out;
+    if (a.ctl && a.ctl_mode == 1) {
+        hd_inv_std = a.ctl->inv_std[a.stage]; hd_coef = a.ctl->coef[a.stage];
+        hd_out = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
+    }
+    const float hd_b2 = a.b2[n * 3 + tid % 3];
+
     // tiles through buffer resources: per-lane byte offsets are loop constants, the k advance is the instruction's scalar offset;
     // hypothesis rows beyond R (or beyond the tile) carry an out-of-range offset (the hardware writes zeros)
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wg), 0, 256 * 256 * 4, 0x00020000);
@@ -598,33 +607,26 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     }
     VPHO_STAMP_AT(5);
     __syncthreads();
-    if (tid < ROWS) {
-        const int orow = r0 + tid;
-        float inv_std = a.inv_std_den, coef = a.coef;
-        float* outp = a.out;
-        if (a.ctl && a.ctl_mode == 1) {
-            inv_std = a.ctl->inv_std[a.stage]; coef = a.ctl->coef[a.stage];
-            outp = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
-        }
+    // One output per thread: thread t -> (row t / 3, component t % 3), 3 x ROWS threads.  Round 4 gave a row's three components to ONE of
+    // 128 threads (two of the eight waves: 24 strided LDS reads, three 4-byte stores 384 B apart and three divisions each, behind two
+    // dependent global loads of the controller's scalars): 5.7 us of a 62-us tile life with six waves idle (profiles/r05_inkernel_clock.txt).
+    // The scalars and b2 are fetched at the kernel's start now (hd_inv_std, hd_coef, hd_out, hd_b2).  Same sums in the same order.
+    if (tid < 3 * ROWS) {
+        const int rl = tid / 3, dd = tid - 3 * rl, orow = r0 + rl;
         if (orow < a.R) {
-            int nans = 0;
+            float acc2 = Ob[rl * 4 + dd];                                 // partial sums of the hidden slices, ascending
 #pragma unroll
-            for (int dd = 0; dd < 3; ++dd) {
-                float acc2 = Ob[tid * 4 + dd];                            // partial sums of the hidden slices, ascending
-#pragma unroll
-                for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + tid) * 4 + dd];
-                float sv = (acc2 + a.b2[n * 3 + dd]) / inv_std;
-                if (a.rhs_mode) {
-                    // score_eval_wrapper (score_based_model.py:65-72): nan_to_num(nan=0, posinf=0, neginf=0) on the RHS evaluations of the
-                    // solve -- there, when ANY entry of the evaluation is NaN; here entry by entry: the same result whenever a NaN is
-                    // present, and +-inf without any NaN has no defined outcome in the reference (scipy's controller never recovers).
-                    // The bare score (vpho_score_eval, the final denoise evaluation :100) is NOT guarded, as in the reference.
-                    if (sv != sv) { sv = 0.f; ++nans; } else if (fabsf(sv) == INFINITY) sv = 0.f;
-                    sv = 0.f - coef * sv;
-                }
-                outp[(long long)orow * a.D + n * 3 + dd] = sv;
+            for (int part = 1; part < PARTS; ++part) acc2 += Ob[(part * ROWS + rl) * 4 + dd];
+            float sv = (acc2 + hd_b2) / hd_inv_std;
+            if (a.rhs_mode) {
+                // score_eval_wrapper (score_based_model.py:65-72): nan_to_num(nan=0, posinf=0, neginf=0) on the RHS evaluations of the
+                // solve -- there, when ANY entry of the evaluation is NaN; here entry by entry: the same result whenever a NaN is
+                // present, and +-inf without any NaN has no defined outcome in the reference (scipy's controller never recovers).
+                // The bare score (vpho_score_eval, the final denoise evaluation :100) is NOT guarded, as in the reference.
+                if (sv != sv) { sv = 0.f; atomicAdd(a.nan_count, 1); } else if (fabsf(sv) == INFINITY) sv = 0.f;
+                sv = 0.f - hd_coef * sv;
             }
-            if (nans) atomicAdd(a.nan_count, nans);
+            hd_out[(long long)orow * a.D + n * 3 + dd] = sv;
         }
     }
     VPHO_STAMP_AT(4);
