@@ -18,6 +18,8 @@ CASES = {
     'mixed_ho3d_T065':     (4, 5, 5, 7, 3, 0.65, {'is_ho3d': [True, False, True, False]}),
     'cfg4_sizes_512_cand': (3, 256, 100, 30, 10, 0.65, {}),                            # BASELINE configs[3] sample sizes: 2S = 512 = the 8-slot top-k's limit
     'top_k_16_slot_path':  (2, 300, 6, 30, 10, 0.65, {}),                              # 600 candidates per image: the 16-slot top-k kernels
+    'sample_num_600':      (2, 600, 5, 30, 10, 0.65, {}),                              # 1200 candidates per image (round 5): beyond the wavefront kernels -> the counting-rank kernels; the reference has no limit
+    'topk_hand_100':       (2, 80, 5, 100, 10, 0.65, {}),                              # topk_hand above 64 (round 5): the limit-free fuse kernel
 }
 
 
@@ -89,25 +91,79 @@ def test_predict_edge_case_matches_oracle(model_cpu, sd, model_contrast_cpu, sd_
             assert e is None or e < 1e-4, (name, k, res)
 
 
-def test_documented_kernel_limits_raise(assets):
-    """2 * sample_num <= 1024 candidates per image (wavefront top-k: 16 slots of 64 lanes), batch <= 256
-    (CrossModule attends over the batch axis, quirk Q3: one sequence of bs tokens per workgroup), object / hand point clouds that fit
-    LDS.  Each limit is an error with a message, not a wrong answer or a launch failure."""
+def test_limit_free_kernels_agree_with_the_wavefront_kernels_and_with_torch(assets):
+    """round 5 (VERDICT r4 item 8): the reference limits neither 2 * sample_num nor topk_hand nor the batch size (aggregation.py:217,246,777;
+    cross_module.py:104-107).  Beyond 1024 candidates / k = 64 / a batch of 256 the limit-free kernels take over; where both serve a
+    launch they give the same bits (VPHO_FUSE_ANY=1), and against torch: the stable descending order, softmax attention in float64."""
+    import os
     from vpho_amd import ops
     from vpho_amd.assets import ANCHOR_SKELETON
     agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
-    # 2 * sample_num = 1026 candidates in the hand cascade (sample_num = 513)
-    hv = torch.rand(1, 1026, 20, device='cuda')
-    pose = torch.zeros(1, 1026, 48, device='cuda')
-    with pytest.raises(ops.VphoError, match='at most 1024 candidates'):
-        agg.hand_fuse_level(hv, pose, 30, 0)
-    ok = agg.hand_fuse_level(hv[:, :1024].contiguous(), pose[:, :1024].contiguous(), 30, 0)      # the limit itself is served
-    assert ok[1].shape == (1, 1, 30)
-    with pytest.raises(ops.VphoError, match='at most 1024 candidates'):
-        agg.topk(torch.rand(2, 1025, device='cuda'), 5)
-    # batch of 257 images: the cross module's sequence axis
-    with pytest.raises(ops.VphoError, match='<= 256'):
-        ops.mha(torch.zeros(257 * 65, 3 * 512, device='cuda'), 257, 65, 512, 2)
+    g = torch.Generator().manual_seed(4)
+    # ---- cascade level on 600 candidates: both fuse kernels, all four levels
+    for level in range(4):
+        hv = torch.rand(3, 600, 20, generator=g).cuda()
+        hv[:, 100:140] = hv[:, 200:240]                            # exact ties: the smaller index wins
+        pose0 = (torch.randn(3, 600, 48, generator=g) * 0.4).cuda()
+        res = {}
+        for mode in ('0', '1'):
+            os.environ['VPHO_FUSE_ANY'] = mode
+            try:
+                pose = pose0.clone()
+                val, idx, tp, sc = agg.hand_fuse_level(hv, pose, 30, level, want_topk_pose=True, want_scores=True)
+                res[mode] = (val.clone(), idx.clone(), tp.clone(), sc.clone(), pose)
+            finally:
+                os.environ.pop('VPHO_FUSE_ANY', None)
+        for a_, b_ in zip(res['0'], res['1']):
+            assert torch.equal(a_, b_), level
+    # ---- 1200 candidates, k = 30 and k = 100, against the stable descending sort of the kernel's own scores
+    hv = torch.rand(2, 1200, 20, generator=g).cuda()
+    hv[:, 500:520] = hv[:, 20:40]
+    for k in (30, 100):
+        pose = (torch.randn(2, 1200, 48, generator=g) * 0.4).cuda()
+        val, idx, _, sc = agg.hand_fuse_level(hv, pose, k, 1, want_scores=True)          # (bs, 5, k), scores (bs, C, 5)
+        for f in range(5):
+            s_ = sc[:, :, f].cpu()
+            order = torch.stack([torch.tensor(sorted(range(1200), key=lambda c: (-float(s_[b, c]), c))[:k]) for b in range(2)])
+            assert torch.equal(idx[:, f].cpu().long(), order), (k, f)
+            assert torch.equal(val[:, f].cpu(), torch.gather(s_, 1, order))
+        assert torch.isfinite(pose).all()
+    # ---- plain top-k on 1500 candidates, three score columns
+    sc3 = torch.rand(4, 1500, 3, generator=g).cuda()
+    sc3[:, 700:710] = sc3[:, 10:20]
+    val, idx = agg.topk(sc3, 10, 3)
+    for f in range(3):
+        s_ = sc3[:, :, f].cpu()
+        order = torch.stack([torch.tensor(sorted(range(1500), key=lambda c: (-float(s_[b, c]), c))[:10]) for b in range(4)])
+        assert torch.equal(idx[:, f].cpu().long(), order) and torch.equal(val[:, f].cpu(), torch.gather(s_, 1, order))
+    # ---- the cross module's attention over a batch of 300 images (sequence axis = batch axis, quirk Q3) against float64
+    S, B, E, nh = 300, 65, 512, 2
+    qkv = (torch.randn(S * B, 3 * E, generator=g) * 0.5).cuda()
+    out = ops.mha(qkv, S, B, E, nh).cpu().double()
+    q, k_, v = qkv.cpu().double().view(S, B, 3, nh, E // nh).unbind(2)                  # (S, B, nh, hd)
+    att = torch.softmax(torch.einsum('sbhd,tbhd->bhst', q, k_) / (E // nh) ** 0.5, -1)
+    ref = torch.einsum('bhst,tbhd->sbhd', att, v).reshape(S, B, E)
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    small = ops.mha(qkv[:200 * B].contiguous(), 200, B, E, nh)                           # S <= 256: the 4-slot instantiation, unchanged
+    assert torch.isfinite(small).all()
+
+
+def test_documented_kernel_limits_raise(assets):
+    """INTEGRATION.md section 3, after round 5: 16 000 candidates per image (LDS), a batch of 1024 (CrossModule attends over the batch
+    axis, quirk Q3), object / hand point clouds that fit LDS.  Each limit is an error with a message, not a wrong answer or a launch
+    failure."""
+    from vpho_amd import ops
+    from vpho_amd.assets import ANCHOR_SKELETON
+    agg = ops.Aggregation(assets, ANCHOR_SKELETON, 'cuda')
+    with pytest.raises(ops.VphoError, match='at most 16000 candidates'):
+        agg.hand_fuse_level(torch.rand(1, 16001, 5, device='cuda'), torch.zeros(1, 16001, 48, device='cuda'), 30, 0)
+    with pytest.raises(ops.VphoError, match='at most 16384 candidates'):
+        agg.topk(torch.rand(1, 16385, device='cuda'), 5)
+    with pytest.raises(ops.VphoError, match='k out of range'):
+        agg.topk(torch.rand(2, 100, device='cuda'), 101)
+    # batch of 1025 images: the cross module's sequence axis
+    with pytest.raises(ops.VphoError, match='<= 1024'):
+        ops.mha(torch.zeros(1025 * 2, 3 * 64, device='cuda'), 1025, 2, 64, 2)
     # hand physics: 16-byte LDS records per object vertex (ADVICE r3: the check said 12)
     fp = torch.zeros(1, 31, 32, 3, device='cuda')
     with pytest.raises(ops.VphoError, match='does not fit LDS'):

@@ -5,6 +5,7 @@
 //
 // Top-k order: larger value first, ties broken by the smaller candidate index (torch.topk leaves ties unspecified).
 #include "common.h"
+#include <cstdlib>
 #include "rot.h"
 #include "../../include/vpho_hip.h"
 
@@ -137,6 +138,27 @@ __global__ __launch_bounds__(64) void topk_kernel(const float* __restrict__ scor
     wave_topk(v, n, k, lane, val + (long long)row * k, idx + (long long)row * k);
 }
 
+// Rows beyond 1024 candidates (sample_num > 512: the reference has no limit, aggregation.py:217,246,777): one 256-thread workgroup per row
+// ranks by COUNTING, like hand_fuse_kernel -- candidate c's rank = the number of candidates that precede it in "larger value first, then
+// smaller index" order = its position in the stable descending sort, which is what k rounds of arg-max with that tie rule produce.
+__global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict__ scores, int n, int F, int k,
+                                                        float* __restrict__ val, int* __restrict__ idx) {
+    extern __shared__ float tk_v[];
+    const int row = blockIdx.x, b = row / F, f = row % F, tid = threadIdx.x;
+    for (int c = tid; c < n; c += 256) {
+        float sc = scores[((long long)b * n + c) * F + f];
+        if (sc != sc) sc = INFINITY;               // NaN ranks first, as in torch.topk
+        tk_v[c] = sc;
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+        const float v = tk_v[c];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const float o = tk_v[j]; rank += (o > v || (o == v && j < c)) ? 1 : 0; }
+        if (rank < k) { val[(long long)row * k + rank] = v; idx[(long long)row * k + rank] = c; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- hand cascade
 // candidates: [S diffusion | S regression copies] (aggregation.py:120-126); regression copies take the diffusion wrist
 // before level 0 (aggregation.py:140-143, quirk Q7)
@@ -251,6 +273,76 @@ __global__ __launch_bounds__(FUSE_THREADS) void hand_fuse_kernel(const FuseArgs 
     }
     __syncthreads();
     // broadcast the fused value into every candidate: x*0 + fused (NaN/Inf in x propagate like the reference)
+    for (int i = tid; i < a.C * 3; i += FUSE_THREADS) { float* p = P + (long long)(i / 3) * 48 + (i % 3); *p = *p * 0.f + s_aa[i % 3]; }
+}
+
+// The same cascade level without the size limits of hand_fuse_kernel (at most 1024 candidates, k <= 64): any candidate count that fits LDS
+// (16 000 per image) and any k <= C -- the reference has neither limit (aggregation.py:217,246: torch.topk of 2 x sample_num candidates,
+// topk_hand free).  Candidate scores, the k picks and their quaternions live in dynamic LDS; every sum runs in the order of
+// hand_fuse_kernel (the weight normaliser over ascending rank, the moment matrix entry by entry over ascending rank), so a launch
+// both kernels can serve gives the same bits from either (tests/test_gpu_edge_cases.py).
+__global__ __launch_bounds__(FUSE_THREADS) void hand_fuse_any_kernel(const FuseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fa_sm[];
+    float* s_v = fa_sm;                                  // [C]
+    float* s_val = s_v + ((a.C + 3) & ~3);               // [k]
+    float* s_w = s_val + a.k;                            // [k]
+    float* s_q = s_w + a.k;                              // [k][4]
+    int* s_idx = reinterpret_cast<int*>(s_q + 4 * a.k);  // [k]
+    __shared__ float s_A[16], s_aa[3];
+    const int F = a.level == 0 ? 1 : 5;
+    const int b = blockIdx.x / F, f = blockIdx.x % F, tid = threadIdx.x;
+    const int n_obs = a.level == 0 ? a.n_obs_total : a.n_obs_total / 5;
+    for (int c = tid; c < a.C; c += FUSE_THREADS) {
+        const float* h = a.hv + ((long long)b * a.C + c) * a.n_obs_total;
+        float sc = 0.f;
+        if (a.level == 0) { for (int o = 0; o < n_obs; ++o) sc += h[o]; }
+        else { for (int l = 0; l < n_obs; ++l) sc += h[l * 5 + f]; sc = sc / (float)n_obs; }
+        if (a.score_out) a.score_out[((long long)b * a.C + c) * F + f] = sc;
+        if (sc != sc) sc = INFINITY;
+        s_v[c] = sc;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += FUSE_THREADS) {
+        const float v = s_v[c];
+        int rank = 0;
+        for (int j = 0; j < a.C; ++j) { const float o = s_v[j]; rank += (o > v || (o == v && j < c)) ? 1 : 0; }
+        if (rank < a.k) { s_val[rank] = v; s_idx[rank] = c; }
+    }
+    __syncthreads();
+    const int joint = a.level == 0 ? 0 : a.jid[f];
+    float* P = a.pose + (long long)b * a.C * 48 + joint * 3;
+    float vsum = 0.f;
+    for (int i = 0; i < a.k; ++i) vsum += s_val[i];
+    for (int r = tid; r < a.k; r += FUSE_THREADS) {
+        const float* aa = P + (long long)s_idx[r] * 48;
+        const float ax[3] = {aa[0], aa[1], aa[2]};
+        float q[4];
+        vpho::axis_angle_to_quaternion(ax, q);
+        const float sg = q[0] > 0.f ? 1.f : -1.f;
+        for (int i = 0; i < 4; ++i) s_q[4 * r + i] = q[i] * sg;
+        s_w[r] = (s_val[r] + 1e-8f) / (vsum + 1e-8f);
+        a.val[((long long)b * F + f) * a.k + r] = s_val[r];
+        a.idx[((long long)b * F + f) * a.k + r] = s_idx[r];
+        if (a.topk_pose) { float* tp = a.topk_pose + (((long long)b * a.k + r) * F + f) * 3; tp[0] = ax[0]; tp[1] = ax[1]; tp[2] = ax[2]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int i = tid >> 2, j = tid & 3;
+        float acc = 0.f, wsum = 0.f;
+        for (int r = 0; r < a.k; ++r) { acc += (s_q[4 * r + i] * s_q[4 * r + j]) * s_w[r]; wsum += s_w[r]; }
+        s_A[tid] = acc / wsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float A[4][4], qa[4], aa[3];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) A[i][j] = s_A[i * 4 + j];
+        vpho::sym4_top_eigenvector(A, qa);
+        const float sg = qa[0] > 0.f ? 1.f : -1.f;
+        for (int i = 0; i < 4; ++i) qa[i] *= sg;
+        vpho::quaternion_to_axis_angle(qa, aa);
+        s_aa[0] = aa[0]; s_aa[1] = aa[1]; s_aa[2] = aa[2];
+    }
+    __syncthreads();
     for (int i = tid; i < a.C * 3; i += FUSE_THREADS) { float* p = P + (long long)(i / 3) * 48 + (i % 3); *p = *p * 0.f + s_aa[i % 3]; }
 }
 
@@ -584,8 +676,8 @@ extern "C" int vpho_hand_heat_f32(const float* joints, const float* root, const 
 extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose, int bs, int C, int k, int level,
                                         float* val, int* idx, float* topk_pose, float* score_out, void* stream) {
     VPHO_REQUIRE(hv && pose && val && idx && bs > 0 && C > 0 && level >= 0 && level <= 3, "vpho_hand_fuse_level_f32: bad argument");
-    VPHO_REQUIRE(k > 0 && k <= C && k <= 64, "selected index k out of range (topk_hand=%d, candidates=%d, max 64)", k, C);
-    VPHO_REQUIRE(C <= 64 * TOPK_MAX_SLOTS, "vpho_hand_fuse_level_f32: at most %d candidates per image", 64 * TOPK_MAX_SLOTS);
+    VPHO_REQUIRE(k > 0 && k <= C, "selected index k out of range (topk_hand=%d, candidates=%d)", k, C);
+    VPHO_REQUIRE(C <= 16000, "vpho_hand_fuse_level_f32: at most 16000 candidates per image (got %d)", C);
     VPHO_REQUIRE(level == 0 || n_obs % 5 == 0, "vpho_hand_fuse_level_f32: n_obs must be a multiple of 5 for finger levels");
     static const int jid[4][5] = {{0, 0, 0, 0, 0}, {13, 1, 4, 10, 7}, {14, 2, 5, 11, 8}, {15, 3, 6, 12, 9}};   // MANO_PARAMS_LEVEL // 3
     FuseArgs a;
@@ -596,6 +688,15 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
     vpho::ProfScope prof(vpho::PROF_HAND_FUSE, (hipStream_t)stream, 0.0,
                          (double)bs * C * ((double)n_obs * 4 + (level == 0 ? 3 : 15) * 4) + (double)bs * (level == 0 ? 1 : 5) * k * 8);
     const dim3 grid(bs * (level == 0 ? 1 : 5));
+    const char* any_env = getenv("VPHO_FUSE_ANY");                  // 1: the limit-free kernel for every launch (tests: same bits)
+    if (C > 64 * TOPK_MAX_SLOTS || k > 64 || (any_env && atoi(any_env))) {
+        const size_t lds = (size_t)(((C + 3) & ~3) + 7 * k) * sizeof(float);
+        VPHO_REQUIRE(lds <= 150 * 1024, "vpho_hand_fuse_level_f32: %d candidates with k = %d do not fit LDS", C, k);
+        static bool opt_in = false;
+        if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hand_fuse_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
+        hipLaunchKernelGGL(hand_fuse_any_kernel, grid, dim3(FUSE_THREADS), lds, (hipStream_t)stream, a);
+        return vpho::check_launch("hand_fuse_any_kernel");
+    }
     if (C <= FUSE_THREADS) hipLaunchKernelGGL(hand_fuse_kernel<1>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
     else if (C <= 2 * FUSE_THREADS) hipLaunchKernelGGL(hand_fuse_kernel<2>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(hand_fuse_kernel<4>, grid, dim3(FUSE_THREADS), 0, (hipStream_t)stream, a);
@@ -605,9 +706,10 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
 extern "C" int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, int k, float* val, int* idx, void* stream) {
     VPHO_REQUIRE(scores && val && idx && rows_outer > 0 && n > 0 && F > 0, "vpho_topk_f32: bad argument");
     VPHO_REQUIRE(k > 0 && k <= n, "selected index k out of range (k=%d, candidates=%d)", k, n);
-    VPHO_REQUIRE(n <= 64 * TOPK_MAX_SLOTS, "vpho_topk_f32: at most %d candidates per row", 64 * TOPK_MAX_SLOTS);
+    VPHO_REQUIRE(n <= 16384, "vpho_topk_f32: at most 16384 candidates per row (got %d)", n);
     if (n <= 512) hipLaunchKernelGGL(topk_kernel<8>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
-    else hipLaunchKernelGGL(topk_kernel<16>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
+    else if (n <= 64 * TOPK_MAX_SLOTS) hipLaunchKernelGGL(topk_kernel<16>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
+    else hipLaunchKernelGGL(topk_rank_kernel, dim3(rows_outer * F), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, scores, n, F, k, val, idx);
     return vpho::check_launch("topk_kernel");
 }
 

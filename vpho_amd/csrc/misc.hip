@@ -365,6 +365,9 @@ __global__ __launch_bounds__(256) void mha_generic_kernel(const float* __restric
 // Requires hd % 4 == 0 and hd <= 256.
 // drop (optional, training): [B*nhead][S][S] keep-mask already scaled by 1 / (1 - p) -- nn.MultiheadAttention's dropout on the
 // attention probabilities (after the soft-max, before P V)
+// NSLOT = 64-key slots a lane holds: 4 (S <= 256, every configuration of the reference's scripts) or 16 (S <= 1024: the sequence axis is
+// the BATCH axis, quirk Q3, and the reference has no limit on it).  With NSLOT = 4 the arithmetic is what it always was.
+template <int NSLOT>
 __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv, int S, int B, int E, int nhead, float* __restrict__ out,
                                                   const float* __restrict__ drop) {
     const int hd = E / nhead;
@@ -382,9 +385,9 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) qrow[qi] = base + (long long)min(q0 + qi, S - 1) * rs;
 
-    float p[4][4];                                   // [slot][query]
+    float p[NSLOT][4];                               // [slot][query]
 #pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
+    for (int slot = 0; slot < NSLOT; ++slot) {
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) p[slot][qi] = -INFINITY;
         if (slot < nslot) {
@@ -411,11 +414,11 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
     for (int qi = 0; qi < 4; ++qi) {
         float mx = -INFINITY;
 #pragma unroll
-        for (int slot = 0; slot < 4; ++slot) mx = fmaxf(mx, p[slot][qi]);
+        for (int slot = 0; slot < NSLOT; ++slot) mx = fmaxf(mx, p[slot][qi]);
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
 #pragma unroll
-        for (int slot = 0; slot < 4; ++slot) {
+        for (int slot = 0; slot < NSLOT; ++slot) {
             const int t = slot * 64 + lane;
             p[slot][qi] = t < S ? expf(p[slot][qi] - mx) : 0.f;
             sum += p[slot][qi];
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
         if (drop && q0 + qi < S) {
             const float* dm = drop + ((long long)bh * S + (q0 + qi)) * S;
 #pragma unroll
-            for (int slot = 0; slot < 4; ++slot) {
+            for (int slot = 0; slot < NSLOT; ++slot) {
                 const int t = slot * 64 + lane;
                 if (t < S) p[slot][qi] *= dm[t];
             }
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ qkv,
         for (int c = 0; c < 4; ++c) acc[qi][c] = 0.f;
     const float* vbase = base + 2 * E;
 #pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
+    for (int slot = 0; slot < NSLOT; ++slot) {
         if (slot < nslot) {
             const int tmax = min(64, S - slot * 64);
             for (int tl = 0; tl < tmax; ++tl) {
@@ -650,12 +653,15 @@ extern "C" int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_o
 }
 
 extern "C" int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int nhead, const float* drop_mask, float* out, void* stream) {
-    VPHO_REQUIRE(qkv && out && S > 0 && S <= 256 && B > 0 && nhead > 0 && E % nhead == 0, "vpho_mha_f32: bad argument (sequence = batch axis, quirk Q3, must be <= 256; got %d)", S);
+    VPHO_REQUIRE(qkv && out && S > 0 && S <= 1024 && B > 0 && nhead > 0 && E % nhead == 0, "vpho_mha_f32: bad argument (sequence = batch axis, quirk Q3, must be <= 1024; got %d)", S);
     const int hd = E / nhead;
     if (hd % 4 == 0 && hd <= 256 && E % 4 == 0) {
-        hipLaunchKernelGGL(mha_kernel, dim3((unsigned)(B * nhead * ((S + 15) / 16))), dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out, drop_mask);
+        const dim3 grid((unsigned)(B * nhead * ((S + 15) / 16)));
+        if (S <= 256) hipLaunchKernelGGL(mha_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out, drop_mask);
+        else          hipLaunchKernelGGL(mha_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, qkv, S, B, E, nhead, out, drop_mask);
         return vpho::check_launch("mha_kernel");
     }
+    VPHO_REQUIRE(S <= 256, "vpho_mha_f32: head_dim %d is served for sequences (= batch sizes, quirk Q3) up to 256 only; got %d", hd, S);
     VPHO_REQUIRE(drop_mask == nullptr, "vpho_mha_dropout_f32: the dropout mask needs head_dim %% 4 == 0 and head_dim <= 256 (got %d)", hd);
     size_t lds = (size_t)(S * (hd + 1) + S * hd) * sizeof(float);
     const int use_lds = lds <= 150 * 1024;
