@@ -499,14 +499,18 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         for (int sl = 0; sl <= img_last - img0; ++sl) Cb[sl * CB_LD + j] = a.cimg[(long long)(img0 + sl) * a.NH + n * 256 + j];
     }
 
-    // scalars of the epilogue's last step, requested now (a dependent chain of global loads behind the tile's last barrier otherwise)
-    float hd_inv_std = a.inv_std_den, hd_coef = a.coef;
+    // scalars of the epilogue's last step, requested now (a dependent chain of global loads behind the tile's last barrier otherwise).
+    // (Only on the CB path: the global-load instantiation -- sample_num < 64, tiny launches -- is 2 registers short of keeping them.)
+    float hd_inv_std = a.inv_std_den, hd_coef = a.coef, hd_b2 = 0.f;
     float* hd_out = a.out;
-    if (a.ctl && a.ctl_mode == 1) {
-        hd_inv_std = a.ctl->inv_std[a.stage]; hd_coef = a.ctl->coef[a.stage];
-        hd_out = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
-    }
-    const float hd_b2 = a.b2[n * 3 + tid % 3];
+    auto epilogue_scalars = [&]() {
+        if (a.ctl && a.ctl_mode == 1) {
+            hd_inv_std = a.ctl->inv_std[a.stage]; hd_coef = a.ctl->coef[a.stage];
+            hd_out = a.kbase + (long long)kslot(a.out_slot, a.ctl->kswap) * a.n_el;
+        }
+        hd_b2 = a.b2[n * 3 + tid % 3];
+    };
+    if (CB) epilogue_scalars();
 
     // tiles through buffer resources: per-lane byte offsets are loop constants, the k advance is the instruction's scalar offset;
     // hypothesis rows beyond R (or beyond the tile) carry an out-of-range offset (the hardware writes zeros)
@@ -611,6 +615,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     // 128 threads (two of the eight waves: 24 strided LDS reads, three 4-byte stores 384 B apart and three divisions each, behind two
     // dependent global loads of the controller's scalars): 5.7 us of a 62-us tile life with six waves idle (profiles/r05_inkernel_clock.txt).
     // The scalars and b2 are fetched at the kernel's start now (hd_inv_std, hd_coef, hd_out, hd_b2).  Same sums in the same order.
+    if (!CB) epilogue_scalars();
     if (tid < 3 * ROWS) {
         const int rl = tid / 3, dd = tid - 3 * rl, orow = r0 + rl;
         if (orow < a.R) {
