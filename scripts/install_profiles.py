@@ -1,4 +1,5 @@
-"""Copy the summaries scripts/profile_round.sh left under gpurun_out/ (r02b_*) into profiles/ with their command headers."""
+"""Copy the summaries scripts/profile_round.sh left under gpurun_out/ (<tag>_*) into profiles/ with their command headers:
+    python scripts/install_profiles.py r05 r05b     (PART=cfg2 files are required, cfg4 / train / force files are installed when present)"""
 import json, shutil, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 tag = sys.argv[2] if len(sys.argv) > 2 else rnd + 'b'
@@ -32,3 +33,35 @@ print('head:', d['roofline']['score_head'])
 print('hbm:', {k: (round(v['GB/s']), round(v['frac'], 3), round(v['avg_launch_us'], 1)) for k, v in d['hbm']['kernels'].items()})
 print('cpu:', d['cpu_baseline']); p = d['parity']
 print({k: v for k, v in p['end_to_end_vs_oracle'].items() if k != 'per_stage'}); print({k: v for k, v in p['aggregation_given_identical_candidates'].items() if k != 'per_stage'})
+
+# ---- the other configurations (profile_round.sh PART="cfg4 train force"), installed when their files exist
+def _copy(src, dst, header=None):
+    if not os.path.exists(g + src):
+        return False
+    body = open(g + src).read()
+    open('profiles/' + dst, 'w').write((header + '\n' if header else '') + body)
+    return True
+
+
+if _copy(tag + '_bench_cfg4.json', f'{rnd}_bench_cfg4.json'):
+    _copy(tag + '_cfg4_stats.txt', f'{rnd}_kernel_stats_bench_cfg4.txt',
+          f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --bs 128 --sample_num 256 --sampling_steps 100 --steps 4 --warmup 2 --no_cpu_baseline --no_opt_in --no_kernel_timing --pipeline 1   (MI355X, {rnd}; BASELINE configs[3]; bench line: profiles/{rnd}_bench_cfg4.json)')
+    c4 = json.load(open(g + tag + '_bench_cfg4.json'))
+    print('cfg4:', c4['metric'], round(c4['value'], 1), round(c4['ms_per_step'], 2), 'head', c4['roofline']['score_head']['samplers_serialised'], 'pose encoder', c4['roofline'].get('pose_encoder'))
+for bs_tag in ('', '_bs32'):
+    if _copy(tag + f'_train_step{bs_tag}.json', f'{rnd}_train_step{bs_tag}.json'):
+        t = json.load(open(g + tag + f'_train_step{bs_tag}.json'))
+        print(f'train{bs_tag}:', round(t['value'], 1), round(t['ms_per_step'], 2), (t.get('roofline') or {}).get('frac'), (t.get('roofline') or {}).get('traffic'))
+_copy(tag + '_train_stats.txt', f'{rnd}_train_step_kernel_stats.txt',
+      f'# VPHO_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python3 train.py --steps 5 --warmup 2   (MI355X, {rnd}; ONE stream, so durations are exclusive; steady state = the last 370 ms; then the idle-gap analysis of scripts/rocpd_gaps.py)')
+_copy(tag + '_train_stats_bs32.txt', f'{rnd}_train_step_bs32_kernel_stats.txt',
+      f'# VPHO_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python3 train.py --bs 32 --steps 5 --warmup 2   (MI355X, {rnd}; cfg3\'s own per-GPU batch; one stream; steady state = the last 200 ms)')
+if os.path.exists(g + tag + '_train_pmc_hbm.json'):
+    shutil.copy(g + tag + '_train_pmc_hbm.json', f'profiles/{rnd}_train_pmc_hbm_traffic.json')
+    _copy(tag + '_train_pmc_hbm.txt', f'{rnd}_train_pmc_hbm_traffic.txt', f'# HBM traffic per launch of one training step (two rocprofv3 --pmc passes: FETCH_SIZE; WRITE_SIZE) of  VPHO_WGRAD_STREAM=0 python3 train.py --steps 1 --warmup 1 --no_roofline  ({rnd}; (2*FETCH_SIZE + WRITE_SIZE)*1024 B)')
+if _copy(tag + '_force_optim.json', f'{rnd}_force_optim.json'):
+    f = json.load(open(g + tag + '_force_optim.json'))
+    print('force:', round(f['value'], 1), f.get('unit'), (f.get('roofline') or {}).get('frac'), (f.get('roofline') or {}).get('traffic'))
+if os.path.exists(g + tag + '_fo_pmc_hbm.json'):
+    shutil.copy(g + tag + '_fo_pmc_hbm.json', f'profiles/{rnd}_force_pmc_hbm_traffic.json')
+    _copy(tag + '_fo_pmc_hbm.txt', f'{rnd}_force_pmc_hbm_traffic.txt', f'# HBM traffic per launch of  python3 force_optim.py --pairs 10048  (two rocprofv3 --pmc passes, {rnd})')
