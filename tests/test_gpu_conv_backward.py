@@ -97,6 +97,62 @@ def test_batchnorm_training_mode_matches_autograd(N, H, W, C, slope):
     np.testing.assert_allclose(dbet.cpu().numpy(), beta.grad.numpy(), atol=tol(beta.grad), rtol=1e-4)
 
 
+@pytest.mark.parametrize('rows,C', [(64 * 32 * 32, 64), (64 * 64 * 64, 256), (4 * 16 * 12, 33), (3, 8), (64 * 16 * 16, 1024)])
+def test_in_launch_finish_of_the_column_reductions_equals_the_finishing_kernels(rows, C, monkeypatch):
+    """The workgroup that draws the last arrival ticket of its column block finishes the block's channels inside the reduction launch
+    (train_score.hip::col_reduce_kernel, VPHO_COL_FINISH=fused; the default stays the separate finishing kernels, which measured
+    faster inside the training step).  Same chunk order as the finishing kernels: bit for bit the same
+    statistics / gradients / column sums -- on the first launch of a stream, on repeated launches (the tickets go back to zero) and on
+    two streams whose launches overlap."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).cuda()
+    dy = torch.randn(rows, C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    rm0, rv0 = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+
+    def run():
+        rm, rv = rm0.clone(), rv0.clone()
+        y, saved = ops.bn_train_forward(x, gamma, beta, rm, rv, slope=0.01)
+        dx, dgam, dbet = ops.bn_train_backward(x, dy, gamma, saved)
+        return [y, saved[0], saved[1], rm, rv, dx, dgam, dbet, ops.colsum(dy)]
+
+    monkeypatch.setenv('VPHO_COL_FINISH', 'separate')
+    want = run()
+    monkeypatch.setenv('VPHO_COL_FINISH', 'fused')
+    for _ in range(3):
+        got = run()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(4):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(run())
+    torch.cuda.synchronize()
+    for got in outs:
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('N,H,W,cin,cout', [(64, 64, 64, 64, 256), (64, 32, 32, 128, 512), (16, 32, 32, 64, 64), (64, 16, 16, 1024, 256)])
+def test_weight_gradient_with_many_pixel_slices_is_deterministic_and_exact_to_rounding(N, H, W, cin, cout):
+    """Small dW, many pixel slices (up to 256): the slices are summed by 4 or 16 threads per quad (each ascending over its slices, then
+    ascending over the threads; conv_wgrad.hip::wgrad_reduce_grouped_kernel).  A fixed order: repeated launches are bit-identical, and
+    the result is the fp64 product to fp32 rounding."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(N + cin)
+    x = torch.randn(N, H, W, cin, generator=g).cuda()
+    dy = torch.randn(N, H, W, cout, generator=g).cuda()
+    got = ops.conv2d_wgrad_nhwc(x, dy, 1, 1, 1, 0, 0)
+    for _ in range(3):
+        assert torch.equal(ops.conv2d_wgrad_nhwc(x, dy, 1, 1, 1, 0, 0), got)
+    ref = dy.reshape(-1, cout).double().t() @ x.reshape(-1, cin).double()
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize('tag,stride', [('id', 1), ('down', 2)])
 def test_bottleneck_training_step_matches_reference_module(tag, stride):
     """Training-mode forward + backward of a whole Bottleneck (conv/BN(train)/LeakyReLU x3, shortcut, residual) vs the

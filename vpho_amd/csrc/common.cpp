@@ -1,4 +1,5 @@
 #include "common.h"
+#include <map>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -24,6 +25,24 @@ void prof_record(int cls, hipEvent_t a, hipEvent_t b, double flops, double bytes
     g_prof[cls].ev.emplace_back(a, b);
     g_prof[cls].flops += flops;
     g_prof[cls].bytes += bytes;
+}
+
+// Arrival tickets of the in-launch reductions ("the workgroup that draws the last ticket of its group finishes the sum"): one zeroed
+// array of TICKET_SLOTS ints per (device, stream).  Launches of one stream run one after the other and every kernel puts its tickets
+// back to zero before it ends, so a stream needs one array; launches of different streams may overlap and never share one.
+static std::map<std::pair<int, hipStream_t>, int*> g_tickets;
+static std::mutex g_tickets_mu;
+int* tickets_for(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(g_tickets_mu);
+    auto it = g_tickets.find({dev, s});
+    if (it != g_tickets.end()) return it->second;
+    int* p = nullptr;
+    if (hipMalloc(&p, TICKET_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, TICKET_SLOTS * sizeof(int), s) != hipSuccess) { (void)hipFree(p); return nullptr; }     // ordered before the first use, which is on s
+    g_tickets[{dev, s}] = p;
+    return p;
 }
 }  // namespace vpho
 

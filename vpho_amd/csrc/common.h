@@ -28,6 +28,9 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(e1, s); prof_record(cls, e0, e1, flops, bytes); } }
 };
+// zeroed arrival-ticket array of a stream (common.cpp); nullptr when it cannot be allocated
+constexpr int TICKET_SLOTS = 4096;
+int* tickets_for(hipStream_t s);
 }  // namespace vpho
 
 #define VPHO_REQUIRE(cond, ...) do { if (!(cond)) return vpho::fail(__VA_ARGS__); } while (0)

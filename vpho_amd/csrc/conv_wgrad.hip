@@ -205,6 +205,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(part)[(long long)k * n4 + i];
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
+// The same sum for a SMALL dW cut into MANY slices (1x1 64 -> 256 on 64 x 64 maps: 4 096 quads x 256 slices -- the kernel above is 16
+// workgroups whose threads walk 256 dependent-latency loads): G threads share a quad, thread g sums the slices g, g + G, ... in
+// ascending order, the G sums are combined in ascending g.  A fixed order for a given (slices, G), hence deterministic; not the order
+// of the kernel above (which order a shape takes is decided by wgrad_reduce_groups from its sizes alone).
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float* __restrict__ part, int splits, long long n4, float* __restrict__ out) {
+    constexpr int Q = 256 / G;
+    __shared__ f32x4 red[G][Q];
+    const int q = threadIdx.x % Q, g = threadIdx.x / Q;
+    const long long i = (long long)blockIdx.x * Q + q;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) for (int k = g; k < splits; k += G) s += reinterpret_cast<const f32x4*>(part)[(long long)k * n4 + i];
+    red[g][q] = s;
+    __syncthreads();
+    if (g != 0 || i >= n4) return;
+    for (int k = 1; k < G; ++k) s += red[k][q];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+// threads per quad: 1 (the plain kernel) while it already fills the chip or the slices are few
+inline int wgrad_reduce_groups(int splits, long long n4) {
+    if (splits < 8 || n4 >= 256ll * 1024) return 1;
+    return splits >= 32 && n4 < 64ll * 1024 ? 16 : 4;
+}
 
 // ordered list of the live groups of BK consecutive pixels of an (N, H, W) map: group g is live when one of its pixels lies in the
 // window (y0, x0, w, h) of its image (vpho_roi_windows_i32's table).  One workgroup: every thread counts its run of consecutive
@@ -332,7 +355,11 @@ static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, 
     else hipLaunchKernelGGL((conv_wgrad_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
     if (p.splits > 1) {
         const long long n4 = (long long)Cout * a.K / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, p.splits, n4, dw);
+        static const int g_env = getenv("VPHO_WGRAD_REDUCE_GROUPS") ? atoi(getenv("VPHO_WGRAD_REDUCE_GROUPS")) : 0;      // tuning aid: 1 / 4 / 16
+        const int G = g_env == 1 || g_env == 4 || g_env == 16 ? g_env : wgrad_reduce_groups(p.splits, n4);
+        if (G == 16) hipLaunchKernelGGL(wgrad_reduce_grouped_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)workspace, p.splits, n4, dw);
+        else if (G == 4) hipLaunchKernelGGL(wgrad_reduce_grouped_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, (const float*)workspace, p.splits, n4, dw);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, p.splits, n4, dw);
     }
     return vpho::check_launch("conv_wgrad_tn_kernel");
 }
