@@ -235,6 +235,12 @@ VPHO_API int vpho_resize_bilinear_rows_nhwc_f32(const float* x, int N, int H, in
 VPHO_API int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
                                    float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off, int rows_hint,
                                    void* stream);
+/* the same pooling pass with TWO destinations (each with its own optional W-flip flags): the object branch pools bbox_obj_rect twice,
+ * plain for the heat-map head and flipped for left hands into the encoder input (VPHO.py:126-138) -- one read of the map, values
+ * bit-identical to two vpho_roi_align_window_nhwc_f32 calls */
+VPHO_API int vpho_roi_align_window_dual_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
+                                        float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
+                                        const unsigned char* flip_w2, float* out2, int ldo2, int c_off2, int rows_hint, void* stream);
 /* align_hm_to_bbox_rectangle (VPHO.py:333-346, transposing, quirk Q2) (+ optional W flip, VPHO.py:139) */
 VPHO_API int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                 const unsigned char* flip_w, float* out, void* stream);

@@ -10,7 +10,7 @@ a = synthetic_assets(0); m = vpho_net(a); sd = bench_state_dict(m, 1)
 dev = 'cuda'
 for name, D in (('hand', 96), ('obj', 9)):
     net = ops.ScoreNet(sd, f'denoiser_{name}', dev)
-    bs, S = 64, 100
+    bs, S = int(os.environ.get('PE_BS', 64)), int(os.environ.get('PE_S', 100))          # cfg4: PE_BS=128 PE_S=256
     feat = torch.randn(bs, 1024, device=dev) * 0.3
     x = torch.randn(bs * S, D, device=dev)
     for _ in range(40): net.score(feat, x, 0.3, S)

@@ -132,6 +132,12 @@ def test_roi_windows_give_bit_identical_roi_align(C, k):
                 ref = ops.roi_align_nhwc(full, boxes, R, 0.25, flip_w=fl)
                 got = ops.roi_align_nhwc(rows, boxes, R, 0.25, flip_w=fl, win=win)
                 assert torch.equal(got, ref)
+        # one pooling pass, two destinations (the object branch: plain crop + flipped crop into a wider buffer at a channel offset)
+        wide = torch.full((N, R, R, C + 8), -3.0).cuda()
+        plain = ops.roi_align_dual_nhwc(rows, ba, R, 0.25, win, wide, flip_w2=flip, c_off2=4)
+        assert torch.equal(plain, ops.roi_align_nhwc(full, ba, R, 0.25))
+        assert torch.equal(wide[..., 4:4 + C], ops.roi_align_nhwc(full, ba, R, 0.25, flip_w=flip))
+        assert bool((wide[..., :4] == -3.0).all()) and bool((wide[..., 4 + C:] == -3.0).all())
     # a box whose window is the whole map: every pixel listed once, in order
     whole = torch.tensor([[0.0, 0.0, 256.0, 256.0]] * N).cuda()
     win = ops.roi_windows(whole, None, N, H, W, 0.25)

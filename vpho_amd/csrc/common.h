@@ -46,6 +46,19 @@ int* tickets_for(hipStream_t s);
 // (lgkmcnt(0)), LDS-DMA tiles are covered by the caller's own counted vmcnt wait.  Global memory is NOT ordered by it.
 #define VPHO_BARRIER_LDS_ONLY() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Wave priority around the main loop of the chip-filling kernels (two workgroups share a CU: one's epilogue -- vector ALU, LDS, stores --
+// runs beside the other's matrix loop; the SIMD's arbiter otherwise serves the OLDER wave first, i.e. the one in its epilogue).
+#ifndef VPHO_MAINLOOP_PRIO
+#define VPHO_MAINLOOP_PRIO 0
+#endif
+#if VPHO_MAINLOOP_PRIO
+#define VPHO_PRIO_MAIN() __builtin_amdgcn_s_setprio(VPHO_MAINLOOP_PRIO)
+#define VPHO_PRIO_REST() __builtin_amdgcn_s_setprio(0)
+#else
+#define VPHO_PRIO_MAIN() ((void)0)
+#define VPHO_PRIO_REST() ((void)0)
+#endif
+
 // F.interpolate(mode='bilinear', align_corners=False): src = max((dst+0.5)*scale-0.5, 0), scale = in/out
 __device__ inline void lin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     float s = ((float)dst + 0.5f) * scale - 0.5f;

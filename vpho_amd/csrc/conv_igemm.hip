@@ -607,6 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
         }
     };
     VPHO_STAMP_AT(2);
+    VPHO_PRIO_MAIN();
     for (int kt = 0; kt + 1 < nk; ++kt) {
         if (kt > 0 || (g.dbg & 16)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
         compute(kt);
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     if (res_early) { if (d.res_up) load_res_up(); else load_res(); __builtin_amdgcn_sched_barrier(0); }
     compute(nk - 1);
     VPHO_SYNC_LDS_DMA();
+    VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
 
     if (g.vec_epilogue) {
@@ -852,6 +854,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         else        { if (first) VPHO_WAIT_VM(0);  else VPHO_WAIT_VM(NIT); }
         VPHO_BARRIER_LDS_ONLY();                                    // (not __syncthreads(): its fence would wait for the previous tile's stores)
         if (first) VPHO_STAMP_AT(2);
+        VPHO_PRIO_MAIN();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -882,6 +885,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         // in front of the next tile's fills instead of in the epilogue, where it would wait for those fills too)
 #pragma unroll
         for (int k = 0; k < NIT; ++k) asm volatile("" :: "v"(rv[k]));
+        VPHO_PRIO_REST();
         if (first) VPHO_STAMP_AT(3);
         // ---- next tile: its first two stages are requested BEFORE this tile's epilogue
         const int em0 = m0, en0 = n0, etp = tp;

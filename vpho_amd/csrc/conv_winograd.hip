@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         }
     };
     VPHO_STAMP_AT(2);
+    VPHO_PRIO_MAIN();
     for (int ss = 0; ss < nss; ++ss) {
         const int ssn = ss + 1 < nss ? ss + 1 : ss;
         stage(2 * ss, 0, ssn);
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
     }
+    VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel

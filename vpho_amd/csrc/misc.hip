@@ -147,7 +147,8 @@ __device__ inline void roi_bilinear(const float* __restrict__ f, int H, int W, i
 template <int V>
 __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int H, int W, int C, const float* __restrict__ boxes,
                                       float scale, int P, const unsigned char* __restrict__ flip_w,
-                                      float* __restrict__ out, int ldo, int c_off, const RoiWin* __restrict__ wins) {
+                                      float* __restrict__ out, int ldo, int c_off, const RoiWin* __restrict__ wins,
+                                      float* __restrict__ out2 = nullptr, int ldo2 = 0, int c_off2 = 0, const unsigned char* __restrict__ flip_w2 = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int CV = C / V;
     const long long total = (long long)N * P * P * CV;
@@ -180,6 +181,10 @@ __global__ void roi_align_nhwc_kernel(const float* __restrict__ feat, int N, int
 #pragma unroll
     for (int u = 0; u < V; ++u) acc[u] = acc[u] / cnt;
     stv<V>(out + (((long long)n * P + ph) * P + ow) * ldo + c_off + c, acc);
+    if (out2) {                                   // the same pooled values once more, under the second destination's own flip flags
+        const int ow2 = (flip_w2 && flip_w2[n]) ? P - 1 - pw : pw;
+        stv<V>(out2 + (((long long)n * P + ph) * P + ow2) * ldo2 + c_off2 + c, acc);
+    }
 }
 
 // RoI windows (demand-driven FPN output): RoIAlign is the only reader of the stride-4 FPN maps (VPHO.py:115,126-129), so the last
@@ -630,6 +635,22 @@ extern "C" int vpho_roi_align_window_nhwc_f32(const float* feat_rows, const int*
     else
         LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins);
     return vpho::check_launch("roi_align_nhwc_kernel(window)");
+}
+
+// One pooling pass, two destinations: the object branch reads the same boxes twice -- plain for the heat-map head, W-flipped for left
+// hands into the encoder input (VPHO.py:126-138) -- and the two crops differ only in where a pooled value is written.
+extern "C" int vpho_roi_align_window_dual_nhwc_f32(const float* feat_rows, const int* wins, int N, int H, int W, int C, const float* boxes,
+                                                   float spatial_scale, int out_size, const unsigned char* flip_w, float* out, int ldo, int c_off,
+                                                   const unsigned char* flip_w2, float* out2, int ldo2, int c_off2, int rows_hint, void* stream) {
+    VPHO_REQUIRE(feat_rows && wins && boxes && out && out2 && N > 0 && C > 0 && out_size > 0 && ldo >= c_off + C && c_off >= 0 && ldo2 >= c_off2 + C && c_off2 >= 0,
+                 "vpho_roi_align_window_dual_nhwc_f32: bad argument");
+    const double rows_read = rows_hint > 0 ? (double)rows_hint : (double)N * H * W;
+    vpho::ProfScope prof(vpho::PROF_ROI_ALIGN, (hipStream_t)stream, 0.0, 4.0 * C * (rows_read + 2.0 * N * out_size * out_size));
+    if (C % 4 == 0 && ldo % 4 == 0 && c_off % 4 == 0 && ldo2 % 4 == 0 && c_off2 % 4 == 0 && ((uintptr_t)feat_rows | (uintptr_t)out | (uintptr_t)out2) % 16 == 0)
+        LAUNCH1D(roi_align_nhwc_kernel<4>, (long long)N * out_size * out_size * (C / 4), stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins, out2, ldo2, c_off2, flip_w2);
+    else
+        LAUNCH1D(roi_align_nhwc_kernel<1>, (long long)N * out_size * out_size * C, stream, feat_rows, N, H, W, C, boxes, spatial_scale, out_size, flip_w, out, ldo, c_off, (const RoiWin*)wins, out2, ldo2, c_off2, flip_w2);
+    return vpho::check_launch("roi_align_nhwc_kernel(window, two destinations)");
 }
 
 extern "C" int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,

@@ -551,6 +551,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     VPHO_SYNC_LDS_DMA();
     fill(1, 1);
     VPHO_STAMP_AT(2);
+    VPHO_PRIO_MAIN();
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
@@ -577,6 +578,7 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
         mfmas();
     }
     __syncthreads();
+    VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
 
     // epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
@@ -611,6 +613,10 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     }
     VPHO_STAMP_AT(5);
     __syncthreads();
+    // (Round 5, measured no better on one box, 3 interleaved runs each: the combine WITHOUT this barrier -- the waves that share a row group
+    // draw an LDS ticket and the last one combines its 32 rows, 233-238 us against 234-237; s_setprio 1 / 3 around the main loop, 230 against
+    // 228-230 (scripts/build_prio.sh).  With the persistent variant below that is four ways of shortening a tile's life outside its main
+    // loop without moving the launch time: the 2 x 8 waves of a CU are bound by what they share, not by a workgroup's own serial parts.)
     // One output per thread: thread t -> (row t / 3, component t % 3), 3 x ROWS threads.  Round 4 gave a row's three components to ONE of
     // 128 threads (two of the eight waves: 24 strided LDS reads, three 4-byte stores 384 B apart and three divisions each, behind two
     // dependent global loads of the controller's scalars): 5.7 us of a 62-us tile life with six waves idle (profiles/r05_inkernel_clock.txt).
@@ -783,6 +789,7 @@ __global__ __launch_bounds__(512, 4) void score_head_pers_kernel(const HeadArgs 
         if (first) VPHO_WAIT_VMH(NF); else VPHO_WAIT_VMH(NF + 1);
         VPHO_BARRIER_LDS_ONLY();                                    // (not __syncthreads(): its fence would wait for the previous tile's store)
         if (first) VPHO_STAMP_AT(2);
+        VPHO_PRIO_MAIN();
         for (int kt = 0; kt < NK; ++kt) {
             const int buf = kt & 1;
             const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
@@ -811,6 +818,7 @@ __global__ __launch_bounds__(512, 4) void score_head_pers_kernel(const HeadArgs 
             mfmas();
         }
         __syncthreads();                                            // both stage buffers are free
+        VPHO_PRIO_REST();
         if (first) VPHO_STAMP_AT(3);
         // ---- next tile: tables into registers, then its first two stages, BEFORE this tile's epilogue
         const int en = n, er0 = r0, erows = rows;

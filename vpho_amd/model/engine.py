@@ -292,8 +292,11 @@ class Engine:
         tr = self._fpn_trunk(rgb)
         with self._side():                                                               # object branch
             obj_feat = self._fpn_branch('o', tr, windows)
-            of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, win=win_o)
-            ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o, win=win_o)   # VPHO.py:138
+            if win_o is not None:                                                        # one pooling pass, two destinations (VPHO.py:126-138)
+                of_or_rect = ops.roi_align_dual_nhwc(obj_feat, bb_or, R, 0.25, win_o, in_o, flip_w2=left_u8)
+            else:
+                of_or_rect = ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25)
+                ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o)           # VPHO.py:138
             hm_obj = self._hm_head(of_or_rect, self.hm['obj'])                           # (bs,64,64,27)
             ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_obj, bb_o, bb_or, flip_w=left_u8), R, R, out=in_o, c_off=256)
             enc_o, st_o = self._encoder(in_o, eo)

@@ -573,6 +573,18 @@ def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, 
     return out
 
 
+def roi_align_dual_nhwc(feat, boxes, out_size, spatial_scale, win, out2, flip_w2=None, c_off2=0):
+    """one pooling pass over the compact window matrix, two destinations: returns the plain crop (new tensor) and writes the same values
+    into ``out2`` at channel offset ``c_off2`` under ``flip_w2`` (vpho_roi_align_window_dual_nhwc_f32)"""
+    N, H, W = win.shape
+    Cc = feat.shape[-1]
+    out = _new((N, out_size, out_size, Cc), feat)
+    _call('vpho_roi_align_window_dual_nhwc_f32', _f32(feat), _ptr(win.wins, torch.int32), I(N), I(H), I(W), I(Cc), _f32(boxes),
+          F(spatial_scale), I(out_size), _u8(None), _f32(out), I(Cc), I(0), _u8(flip_w2), _f32(out2), I(out2.shape[-1]), I(c_off2),
+          I(int(win.count.item()) if _prof_on else 0))
+    return out
+
+
 def align_heatmap_nhwc(hm, bbox, bbox_rect, flip_w=None):
     N, S, _, Cc = hm.shape
     out = torch.empty_like(hm)
