@@ -533,8 +533,13 @@ VPHO_API int vpho_cross_tokens_bwd_f32(const float* dtok, int bs, float* d_proj_
 VPHO_API int vpho_layernorm_bwd_f32(const float* x, const float* r, const float* gamma, const float* dy, long long rows, int E, float eps,
                            float* dx, float* dy_xhat, void* stream);
 /* backward of vpho_mha_dropout_f32 (nn.MultiheadAttention inside the encoder layer, sequence axis = batch, quirk Q3):
- * qkv [S*B][3E], d_out [S*B][E], drop_mask as in the forward (NULL = none) -> dqkv [S*B][3E]; S <= 64 */
+ * qkv [S*B][3E], d_out [S*B][E], drop_mask as in the forward (NULL = none) -> dqkv [S*B][3E]; S <= 64 (one launch, tables in LDS) */
 VPHO_API int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv, void* stream);
+/* the same for S <= 1024 (a per-rank training batch above 64 images): above 64 positions three launches over a workspace of
+ * vpho_mha_bwd_workspace_bytes (two S x S tables per (b, head); 0 for S <= 64, which runs the one-launch kernel; -1 = bad argument) */
+VPHO_API long long vpho_mha_bwd_workspace_bytes(int S, int B, int nhead);
+VPHO_API int vpho_mha_bwd_ws_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv,
+                        void* workspace, void* stream);
 /* HeadPhysics tail + losses + gradient (physics.py:546-557 get_local_force with the double soft-max of :659-664, :362-371
  * from_local_to_global on the GROUND-TRUTH vertices, :456-500 get_loss; weights as VPHO.py:214-219): scale_raw [bs*32] (fc_scale
  * output), logits [bs*32][8] (fc_weight before its Softmax), com [bs*32][3] (fc_CoM output); frame [bs][32][3][3] / point

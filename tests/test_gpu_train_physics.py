@@ -79,10 +79,11 @@ def test_stage_map_gradients(run):
         assert np.abs(g[::101].numpy() - ref).max() < 2e-4 * np.abs(ref).max(), k
 
 
-@pytest.mark.parametrize('S,p', [(6, 0.0), (32, 0.1), (64, 0.3)])
+@pytest.mark.parametrize('S,p', [(6, 0.0), (32, 0.1), (64, 0.3), (65, 0.0), (100, 0.2), (192, 0.1)])
 def test_attention_forward_backward_with_dropout_mask_matches_autograd(S, p):
     """vpho_mha_dropout_f32 / vpho_mha_bwd_f32 (sequence axis = batch, 65 token slots x 2 heads) vs fp64 autograd of the same
-    attention written out with an explicit keep-mask / (1 - p) on the probabilities (nn.MultiheadAttention's dropout site)."""
+    attention written out with an explicit keep-mask / (1 - p) on the probabilities (nn.MultiheadAttention's dropout site).  Above 64
+    positions (a per-rank batch above 64 images) the backward is the three-launch form over a workspace (vpho_mha_bwd_ws_f32)."""
     from vpho_amd import ops
     B, E, H = 65, 512, 2
     hd = E // H

@@ -187,6 +187,143 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---- the same backward for LONGER sequences (the sequence axis is the batch, quirk Q3: a per-rank training batch above 64 images).
+// Three launches over a workspace of two S x S tables per (b, head) -- raw scores -> P, dP -> dS --, S <= 1024 like the forward kernel
+// (misc.hip::mha_kernel):  A  64 x 64 blocks of scl Q K^T and dO V^T (the register blocking of mha_bwd_kernel);  B  one wave per row:
+// soft-max, dropout mask, dS = P o (dP - rowsum(dP o P));  C  64-row blocks of dV = P^T dO, dQ = scl dS K, dK = scl dS^T Q, the tables
+// staged through LDS 64 x 64 at a time.  Sums ascending in the reduction index, fixed: deterministic.
+__global__ __launch_bounds__(256) void mha_bwd_scores_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, int S, int B, int E, int nhead,
+                                                             float* __restrict__ Pw, float* __restrict__ dPw) {
+    __shared__ float Qc[64][17], Kc[64][17], Gc[64][17], Vc[64][17];
+    const int hd = E / nhead, bh = blockIdx.z, b = bh / nhead, h = bh % nhead, tid = threadIdx.x;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const long long rs = (long long)B * 3 * E, ro = (long long)B * E;
+    const float* q = qkv + (long long)b * 3 * E + h * hd;
+    const float* k = q + E;
+    const float* v = q + 2 * E;
+    const float* go = dout + (long long)b * E + h * hd;
+    const float scl = 1.0f / sqrtf((float)hd);
+    const int ti = tid >> 4, tj = tid & 15, lr = tid >> 2, lc = (tid & 3) * 4;
+    float accA[4][4], accD[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { accA[u][w] = 0.f; accD[u][w] = 0.f; }
+    for (int c0 = 0; c0 < hd; c0 += 16) {
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, g4 = q4, v4 = q4;
+        if (c0 + lc < hd) {
+            if (i0 + lr < S) { q4 = *reinterpret_cast<const f32x4*>(q + (i0 + lr) * rs + c0 + lc); g4 = *reinterpret_cast<const f32x4*>(go + (i0 + lr) * ro + c0 + lc); }
+            if (j0 + lr < S) { k4 = *reinterpret_cast<const f32x4*>(k + (j0 + lr) * rs + c0 + lc); v4 = *reinterpret_cast<const f32x4*>(v + (j0 + lr) * rs + c0 + lc); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { Qc[lr][lc + u] = q4[u] * scl; Kc[lr][lc + u] = k4[u]; Gc[lr][lc + u] = g4[u]; Vc[lr][lc + u] = v4[u]; }
+        __syncthreads();
+        const int nc = hd - c0 < 16 ? hd - c0 : 16;
+        for (int c = 0; c < nc; ++c) {
+            float qv[4], kv[4], gv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { qv[u] = Qc[ti + 16 * u][c]; gv[u] = Gc[ti + 16 * u][c]; kv[u] = Kc[tj + 16 * u][c]; vv[u] = Vc[tj + 16 * u][c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { accA[u][w] += qv[u] * kv[w]; accD[u][w] += gv[u] * vv[w]; }
+        }
+        __syncthreads();
+    }
+    float* Pb = Pw + (long long)bh * S * S;
+    float* Db = dPw + (long long)bh * S * S;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int i = i0 + ti + 16 * u, j = j0 + tj + 16 * w;
+            if (i < S && j < S) { Pb[(long long)i * S + j] = accA[u][w]; Db[(long long)i * S + j] = accD[u][w]; }
+        }
+}
+// one wave per row (i, bh): lane l owns the columns l, l + 64, ... (<= 16 of them at S <= 1024)
+__global__ __launch_bounds__(256) void mha_bwd_softmax_kernel(int S, long long rows, const float* __restrict__ drop, float* __restrict__ Pw, float* __restrict__ dPw) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // = bh * S + i
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* Pr = Pw + row * S;
+    float* Dr = dPw + row * S;
+    float sc[16], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int j = lane + 64 * t; sc[t] = j < S ? Pr[j] : -INFINITY; mx = fmaxf(mx, sc[t]); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { sc[t] = lane + 64 * t < S ? expf(sc[t] - mx) : 0.f; sum += sc[t]; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    float dp[16], m[16], tt = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int j = lane + 64 * t;
+        sc[t] = sc[t] / sum;
+        m[t] = (drop && j < S) ? drop[row * S + j] : 1.f;
+        dp[t] = j < S ? Dr[j] * m[t] : 0.f;
+        tt += dp[t] * sc[t];
+    }
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int j = lane + 64 * t;
+        if (j < S) { Pr[j] = sc[t] * m[t]; Dr[j] = sc[t] * (dp[t] - tt); }
+    }
+}
+// block = 64 rows r of one (b, head); thread = (column c = tid & 63 (+ 64, ...), row group rq = tid >> 6: rows 16 rq .. 16 rq + 15)
+__global__ __launch_bounds__(256) void mha_bwd_grads_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, int S, int B, int E, int nhead,
+                                                            const float* __restrict__ Pw, const float* __restrict__ dSw, float* __restrict__ dqkv) {
+    __shared__ float Pt[64][65], St[64][65], Sr[64][65];     // P[i][r], dS[i][r] (i = reduction chunk, r = block row); dS[r][j] (j = reduction chunk)
+    const int hd = E / nhead, bh = blockIdx.y, b = bh / nhead, h = bh % nhead, tid = threadIdx.x;
+    const int r0 = blockIdx.x * 64, cl = tid & 63, rq = tid >> 6;
+    const long long rs = (long long)B * 3 * E, ro = (long long)B * E;
+    const float* q = qkv + (long long)b * 3 * E + h * hd;
+    const float* k = q + E;
+    const float* go = dout + (long long)b * E + h * hd;
+    float* dq = dqkv + (long long)b * 3 * E + h * hd;
+    float* dk = dq + E;
+    float* dv = dq + 2 * E;
+    const float* Pb = Pw + (long long)bh * S * S;
+    const float* Sb = dSw + (long long)bh * S * S;
+    const float scl = 1.0f / sqrtf((float)hd);
+    for (int c0 = 0; c0 < hd; c0 += 64) {
+        const int c = c0 + cl;
+        float aV[16], aQ[16], aK[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { aV[u] = 0.f; aQ[u] = 0.f; aK[u] = 0.f; }
+        for (int x0 = 0; x0 < S; x0 += 64) {                 // reduction chunk: i (dV, dK) or j (dQ) in [x0, x0 + 64)
+            __syncthreads();
+            for (int e = tid; e < 64 * 64; e += 256) {
+                const int a = e >> 6, bb = e & 63;           // tables read along their rows (bb fastest)
+                const bool in = x0 + a < S && r0 + bb < S;
+                Pt[a][bb] = in ? Pb[(long long)(x0 + a) * S + r0 + bb] : 0.f;
+                St[a][bb] = in ? Sb[(long long)(x0 + a) * S + r0 + bb] : 0.f;
+                Sr[a][bb] = (r0 + a < S && x0 + bb < S) ? Sb[(long long)(r0 + a) * S + x0 + bb] : 0.f;
+            }
+            __syncthreads();
+            if (c < hd) {
+                for (int x = 0; x < 64 && x0 + x < S; ++x) {
+                    const float gv = go[(long long)(x0 + x) * ro + c], kv = k[(long long)(x0 + x) * rs + c], qv = q[(long long)(x0 + x) * rs + c];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        aV[u] += Pt[x][16 * rq + u] * gv;
+                        aQ[u] += Sr[16 * rq + u][x] * kv;
+                        aK[u] += St[x][16 * rq + u] * qv;
+                    }
+                }
+            }
+        }
+        if (c < hd) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + 16 * rq + u;
+                if (r < S) { dv[(long long)r * rs + c] = aV[u]; dq[(long long)r * rs + c] = aQ[u] * scl; dk[(long long)r * rs + c] = aK[u] * scl; }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ physics losses
 struct PhysArgs {
     const float *scale_raw, *logits, *com;     // fc_scale output [bs*32], fc_weight logits [bs*32][8], fc_CoM output [bs*32][3]
@@ -301,12 +438,37 @@ extern "C" int vpho_layernorm_bwd_f32(const float* x, const float* r, const floa
     return vpho::check_launch("layernorm_bwd_kernel");
 }
 
+constexpr int MB_S_MAX = 1024;
+extern "C" long long vpho_mha_bwd_workspace_bytes(int S, int B, int nhead) {
+    if (S <= 0 || B <= 0 || nhead <= 0 || S > MB_S_MAX) return -1;
+    return S <= MB_S ? 0 : 2ll * B * nhead * S * S * 4;
+}
+
+extern "C" int vpho_mha_bwd_ws_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv,
+                                   void* workspace, void* stream) {
+    VPHO_REQUIRE(qkv && d_out && dqkv && S > 0 && B > 0 && nhead > 0 && E % nhead == 0 && (E / nhead) % 4 == 0, "vpho_mha_bwd_f32: bad argument");
+    VPHO_REQUIRE(S <= MB_S_MAX, "vpho_mha_bwd_f32: sequence (= batch, quirk Q3) of %d exceeds the %d positions of the attention kernels", S, MB_S_MAX);
+    hipStream_t s = (hipStream_t)stream;
+    if (S <= MB_S) {
+        hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * nhead), dim3(256), 0, s, qkv, d_out, S, B, E, nhead, dqkv, drop_mask);
+        return vpho::check_launch("mha_bwd_kernel");
+    }
+    VPHO_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0, "vpho_mha_bwd_ws_f32: %d positions need the workspace of vpho_mha_bwd_workspace_bytes", S);
+    VPHO_REQUIRE((long long)B * nhead <= 65535, "vpho_mha_bwd_ws_f32: B * nhead = %lld exceeds the grid", (long long)B * nhead);
+    float* Pw = (float*)workspace;
+    float* Dw = Pw + (long long)B * nhead * S * S;
+    const int nb = (S + 63) / 64;
+    hipLaunchKernelGGL(mha_bwd_scores_kernel, dim3(nb, nb, B * nhead), dim3(256), 0, s, qkv, d_out, S, B, E, nhead, Pw, Dw);
+    const long long rows = (long long)B * nhead * S;
+    hipLaunchKernelGGL(mha_bwd_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, rows, drop_mask, Pw, Dw);
+    hipLaunchKernelGGL(mha_bwd_grads_kernel, dim3(nb, B * nhead), dim3(256), 0, s, qkv, d_out, S, B, E, nhead, (const float*)Pw, (const float*)Dw, dqkv);
+    return vpho::check_launch("mha_bwd kernels (long sequence)");
+}
+
 extern "C" int vpho_mha_bwd_f32(const float* qkv, const float* d_out, int S, int B, int E, int nhead, const float* drop_mask, float* dqkv,
                                 void* stream) {
-    VPHO_REQUIRE(qkv && d_out && dqkv && S > 0 && B > 0 && nhead > 0 && E % nhead == 0 && (E / nhead) % 4 == 0, "vpho_mha_bwd_f32: bad argument");
-    VPHO_REQUIRE(S <= MB_S, "vpho_mha_bwd_f32: sequence (= batch, quirk Q3) of %d exceeds the %d positions of the training kernel", S, MB_S);
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * nhead), dim3(256), 0, (hipStream_t)stream, qkv, d_out, S, B, E, nhead, dqkv, drop_mask);
-    return vpho::check_launch("mha_bwd_kernel");
+    VPHO_REQUIRE(S <= MB_S, "vpho_mha_bwd_f32: sequence (= batch, quirk Q3) of %d exceeds the %d positions of the one-launch kernel: vpho_mha_bwd_ws_f32 takes up to %d", S, MB_S, MB_S_MAX);
+    return vpho_mha_bwd_ws_f32(qkv, d_out, S, B, E, nhead, drop_mask, dqkv, nullptr, stream);
 }
 
 extern "C" int vpho_physics_loss_f32(const float* scale_raw, const float* logits, const float* com, const float* anchor, float friction,

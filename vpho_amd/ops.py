@@ -20,6 +20,7 @@ lib.vpho_abi_version.restype = C.c_int
 lib.vpho_obj_metrics_workspace_bytes.restype = C.c_longlong
 lib.vpho_bn_workspace_bytes.restype = C.c_longlong
 lib.vpho_conv2d_wgrad_workspace_bytes.restype = C.c_longlong
+lib.vpho_mha_bwd_workspace_bytes.restype = C.c_longlong
 
 
 class VphoError(RuntimeError):
@@ -1180,7 +1181,11 @@ def layernorm_bwd(x, r, gamma, dy, eps=1e-5):
 
 def mha_bwd(qkv, d_out, S, B, E, nhead, drop=None):
     dqkv = torch.empty_like(qkv)
-    _call('vpho_mha_bwd_f32', _f32(qkv), _f32(d_out), I(S), I(B), I(E), I(nhead), _f32(drop), _f32(dqkv))
+    need = lib.vpho_mha_bwd_workspace_bytes(I(S), I(B), I(nhead))
+    if need < 0:
+        raise VphoError(f'vpho_mha_bwd_workspace_bytes: bad argument (S={S}, B={B}, nhead={nhead}; at most 1024 positions)')
+    ws = torch.empty(need, dtype=torch.uint8, device=qkv.device) if need > 0 else None
+    _call('vpho_mha_bwd_ws_f32', _f32(qkv), _f32(d_out), I(S), I(B), I(E), I(nhead), _f32(drop), _f32(dqkv), _ptr(ws))
     return dqkv
 
 
