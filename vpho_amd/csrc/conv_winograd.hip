@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // stage of a super-stage the 16 patch loads of the next super-stage (groups 2-5), the row transform (group 11) and one frequency row
     // of the column transform + its 4 LDS writes (groups 12-15).  Branch-free -- the last stages prefetch the last super-stage once
     // more into registers / the idle buffer -- so that the loop body is ONE basic block the scheduler can interleave.
+    // (Round 5, measured and not kept: requesting the next stage's first fragments right behind the stage barrier, in FRONT of the current
+    // stage's last four matrix instructions -- whose operands are in registers --, so that no LDS round trip is exposed at the boundary:
+    // same-box A/B over six layers, 3 interleaved runs: +0.5 ... +1.5 % on five of them (1 306-1 313 against 1 290-1 295 us at 256 -> 256 on
+    // 64 x 64), -2 % at 256 -> 256 on 16 x 16.  The boundary's cost is the barrier's skew, not the fragment latency behind it.)
     auto stage = [&](int kc, int e, int ssn) {
         const int buf = e;                                          // stage kc = 2 ss + e computes from buffer e
         const int kn = kc + 1 < 2 * nss ? kc + 1 : kc;              // the stage whose V / U this one prepares (into buffer e ^ 1)
