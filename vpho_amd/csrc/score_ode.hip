@@ -650,6 +650,9 @@ __global__ __launch_bounds__(512, 4) void score_head_kernel(const HeadArgs a) {
     // [2] stages x ([256][HB_K] weights | [128][HB_K] activations), unpadded rows filled by global_load_lds with the 16-B chunk
     // index XOR-swizzled (see conv_igemm_glds_kernel); then [256][4] {ct, w2_0, w2_1, w2_2}; the [8][ROWS][4] partial outputs of the epilogue reuse the stages
     if (ctl_skip(a.ctl, a.ctl_mode)) return;
+    // (measured no better, round 5: 64-row tiles for launches with fewer 128-row tiles than CUs -- the object head, 3 heads x 50 tiles = 150
+    // workgroups -> 300: 39.4-39.5 us against 39.8-40.2, step unchanged.  A tile alone on its CU is a chain of 16 barrier-separated k stages,
+    // ~2.3 us each whether the stage holds 32 or 16 matrix instructions per wave: the launch is as long as one tile's life either way.)
     // (measured no better: dispatching the tail tiles first, next to ordinary tiles, 233 vs 230 us; giving each XCD whole heads of
     // tail tiles, 231 us -- a tail tile is bound by its chain of 16 barrier-separated weight stages, not by where the weights are)
     const int b = blockIdx.x, n_full = a.nheads * a.full_tiles;
