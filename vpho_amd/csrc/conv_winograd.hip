@@ -24,7 +24,7 @@ namespace {
 #define WINO8_ABLATE 0                         // the same for conv_winograd8_kernel (scripts/kernel_ablate.sh conv_winograd WINO8_ABLATE ...): 1 no transform / V
 #endif                                         // stores, 2 no patch loads, 4 no U fill, 16 no stage barrier -- wrong results, compile-time only
 #ifndef WINO_ABLATE
-#define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh): 1 no patch loads, 2 no U fill, 4 no transform /
+#define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh; 512: no output stores): 1 no patch loads, 2 no U fill, 4 no transform /
 #endif                                         // V stores, 8 no stage barrier, 16 no fragment reads -- wrong results, never in the product build
 constexpr int WK = 8;                          // input channels per stage
 constexpr int W_TB = 64, W_CB = 64;            // tiles / output channels per workgroup
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
                 float v = o[p];
                 if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
+                if ((WINO_ABLATE & 512) && v != 1.2345e-30f) continue;          // timing: the output transform without its stores
                 yp[offs[p]] = v > 0.f ? v : v * a.out_slope;
             }
         }
