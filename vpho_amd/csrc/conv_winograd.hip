@@ -212,6 +212,12 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // stage's last four matrix instructions -- whose operands are in registers --, so that no LDS round trip is exposed at the boundary:
     // same-box A/B over six layers, 3 interleaved runs: +0.5 ... +1.5 % on five of them (1 306-1 313 against 1 290-1 295 us at 256 -> 256 on
     // 64 x 64), -2 % at 256 -> 256 on 16 x 16.  The boundary's cost is the barrier's skew, not the fragment latency behind it.)
+    // (Round 5, the ablations re-run on this kernel -- scripts/wino_ablate.sh, 256 -> 256 on 64 x 64 x 64 images, 1 290 us: without the fragment
+    // reads 1 285 (they cost nothing any more), without the stage barrier 1 203, without the U fills 1 219, without the patch loads AND the
+    // transforms they feed 1 048, the matrix instructions alone ~1 010.  Of the patch loads' 245 us, 171 go when all 16 loads of a lane hit one
+    // line and 74 when the addresses are dense: it is the gather's way through the address / L1 path -- 16 half-lines per wave instruction --,
+    // not DRAM latency: requesting the lines of the super-stage after next one super-stage early (four 4-byte `buffer_load ... lds` per even
+    // stage into a scratch kilobyte) changed nothing, 1 294-1 299 against 1 272-1 292, and was dropped.)
     auto stage = [&](int kc, int e, int ssn) {
         const int buf = e;                                          // stage kc = 2 ss + e computes from buffer e
         const int kn = kc + 1 < 2 * nss ? kc + 1 : kc;              // the stage whose V / U this one prepares (into buffer e ^ 1)
