@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // transforms they feed 1 048, the matrix instructions alone ~1 010.  Of the patch loads' 245 us, 171 go when all 16 loads of a lane hit one
     // line and 74 when the addresses are dense: it is the gather's way through the address / L1 path -- 16 half-lines per wave instruction --,
     // not DRAM latency: requesting the lines of the super-stage after next one super-stage early (four 4-byte `buffer_load ... lds` per even
-    // stage into a scratch kilobyte) changed nothing, 1 294-1 299 against 1 272-1 292, and was dropped.)
+    // stage into a scratch kilobyte) changed nothing, 1 294-1 299 against 1 272-1 292, and was dropped; so was taking patch columns 2, 3 from
+    // the right neighbour's lanes (v_mov_dpp row_shl:4 for 3 tiles of 4, 3/8 fewer line requests): 1 273 against 1 287-1 296, the other layers +-0.)
     auto stage = [&](int kc, int e, int ssn) {
         const int buf = e;                                          // stage kc = 2 ss + e computes from buffer e
         const int kn = kc + 1 < 2 * nss ? kc + 1 : kc;              // the stage whose V / U this one prepares (into buffer e ^ 1)
