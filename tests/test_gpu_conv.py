@@ -208,6 +208,37 @@ def test_two_waves_per_simd_winograd_is_bit_identical_to_the_one_wave_kernel(N, 
     _close(y8.permute(0, 3, 1, 2), ref, tol=3e-6)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(4, 32, 32, 128, 128), (9, 16, 16, 256, 256), (130, 8, 8, 512, 64), (5, 64, 64, 128, 64), (3, 64, 64, 16, 64), (2, 32, 16, 48, 192),
+                                            (7, 8, 8, 128, 128), (1, 16, 64, 32, 64)])
+def test_winograd_with_the_input_staged_through_lds_is_bit_identical(N, H, W, Cin, Cout):
+    """round 5: conv_winograd_kernel<true> moves the block's unique input pixels of a super-stage into a third LDS region by
+    `buffer_load ... lds` and lets every lane read its 4 x 4 patch from there (one 64-register patch set instead of two) -- against the
+    register path (VPHO_WINO_STAGED=0).  Same transforms on the same values: bit-identical.  Maps of 64 / 32 / 16 / 8 columns (2 / 4 / 8 tile
+    rows per block of one image, four whole images per block), image counts that leave the last block ragged or with absent images, one and
+    three super-stages, Cout = 192 (the non-XCD block order), non-square maps."""
+    import os
+    from vpho_amd import ops
+    from vpho_amd.model.pack import pack_conv, winograd_weights
+    x = _rand((N, H, W, Cin), 80).cuda()
+    w = _rand((Cout, Cin, 3, 3), 81, (2.0 / (9 * Cin)) ** 0.5)
+    b = _rand((Cout,), 82).cuda()
+    u = winograd_weights(pack_conv(w).cuda())
+    try:
+        os.environ['VPHO_WINO8'] = '0'
+        os.environ['VPHO_WINO_STAGED'] = '0'
+        y_reg = ops.conv3x3_winograd(x, u, b, 0.01)
+        os.environ['VPHO_WINO_STAGED'] = '1'
+        y_lds = ops.conv3x3_winograd(x, u, b, 0.01)
+        y_lds2 = ops.conv3x3_winograd(x, u, b, 0.01)
+    finally:
+        os.environ.pop('VPHO_WINO8', None)
+        os.environ.pop('VPHO_WINO_STAGED', None)
+    assert torch.isfinite(y_lds).all() and float(y_lds.abs().max()) > 0.1
+    assert torch.equal(y_lds, y_reg) and torch.equal(y_lds2, y_reg)
+    ref = F.leaky_relu(F.conv2d(x[:4].cpu().permute(0, 3, 1, 2).double(), w.double(), b.cpu().double(), 1, 1), 0.01)
+    _close(y_lds[:4].permute(0, 3, 1, 2), ref, tol=3e-6)
+
+
 @pytest.mark.parametrize('N,H,Cin,Cout', [(64, 16, 1024, 256), (8, 32, 512, 256), (3, 10, 64, 128), (2, 6, 96, 64)])
 def test_upsampled_residual_in_the_epilogue_equals_the_separate_top_down_pass(N, H, Cin, Cout):
     """round 4: `_upsample_add(p, lateral(c))` (backbone_FPN_HFL.py:66-68,98-104) inside the lateral 1x1 convolution's epilogue

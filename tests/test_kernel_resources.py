@@ -51,7 +51,7 @@ BUDGET = {
     'pose_encoder_reg_kernel<1>': (4, 128), 'pose_encoder_reg_kernel<3>': (4, 128), 'pose_encoder_reg_kernel<4>': (4, 128),
     'conv_igemm_glds_kernel<128, 128, 4, 2, false>': (4, 128), 'conv_igemm_glds_kernel<128, 64, 4, 2, false>': (4, 128),
     'conv_igemm_glds_kernel<64, 64, 2, 2, false>': (4, 128),
-    'conv_winograd_kernel': (1, 256),                         # one wave per SIMD by design: 256 accumulators
+    'conv_winograd_kernel<false>': (1, 256), 'conv_winograd_kernel<true>': (1, 256),   # one wave per SIMD by design: 256 accumulators
     'conv_winograd8_kernel': (2, 256),
     'conv_wgrad_tn_kernel<64, 64, 2, 2>': (4, 128), 'conv_wgrad_tn_kernel<128, 128, 4, 2>': (4, 128),
     'mano_fk_kernel<16>': (3, 168),

@@ -24,11 +24,21 @@ namespace {
 #define WINO8_ABLATE 0                         // the same for conv_winograd8_kernel (scripts/kernel_ablate.sh conv_winograd WINO8_ABLATE ...): 1 no transform / V
 #endif                                         // stores, 2 no patch loads, 4 no U fill, 16 no stage barrier -- wrong results, compile-time only
 #ifndef WINO_ABLATE
-#define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh; 512: no output stores): 1 no patch loads, 2 no U fill, 4 no transform /
+#define WINO_ABLATE 0                          // timing experiments only (scripts/wino_ablate.sh; 512: no output stores; 32 staged kernel: no input DMA): 1 no patch loads, 2 no U fill, 4 no transform /
 #endif                                         // V stores, 8 no stage barrier, 16 no fragment reads -- wrong results, never in the product build
 constexpr int WK = 8;                          // input channels per stage
 constexpr int W_TB = 64, W_CB = 64;            // tiles / output channels per workgroup
 constexpr int W_STAGE = 2 * 16 * 64 * WK;      // floats per stage: V | U
+constexpr int W_IN_PIXELS = 480;               // STAGED kernel: pixels (64 bytes each) of the input region IN behind the two stages: 128 + 30 KB of the 160
+// STAGED geometry: a 64-tile block = whole tile rows (TW | 64) of one image (NR = 64 / TW <= TH, TH % NR == 0) or all rows of NR / TH
+// images (TH | NR), and the region's pixels fit IN
+inline bool wino_staged_ok(int TH, int TW, int W) {
+    if (TW < 4 || TW > 32 || (W_TB % TW) != 0) return false;
+    const int NR = W_TB / TW;
+    if (NR <= TH ? (TH % NR) != 0 : (NR % TH) != 0) return false;
+    const int rpp = NR < TH ? NR : TH, ipb = NR / rpp;
+    return ipb * (2 * rpp + 2) * (W + 2) <= W_IN_PIXELS;
+}
 
 struct WinoArgs {
     const float* x; const float* u; const float* bias; float* y;
@@ -63,6 +73,14 @@ __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int&
     return true;
 }
 
+// STAGED (round 5; full maps whose 64-tile blocks are whole tile rows: wino_staged_ok): the input patches do not come through vector
+// registers.  Ablations of the kernel (scripts/wino_ablate.sh): the 16 x 16-byte patch loads of a lane cost 245 us of a 1 290-us launch --
+// three times what the U fills of the same volume cost, whatever their addresses: it is the loads' return path into the register file,
+// beside the matrix instructions, that is dear.  Here the block's UNIQUE input pixels of a super-stage (a tile's 4 x 4 patch overlaps its
+// neighbours': 1 024 pixel loads for ~340-400 distinct pixels) are moved by `buffer_load ... lds` into a third LDS region IN (<= 30 KB,
+// single: filled in the even stage, read in the odd one, the stage barriers in between), and a lane reads its patch from there with 16
+// ds_read_b128 just before it needs it -- so one 64-register patch set is enough (the second one was there to cover HBM latency).
+template <bool STAGED>
 __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     VPHO_STAMP_INIT();
@@ -127,7 +145,49 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     // instruction asks for 64 contiguous bytes of a pixel instead of 32).  A k stage takes one channel PAIR of every lane: stage e
     // (0 / 1) of super-stage ss multiplies channels 16 ss + {0,1,4,5,8,9,12,13} + 2 e -- any 8 channels will do as long as u holds the
     // same ones in the same slots (pack.winograd_weights).  pc: the super-stage being consumed, pnx: the next one, in flight.
-    f32x4 pc[16], pnx[16];
+    // ---- STAGED: the block's pixel region.  A block is NR = 64 / TW whole tile rows: of one image (NR <= TH), or all TH rows of
+    // ipb = NR / TH consecutive images.  Region of a part: RR = 2 rpp + 2 pixel rows (the tile rows' pixels + one halo row above and below)
+    // x RC = W + 2 columns; pixel (k, rr, rc) = image n0 + k, row 2 ty0 - 1 + rr, column rc - 1.  IN holds 16 channels = 64 bytes per pixel.
+    float* INb = smem + 2 * W_STAGE;
+    int doff[8];                                                   // this wave's DMA instructions j = wave, wave + 4, ...: 16 pixels each
+    int in_ni = 0;                                                 // DMA instructions of the block
+    int rowb[4];                                                   // LDS float offset of this lane's patch rows
+    if constexpr (STAGED) {
+        const int NR = W_TB / a.TW, rpp = NR < a.TH ? NR : a.TH, ipb = NR / rpp;
+        const int RR = 2 * rpp + 2, RC = a.W + 2, P = ipb * RR * RC;
+        const int n0 = t0 / (a.TH * a.TW), ty0 = (t0 - n0 * a.TH * a.TW) / a.TW;
+        in_ni = (P + 15) >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 16 * (wave + 4 * j) + (lane >> 2);
+            const int k = q / (RR * RC), r2 = q - k * RR * RC, rr = r2 / RC, rc = r2 - rr * RC;
+            const int n = n0 + k, iy = 2 * ty0 - 1 + rr, ix = rc - 1;
+            const bool in = q < P && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            doff[j] = in ? (int)((((long long)(n * a.H + iy) * a.W + ix) * a.x_ld + 4 * (lane & 3)) * 4) : -1;
+        }
+        const int k = tl / (rpp * a.TW), rem = tl - k * rpp * a.TW, tyl = rem / a.TW, txl = rem - tyl * a.TW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowb[i] = ((k * RR + 2 * tyl + i) * RC + 2 * txl) * 16 + 4 * cp;
+    }
+    // the wave's share of the region's DMA instructions [j0, j1) for super-stage ss (16 channels = 64 bytes per pixel at byte ss * 64)
+    auto fill_in = [&](int ss, int j0, int j1) {
+        if (WINO_ABLATE & (1 | 32)) return;
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+            if (wave + 4 * j < in_ni)                               // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(INb + (wave + 4 * j) * 256), 16, doff[j], ss * 64, 0, 0);
+    };
+    f32x4 pc[16], pnx[STAGED ? 1 : 16];
+    // patch rows [i0, i1) of this lane from IN
+    auto read_patch = [&](f32x4 (&dst)[16], int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (WINO_ABLATE & 1) { dst[4 * i + j] = f32x4{(float)(4 * i + j), 1.f, 2.f, 3.f}; continue; }
+                dst[4 * i + j] = *reinterpret_cast<const f32x4*>(INb + rowb[i] + 16 * j);
+            }
+    };
     f32x2 r[16];
     auto load_patch = [&](f32x4 (&dst)[16], int ss, int p0 = 0, int p1 = 16) {
 #pragma unroll
@@ -194,8 +254,15 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 
     const int nss = a.Cin / (2 * WK);                              // super-stages of 16 channels = 2 k stages
     const int fsw = (li >> 3) & 1;
-    load_patch(pc, 0);
-    fill_u(0, 0);
+    if constexpr (STAGED) {
+        fill_in(0, 0, 8);
+        fill_u(0, 0);
+        VPHO_SYNC_LDS_DMA();
+        read_patch(pc, 0, 4);
+    } else {
+        load_patch(pc, 0);
+        fill_u(0, 0);
+    }
     VPHO_STAMP_AT(1);
     row_transform(pc, 0);
 #pragma unroll
@@ -237,8 +304,16 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             // patch loads stay in flight (vmcnt(16)) and still know the fills have landed -- the patch has until the row transform of the
             // NEXT stage to arrive (with vmcnt(0) here it had to beat the barrier of its own stage: 12 % of the kernel's time)
             if (f < 2) fill_u(buf ^ 1, kn, 4 * f, 4 * f + 4);
-            if (e == 0 && f >= 2 && f < 6) load_patch(pnx, ssn, 4 * (f - 2), 4 * (f - 2) + 4);
-            if (f == 11) { if (e == 0) row_transform(pc, 1); else row_transform(pnx, 0); }
+            if constexpr (STAGED) {
+                // even stage: the next super-stage's pixels into IN (every wave has read the previous ones: the barrier behind the odd stage);
+                // odd stage: this lane's patch from IN (they landed before the barrier behind the even stage), a patch row per two groups
+                if (e == 0 && f >= 2 && f < 6) fill_in(ssn, 2 * (f - 2), 2 * (f - 2) + 2);
+                if (e == 1 && f >= 2 && f < 10 && !(f & 1)) read_patch(pc, (f - 2) >> 1, ((f - 2) >> 1) + 1);
+                if (f == 11) row_transform(pc, e == 0 ? 1 : 0);
+            } else {
+                if (e == 0 && f >= 2 && f < 6) load_patch(pnx, ssn, 4 * (f - 2), 4 * (f - 2) + 4);
+                if (f == 11) { if (e == 0) row_transform(pc, 1); else row_transform(pnx, 0); }
+            }
             if (f >= 12) store_v_row(buf ^ 1, f - 12);
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f & 1][q], bv[f & 1][q], acc[f], 0, 0, 0);
@@ -254,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(WINO_ABLATE & 8)) {
-            if (e == 0 && !(WINO_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
+            if (!STAGED && e == 0 && !(WINO_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
             else VPHO_SYNC_LDS_DMA();
         }
     };
@@ -264,8 +339,10 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
         const int ssn = ss + 1 < nss ? ss + 1 : ss;
         stage(2 * ss, 0, ssn);
         stage(2 * ss + 1, 1, ssn);
+        if constexpr (!STAGED) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
+            for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
+        }
     }
     VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
@@ -650,9 +727,11 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     a.TH = H / 2; a.TW = W / 2; a.T = N * a.TH * a.TW; a.out_slope = out_slope;
     a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope; a.scatter = scatter;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
+    const size_t lds_staged = lds + (size_t)W_IN_PIXELS * 64;
     static bool opt_in = false;
     if (!opt_in) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
         opt_in = true;
     }
     const int tbs = (a.T + W_TB - 1) / W_TB;
@@ -668,10 +747,18 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     // tile has few k stages (Cin = 64: 124 against 131 us at 64 x 64 x 64 images) -- its per-stage barrier joins 8 unequally loaded waves
     // and costs 14 % of its time against 4 % for the 4-wave kernel -- and loses 1 ... 10 % on the long-K layers.  VPHO_WINO8 = 1 / 0 forces
     // either kernel (read per call; the two are bit-identical, tests/test_gpu_conv.py).
+    // Round 5: with the halved epilogue and the input staged through LDS the 4-wave kernel wins there as well (64 -> 64 on 64 x 64 x 64
+    // images: 113 us staged, 115 through registers, 124 for the 8-wave kernel), so the 8-wave kernel is only run on request.
     const char* w8 = getenv("VPHO_WINO8");
-    const bool use8 = w8 ? atoi(w8) != 0 : Cin <= 64;
+    const bool use8 = w8 ? atoi(w8) != 0 : false;
     if (!use8) {
-        hipLaunchKernelGGL(conv_winograd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+        // input patches through LDS where the blocks are whole tile rows of full maps (see the kernel); VPHO_WINO_STAGED=0: registers (A/B aid,
+        // bit-identity test; read per call)
+        const char* st = getenv("VPHO_WINO_STAGED");
+        if (!wins && (st ? atoi(st) != 0 : true) && wino_staged_ok(a.TH, a.TW, W))
+            hipLaunchKernelGGL(conv_winograd_kernel<true>, dim3(blocks), dim3(256), lds_staged, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(conv_winograd_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
         return vpho::check_launch("conv_winograd_kernel");
     }
     static bool opt_in8 = false;
