@@ -27,6 +27,9 @@ VPHO_STAMP_DECL(head)
 
 namespace {
 
+#ifndef HEAD_ABLATE
+#define HEAD_ABLATE 0                          // timing experiments on head_tile (scripts/kernel_ablate.sh score_ode HEAD_ABLATE ...): 1 no stage fills after the
+#endif                                         // first two, 2 no fragment reads after the first, 4 no stage barrier, 8 no epilogue -- wrong results, never in the product build
 constexpr int HB_K = 16;
 constexpr double SIGMA_MIN = 0.01, SIGMA_MAX = 50.0;
 
@@ -552,12 +555,13 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
     fill(1, 1);
     VPHO_STAMP_AT(2);
     VPHO_PRIO_MAIN();
+    f32x4 b, av[TI];
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
         const float* As = smem + buf * STAGE + (hh * 32 * TI + li) * HB_K;
         const float* Bs = smem + buf * STAGE + 256 * HB_K + (rg * 32 + li) * HB_K;
-        f32x4 b, av[TI];
         auto frags = [&](int kk) {
+            if ((HEAD_ABLATE & 2) && (kt | kk)) return;              // timing: the first fragments only
             const int ch = ((2 * kk + lh) ^ sw) * 4;
             b = *reinterpret_cast<const f32x4*>(Bs + ch);
 #pragma unroll
@@ -573,13 +577,14 @@ __device__ __forceinline__ void head_tile(const HeadArgs& a, float* smem, const 
 #pragma unroll
         for (int kk = 0; kk < NKK - 1; ++kk) { frags(kk); mfmas(); }
         frags(NKK - 1);
-        VPHO_SYNC_LDS_DMA();
-        if (kt + 2 < NK) fill(buf, kt + 2);
+        if (!(HEAD_ABLATE & 4)) VPHO_SYNC_LDS_DMA();
+        if (kt + 2 < NK && !(HEAD_ABLATE & 1)) fill(buf, kt + 2);
         mfmas();
     }
     __syncthreads();
     VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
+    if ((HEAD_ABLATE & 8) && acc[0][0] != 1.2345e-30f) return;       // timing: no epilogue
 
     // epilogue: hidden unit j = 32*TI*hh + 32*i + (e&3) + 8*(e>>2) + 4*lh on the register, hypothesis on the lane
     const int lrow_out = rg * 32 + li;
