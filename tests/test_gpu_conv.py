@@ -211,7 +211,7 @@ def test_two_waves_per_simd_winograd_is_bit_identical_to_the_one_wave_kernel(N, 
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(4, 32, 32, 128, 128), (9, 16, 16, 256, 256), (130, 8, 8, 512, 64), (5, 64, 64, 128, 64), (3, 64, 64, 16, 64), (2, 32, 16, 48, 192),
                                             (7, 8, 8, 128, 128), (1, 16, 64, 32, 64)])
 def test_winograd_with_the_input_staged_through_lds_is_bit_identical(N, H, W, Cin, Cout):
-    """round 5: conv_winograd_kernel<true> moves the block's unique input pixels of a super-stage into a third LDS region by
+    """round 5: conv_winograd_kernel<1> moves the block's unique input pixels of a super-stage into a third LDS region by
     `buffer_load ... lds` and lets every lane read its 4 x 4 patch from there (one 64-register patch set instead of two) -- against the
     register path (VPHO_WINO_STAGED=0).  Same transforms on the same values: bit-identical.  Maps of 64 / 32 / 16 / 8 columns (2 / 4 / 8 tile
     rows per block of one image, four whole images per block), image counts that leave the last block ragged or with absent images, one and
