@@ -20,6 +20,9 @@
 namespace {
 
 constexpr int BK = 32;
+#ifndef WGRAD_ABLATE
+#define WGRAD_ABLATE 0                         // timing experiments (scripts/kernel_ablate.sh conv_wgrad WGRAD_ABLATE ...): 1 no stage fills after the first, 2 no fragment
+#endif                                         // reads after the first stage, 4 no stage barrier -- wrong results, never in the product build
 
 struct WgArgs {
     const float* x; const float* dy; float* out;       // out: [splits][Cout][K]
@@ -149,17 +152,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
         fill(0, 0);
         VPHO_SYNC_LDS_DMA();
     }
+    constexpr int HK = BK / 4;
+    float av[2][HK][TM], bv[2][HK][TN];
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fill(buf ^ 1, kt + 1);
+        if (kt + 1 < nk && !(WGRAD_ABLATE & 1)) fill(buf ^ 1, kt + 1);
         const float* As = smem + buf * TILE + wm * (BM / WM) + li;
         const float* Bs = smem + buf * TILE + BM * BK + wn * (BN / WN) + li;
         // the stage's fragments are read in two halves of 8 k-steps; the second half's ds_reads are in flight while the first
         // half's MFMAs run (scheduling barriers keep the compiler from sinking the reads back next to their uses)
-        constexpr int HK = BK / 4;
-        float av[2][HK][TM], bv[2][HK][TN];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if ((WGRAD_ABLATE & 2) && kt > 0) break;                 // timing: the first stage's fragments for every stage
 #pragma unroll
             for (int kk = 0; kk < HK; ++kk) {
 #pragma unroll
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][kk][i], bv[h][kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        VPHO_SYNC_LDS_DMA();
+        if (!(WGRAD_ABLATE & 4)) VPHO_SYNC_LDS_DMA();
     }
 
     float* out = a.out + (long long)slice * a.Cout * a.K;
@@ -268,7 +272,11 @@ WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     static const int tile_env = getenv("VPHO_WGRAD_TILE") ? atoi(getenv("VPHO_WGRAD_TILE")) : 0;          // tuning aid
     // 128x128 tiles pay off only for the largest products (measured: 3x3 256->256 on 64x64x64 pixels 100 vs 87 TF/s); everywhere else
     // the 64x64 tile wins or ties (3x3 128->128: 79 vs 53 TF/s) -- more tiles, hence fewer, longer pixel slices and less partial-sum traffic
-    const bool big = tile_env ? tile_env == 128 : (K >= 128 && Cout >= 128 && (double)M * K * Cout >= 5e10);
+    // (round 5, re-swept per shape with the grouped slice sum, scripts/wgrad_layers.py under VPHO_WGRAD_TILE=64 / 128: the 128 x 128 tile now
+    // wins or ties from M K Cout ~ 4e9 on -- 1x1 1024 -> 256 on 16 x 16 maps 101 -> 92 us, 3x3 128 -> 128 on 32 x 32 217 -> 206 -- and loses below
+    // (3x3 128 -> 128 on 16 x 16: 74 against 88): 19.6 -> 18.7 ms of weight gradients per training step)
+    static const double big_min = getenv("VPHO_WGRAD_BIG_MIN") ? atof(getenv("VPHO_WGRAD_BIG_MIN")) : 4e9;      // tuning aid (round 4's rule: 5e10)
+    const bool big = tile_env ? tile_env == 128 : (K >= 128 && Cout >= 128 && (double)M * K * Cout >= big_min);
     p.bm = p.bn = big ? 128 : 64;
     p.tiles_m = (Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
