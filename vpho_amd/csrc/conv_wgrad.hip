@@ -20,6 +20,9 @@
 namespace {
 
 constexpr int BK = 32;
+#ifndef WGRAD_RING
+#define WGRAD_RING 2                           // LDS stages of the 64 x 64 tile (A/B builds: 3)
+#endif
 #ifndef WGRAD_ABLATE
 #define WGRAD_ABLATE 0                         // timing experiments (scripts/kernel_ablate.sh conv_wgrad WGRAD_ABLATE ...): 1 no stage fills after the first, 2 no fragment
 #endif                                         // reads after the first stage, 4 no stage barrier -- wrong results, never in the product build
@@ -44,7 +47,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
     static_assert(TM >= 1 && TN >= 1 && A_INSTR % NW == 0 && B_INSTR % NW == 0 && A_LD >= 1 && B_LD >= 1, "tile/wave layout");
     static_assert(64 % A_CPR == 0 && 64 % B_CPR == 0, "a wave instruction must cover whole tile rows");
     constexpr int TILE = (BM + BN) * BK;
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+    // stages in LDS: 2, or WGRAD_RING for the 64 x 64 tile (a fill then has RING - 1 stage times to land; 3 x 16 KB still leaves 3 workgroups per CU)
+    constexpr int NB = (BM == 64 && WGRAD_RING > 2) ? WGRAD_RING : 2;
+    constexpr int FI = A_LD + B_LD;                                        // direct-to-LDS instructions of one stage fill, per wave
+    __shared__ __attribute__((aligned(1024))) float smem[NB * TILE];
 
     // Workgroup -> (pixel slice, tile).  Workgroups go to the 8 XCDs round-robin, each XCD has its own L2: XCD x takes the slices
     // s = x, x + 8, ... and runs ALL tiles of a slice one after the other, so both operands of a slice (its dY rows, its x rows) are
@@ -149,14 +155,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
 
     const int nk = listed ? (s_end > s_begin ? s_end - s_begin : 0) : (m_end - m_begin + BK - 1) / BK;
     if (nk > 0) {
-        fill(0, 0);
+#pragma unroll
+        for (int s0 = 0; s0 < NB - 1; ++s0) if (s0 < nk) fill(s0, s0);
         VPHO_SYNC_LDS_DMA();
     }
     constexpr int HK = BK / 4;
     float av[2][HK][TM], bv[2][HK][TN];
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk && !(WGRAD_ABLATE & 1)) fill(buf ^ 1, kt + 1);
+        const int buf = kt % NB;
+        const bool filled = kt + NB - 1 < nk;
+        if (filled && !(WGRAD_ABLATE & 1)) fill((kt + NB - 1) % NB, kt + NB - 1);
         const float* As = smem + buf * TILE + wm * (BM / WM) + li;
         const float* Bs = smem + buf * TILE + BM * BK + wn * (BN / WN) + li;
         // the stage's fragments are read in two halves of 8 k-steps; the second half's ds_reads are in flight while the first
@@ -183,7 +191,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tn_kernel(const WgArg
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][kk][i], bv[h][kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(WGRAD_ABLATE & 4)) VPHO_SYNC_LDS_DMA();
+        if (!(WGRAD_ABLATE & 4)) {
+            // stage kt + 1 has landed once at most the fills of the NB - 2 stages behind it are outstanding (in order); in the tail, where no
+            // fill was issued this stage, everything
+            // (the fence-free barrier: __syncthreads() would make the compiler drain the fills in flight, common.h)
+            if (NB > 2 && filled) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * FI) : "memory"); VPHO_BARRIER_LDS_ONLY(); }
+            else VPHO_SYNC_LDS_DMA();
+        }
     }
 
     float* out = a.out + (long long)slice * a.Cout * a.K;
@@ -278,6 +292,18 @@ WgPlan plan_wgrad(long long M, int Cin, int Cout, int taps) {
     static const double big_min = getenv("VPHO_WGRAD_BIG_MIN") ? atof(getenv("VPHO_WGRAD_BIG_MIN")) : 4e9;      // tuning aid (round 4's rule: 5e10)
     const bool big = tile_env ? tile_env == 128 : (K >= 128 && Cout >= 128 && (double)M * K * Cout >= big_min);
     p.bm = p.bn = big ? 128 : 64;
+    // Three tiles (re-swept per shape, round 5, scripts/wgrad_layers.py under VPHO_WGRAD_TILE = 64 / 128 / 12864: 19.6 / 20.8 / 18.5 ms of weight
+    // gradients per training step, this rule 18.4, the best tile per shape 18.3): 128 output channels x 64 columns of the (tap, ci) axis --
+    // 0.047 bytes of LDS fill per flop against 0.0625 for 64 x 64, three workgroups per CU -- wherever Cout >= 128 and the product is not tiny
+    // (it also serves K = 64: 64 -> 256 on 64 x 64 maps 93 -> 88 us; 3x3 256 -> 256 on 16 x 16 202 -> 190); 128 x 128 for the 1x1 layers with
+    // K a multiple of 128 from M K Cout = 4e9 on (1024 -> 256 on 16 x 16: 101 -> 92) and for the largest products; 64 x 64 for the rest.
+    if (!tile_env) {
+        const double prod = (double)M * K * Cout;
+        const bool big128 = K >= 128 && Cout >= 128 && ((taps == 1 && K % 128 == 0 && prod >= big_min) || prod >= 5e10);
+        if (big128) p.bm = p.bn = 128;
+        else if (Cout >= 128 && K >= 64 && prod >= 1e9) { p.bm = 128; p.bn = 64; }
+        else p.bm = p.bn = 64;
+    } else if (tile_env == 12864 && Cout >= 128) { p.bm = 128; p.bn = 64; }
     p.tiles_m = (Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
@@ -359,7 +385,8 @@ static int wgrad_launch(const float* x, int N, int H, int W, int Cin, int x_ld, 
     // reported as an upper bound by its own class id would mislead, so group launches are left out of the classes)
     vpho::ProfScope prof(glist ? -1 : (p.bm == 128 ? vpho::PROF_WGRAD128 : vpho::PROF_WGRAD64), s, 2.0 * (double)M * Cout * (double)a.K,
                          4.0 * ((double)N * H * W * Cin + (double)M * Cout + (double)Cout * a.K));
-    if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);
+    if (p.bm == 128 && p.bn == 64) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 64, 4, 2>), grid, dim3(512), 0, s, a);
+    else if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_tn_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
     if (p.splits > 1) {
         const long long n4 = (long long)Cout * a.K / 4;
