@@ -117,8 +117,9 @@ def main():
                            'kernel_ms_per_step': r['total_ms'] / n_prof, 'avg_launch_us': 1e3 * r['total_ms'] / r['launches'], 'flop_per_launch_avg': r['flops'] / r['launches'],
                            'bytes_per_launch_avg': r.get('bytes', 0.0) / r['launches']}
         dom = max(blk, key=lambda k: blk[k]['kernel_ms_per_step']) if blk else None
-        kname = {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64, 64, 2, 2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128, 128, 4, 2>'}
-        res['roofline'] = None if dom is None else {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2>'}[dom]
+        # the 8-wave class = the 128 x 128 and the 128 x 64 tile (both instantiations' rows of the PMC table, launch-weighted)
+        kname = {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64, 64, 2, 2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,'}
+        res['roofline'] = None if dom is None else {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2> and <128,64,4,2> (the 8-wave tiles)'}[dom]
                            + ' (weight gradient dW = dY^T . im2col(x) as an implicit TN GEMM on fp32 MFMA)',
                            'achieved': blk[dom]['TFLOP/s'], 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': blk[dom]['frac'],
                            'traffic': pmc_traffic(kname[dom]), 'traffic_source': pmc_traffic(kname[dom], source=True),
