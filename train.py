@@ -122,7 +122,8 @@ def main():
         res['roofline'] = None if dom is None else {'bound': 'mfma', 'kernel': {'conv_wgrad_64x64': 'conv_wgrad_tn_kernel<64,64,2,2>', 'conv_wgrad_128x128': 'conv_wgrad_tn_kernel<128,128,4,2> and <128,64,4,2> (the 8-wave tiles)'}[dom]
                            + ' (weight gradient dW = dY^T . im2col(x) as an implicit TN GEMM on fp32 MFMA)',
                            'achieved': blk[dom]['TFLOP/s'], 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': blk[dom]['frac'],
-                           'traffic': pmc_traffic(kname[dom]), 'traffic_source': pmc_traffic(kname[dom], source=True),
+                           # the committed counter pass is of the default batch (64 per GPU): no figure for another batch size
+                           'traffic': pmc_traffic(kname[dom]) if bs == 64 else None, 'traffic_source': pmc_traffic(kname[dom], source=True) if bs == 64 else None,
                            'algorithmic_bytes_per_launch': blk[dom].get('bytes_per_launch_avg'),
                            'share_of_step': blk[dom]['kernel_ms_per_step'] / res['ms_per_step'],
                            'timing': 'HIP events around every launch on the launch stream, in an instrumented repeat of the step with the weight gradients kept on '
