@@ -20,7 +20,7 @@ VPHO_STAMP_DECL(conv)
 namespace {
 
 #ifndef CONV_ABLATE
-#define CONV_ABLATE 0                          // timing experiments only (scripts/kernel_ablate.sh conv_igemm CONV_ABLATE 1 2 4): 1 no global loads, 2 no in-loop
+#define CONV_ABLATE 0                          // timing experiments only (scripts/kernel_ablate.sh conv_igemm CONV_ABLATE 1 2 4; direct-to-LDS kernel: 32 a quarter of the fragment reads, 64 no stage fills after the second, 128 no stage barrier, 256 no epilogue): 1 no global loads, 2 no in-loop
 #endif                                         // barriers, 4 no LDS stores in conv_igemm_kernel -- wrong results, never in the product build
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
@@ -578,14 +578,16 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
         const int buf = kt & 1;
         const float* As = smem + buf * TILE + (wm * (BM / WM) + li) * BK;
         const float* Bs = smem + buf * TILE + BM * BK + (wn * (BN / WN) + li) * BK;
+        f32x4 a[TM], b[TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int ch = ((2 * kk + lh) ^ sw) * 4;
-            f32x4 a[TM], b[TN];
+            if (!(CONV_ABLATE & 32) || kk == 0) {                     // timing (32): one fragment read per stage instead of four
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + ch);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + ch);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + ch);
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + ch);
+            }
             if constexpr (PRE) {
                 const int c = kt * BK + (2 * kk + lh) * 4;          // channel of this lane's 4 consecutive k
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(pre_tab + c), sh = *reinterpret_cast<const f32x4*>(pre_tab + GLDS_PRE_MAX + c);
@@ -609,9 +611,9 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     VPHO_STAMP_AT(2);
     VPHO_PRIO_MAIN();
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        if (kt > 0 || (g.dbg & 16)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
+        if ((kt > 0 || (g.dbg & 16)) && !(CONV_ABLATE & 64)) { if (UNI) fill_uni((kt & 1) ^ 1, kt + 1); else fill((kt & 1) ^ 1); }     // stage 1 is already on its way
         compute(kt);
-        VPHO_SYNC_LDS_DMA();
+        if (!(CONV_ABLATE & 128)) VPHO_SYNC_LDS_DMA();
     }
     // last stage: no next fill; the residual tile is requested here and lands under this stage's matrix work
     if (res_early) { if (d.res_up) load_res_up(); else load_res(); __builtin_amdgcn_sched_barrier(0); }
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     VPHO_SYNC_LDS_DMA();
     VPHO_PRIO_REST();
     VPHO_STAMP_AT(3);
+    if ((CONV_ABLATE & 256) && acc[0][0][0] != 1.2345e-30f) return;    // timing: no epilogue
 
     if (g.vec_epilogue) {
         constexpr int C_LD = BN;                                    // ds_write_b32 halves are separate bank groups: no pad needed
@@ -1198,6 +1201,9 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
                       (!d.bias || al16(d.bias)) &&
                       (!d.gate || al16(d.gate)) &&
                       (!d.res || (al16(d.res) && d.r_sx % 4 == 0 && d.r_sy % 4 == 0 && d.r_sn % 4 == 0))) ? 1 : 0;
+    // (round 5: the direct-to-LDS kernel's own ablations on the one-round layers, scripts/conv_oneround.py, 3.36 ms per step over nine shapes: stage
+    // fills 6 %, stage barrier 1.5 %, epilogue 8.6 %, matrix instructions + launch shape the rest; 4-byte stores straight from the accumulators
+    // instead of this 16-byte epilogue: +2.5 %)
     const char* dbg_env = getenv("VPHO_CONV_DBG");
     g.dbg = dbg_env ? (atoi(dbg_env) & (8 | 16)) : 0;          // only the bit-identical A/B orders exist at run time
     if (d.x2) {
