@@ -31,6 +31,9 @@ HBM_LIMITS = {'mano_fk': 'matrix cores / vector ALU, not HBM: pose blend [hands 
               'hand_fuse': 'latency: one workgroup per (image, finger) -- ranking by counting, 30 quaternions, a 4x4 Jacobi eigen-solve',
               'roi_align': 'HBM / L2 gather: window rows read once, pooled output written once',
               'resize_bilinear': 'HBM: read-modify-write of the finer map (top-down add of the FPN)'}
+CONV_CLASS_NAME = ('conv_igemm 128x128 tile class = conv_igemm_glds_kernel<128,128,4,2,false> (one tile per workgroup) + '
+                   'conv_igemm_pers_kernel<128,128,4,2> (persistent tile walk); fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles')
+CONV_CLASS_KERNELS = ('conv_igemm_glds_kernel<128, 128, 4, 2, false>', 'conv_igemm_pers_kernel<128, 128, 4, 2>')
 HBM_KERNEL_NAMES = {'mano_fk': 'mano_fk', 'obj_physics': 'obj_physics_kernel', 'hand_fuse': 'hand_fuse_kernel',
                     'roi_align': 'roi_align_nhwc_kernel', 'resize_bilinear': 'resize_bilinear_nhwc_kernel'}
 
@@ -242,12 +245,21 @@ def main():
         head_excl = dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0)
         pe_excl = dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rank_dt = [dt]
     if world > 1:
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)                       # the per-rank clocks, so that a first multi-GPU run can check itself
+        rank_dt = [float(t.item()) for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert all_rows.shape[0] == world * args.steps * lbs
+    fabric = {'world_size_reported': dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+              'backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else 'none',
+              'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None,
+              'rank_ms_per_step_min_max': [min(rank_dt) / args.steps * 1e3, max(rank_dt) / args.steps * 1e3]}
 
     result = None
+    wl_key = workload_key(args.bs, args.sample_num, args.sampling_steps)
     if rank == 0:
         images = world * args.steps * lbs                  # strong: world * lbs = --bs per step
         host_cpu = {'cpu_seconds_per_step': host_cpu_s / args.steps, 'busy_threads_equivalent': host_cpu_s / dt}
@@ -279,11 +291,13 @@ def main():
                        'weights': ('vpho_amd.synth.bench_state_dict(seed=1): seeded, heat-map contrast 0.7, conditioned score networks' if args.weights == 'conditioned' else 'vpho_amd.synth.synth_state_dict(seed=1): round-1 random set') + '; synthetic MANO/YCB tables', 'parallelism': f'dp{world}',
                        'nfev_hand_obj_per_step': nfev[-1],
                        'prior_draw': 'device generator (Philox), opt-in: NOT the reference RNG stream' if eng.device_prior else 'CPU generator inside the timed step (sde.py:26-28)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_glds_kernel<128,128,4,2,false> (fp32 MFMA implicit GEMM, 8 waves, direct-to-LDS tiles)' if conv_mfma == 'f32'
+            'roofline': {'bound': 'mfma', 'kernel': CONV_CLASS_NAME if conv_mfma == 'f32'
                          else f'conv_igemm_split_kernel<128,128,4,2,{conv_mfma[-1]}> (split-bf16 products, opt-in)', 'achieved': conv_tf,
                          'peak': conv_peak, 'unit': 'TFLOP/s', 'frac': conv_tf / conv_peak,
-                         'traffic': pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>') or pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2>'),
-                         'traffic_source': (pmc_traffic('conv_igemm_glds_kernel<128, 128, 4, 2, false>', per_kernel=True) or {}).get('source'),
+                         # launch-weighted over BOTH kernels of the class (one-tile and persistent multi-tile), and only from a counter
+                         # pass taken at this batch size / sample count
+                         'traffic': pmc_traffic(CONV_CLASS_KERNELS, workload=wl_key),
+                         'traffic_source': (pmc_traffic(CONV_CLASS_KERNELS, per_kernel=True, workload=wl_key) or {}).get('source'),
                          'timing': 'HIP events around every launch, in a separate instrumented repeat of the K steps',
                          'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
                          'pose_encoder': ({'TFLOP/s': prof['pose_encoder']['flops'] / (prof['pose_encoder']['total_ms'] * 1e-3) / 1e12, 'frac': prof['pose_encoder']['flops'] / (prof['pose_encoder']['total_ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -332,29 +346,135 @@ def main():
                                     'launches_per_step': prof[k]['launches'] / max(args.steps, 1),
                                     'kernel_ms_per_step': prof[k]['total_ms'] / max(args.steps, 1),
                                     'algorithmic_bytes_per_launch': prof[k]['bytes'] / max(prof[k]['launches'], 1),
-                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k]), 'traffic_by_kernel': pmc_traffic(HBM_KERNEL_NAMES[k], per_kernel=True),
+                                    'traffic': pmc_traffic(HBM_KERNEL_NAMES[k], workload=wl_key), 'traffic_by_kernel': pmc_traffic(HBM_KERNEL_NAMES[k], per_kernel=True, workload=wl_key),
                                     'limited_by': HBM_LIMITS[k]} for k in hbm_classes}},
             'metrics_rows_gathered': int(all_rows.shape[0]),
             'host_cpu': host_cpu,
+            'fabric': fabric,
         }
+        post_rows = lambda out, batch, engine: E.metric_rows(out, batch, gt_joint, gt_vert, 0, assets)
         if world == 1 and not args.no_opt_in and (score_mfma, conv_mfma) == ('f32', 'f32'):
-            result['opt_in'] = opt_in_leg(args, model, batches, E, lambda out, batch, engine: E.metric_rows(out, batch, gt_joint, gt_vert, 0, assets))
+            result['opt_in'] = {'split_bf16x6': secondary_leg(args, model, batches, E, post_rows, {'VPHO_SCORE_MFMA': 'bf16x6', 'VPHO_CONV_MFMA': 'bf16x6'},
+                'same step, same evaluator; fp32 products of the score head and of the direct convolutions as 6 exact bf16 products each '
+                '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`')}
+        if world == 1 and not args.no_opt_in and eng.roi_window and not args.no_roi_window:
+            # the RoI-window saving is data dependent (boxes that span the crop lose it): the same step with the full stride-4 maps
+            result['value_full_maps'] = secondary_leg(args, model, batches, E, post_rows, {'VPHO_ROI_WINDOW': '0'},
+                'same step with --no_roi_window: the last convolution of each FPN branch on every pixel (what boxes spanning the crop would cost)')
         if world == 1 and not args.no_cpu_baseline:
             result.update(cpu_baseline_leg(args, cfg, model, sd, assets, ANCHOR_SKELETON, dev))
-        print(json.dumps(result), flush=True)
+        emit(result)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return result
 
 
-def opt_in_leg(args, model, batches, E, post):
-    """Secondary, clearly separate from `value`: the same step with every fp32 product of the score head and of the direct convolutions
-    assembled from six exact bf16 x bf16 products on the bf16 matrix cores (fp32 storage and accumulation; error against fp64 at the
-    fp32 kernels' level: DESIGN 4b, tests/test_gpu_split_head.py).  NOT the default and NOT the headline: `value` is the fp32-MFMA path."""
+DETAIL_PATH = os.path.join('gpurun_out', 'bench_detail.json')
+LINE_LIMIT = 6144                  # bytes; the driver's parser read 19.5 KB in round 4 and not 22.3 KB in round 5 -- stay far away
+
+
+def emit(full, stream=None):
+    """The full record (every diagnostic block) goes to a side file and, prefixed, to stderr; the LAST stdout line is the compact result."""
+    stream = stream or sys.stdout
+    line = compact_line(full)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, DETAIL_PATH), 'w') as f:
+            json.dump(full, f, indent=1)
+        line['detail'] = DETAIL_PATH
+    except OSError:
+        line['detail'] = None
+    text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT and '\n' not in text, len(text)
+    sys.stdout.flush()
+    print(text, file=stream, flush=True)
+    return text
+
+
+def _r(x, sig=5):
+    """numbers of the result line at `sig` significant digits (the side file keeps them in full); None for non-finite values"""
+    if isinstance(x, str):
+        return x if len(x) <= 240 else x[:237] + '...'       # no free-text field may grow the line
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float('inf'), float('-inf')):
+            return None
+        return float(f'{x:.{sig}g}')
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    return x
+
+
+def compact_line(full):
+    """The one JSON line the driver parses: the contract keys, `roofline`, `cpu_baseline` and a short numeric `parity` summary --
+    a pure function of the full record (tests/test_bench_line_cpu.py holds it under LINE_LIMIT)."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if (isinstance(d, dict) and len(ks) > 1) else (d.get(ks[0]) if isinstance(d, dict) else None))
+    cfgf, rf = full.get('config', {}), full.get('roofline', {})
+    line = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                     'vs_baseline', 'dtype', 'data')}
+    line['config'] = {k: cfgf.get(k) for k in ('workload', 'per_gpu_batch', 'global_batch_per_step', 'sample_num', 'sampling_steps', 'topk_hand',
+                                               'topk_obj', 'sample_T0', 'crop', 'pipeline_depth', 'parallelism', 'score_mfma', 'conv_mfma',
+                                               'winograd_3x3', 'nfev_hand_obj_per_step')}
+    line['config']['roi_window_pixel_share'] = g(cfgf, 'fpn_roi_window', 'pixel_share_hand_obj_per_batch') if g(cfgf, 'fpn_roi_window', 'enabled') else None
+    ser = g(rf, 'score_head', 'samplers_serialised') or {}
+    line['roofline'] = {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                               'algorithmic_bytes_per_launch', 'flop_per_launch_avg', 'avg_launch_us', 'launches_per_step', 'kernel_ms_per_step')}
+    line['roofline']['timing'] = 'HIP events per launch on the launch stream, instrumented repeat of the K steps'
+    # the largest kernel BY TIME is the score head; `frac` there is from exclusive durations (the object solve after the hand solve)
+    line['roofline']['dominant_by_time'] = {'kernel': 'score_head_kernel<true>', 'frac': ser.get('frac'), 'achieved': ser.get('achieved'),
+                                            'avg_launch_us': ser.get('avg_launch_us'), 'kernel_ms_per_step': g(rf, 'score_head', 'kernel_ms_per_step'),
+                                            'launches_per_step': g(rf, 'score_head', 'launches_per_step'), 'frac_overlapped': g(rf, 'score_head', 'frac')}
+    line['roofline']['classes_TFLOPs_ms'] = {k: [v.get('TFLOP/s'), v.get('kernel_ms_per_step')] for k, v in (rf.get('other_kernels') or {}).items()}
+    pe = g(rf, 'pose_encoder', 'samplers_serialised') or {}
+    line['roofline']['classes_TFLOPs_ms']['pose_encoder'] = [pe.get('TFLOP/s'), None]
+    line['roofline']['conv_family_algorithmic_frac'] = g(rf, 'conv_family_algorithmic', 'frac')
+    hb = g(full, 'hbm', 'kernels') or {}
+    line['hbm_GBps_frac'] = {k: [v.get('GB/s'), v.get('frac')] for k, v in hb.items()}
+    if full.get('cpu_baseline') is not None:
+        line['cpu_baseline'] = full['cpu_baseline']
+    par = full.get('parity')
+    if par is not None:
+        e2e, same = par.get('end_to_end_vs_oracle') or {}, par.get('aggregation_given_identical_candidates') or {}
+        within = 'images_within_1e-3_on_joints_vertices_6dof'
+        selfv = g(par, 'reference_self_agreement', 'variants') or {}
+        s64, f64j = par.get('sampler_vs_fp64') or {}, par.get('fp64_judge') or {}
+        line['parity'] = {
+            'images': e2e.get('images'), 'nfev_equal': par.get('nfev_equal'),
+            'upstream_max_abs': max((par.get('upstream_max_abs') or {'-': None}).values(), key=lambda v: -1.0 if v is None else v),
+            'e2e_lists_identical': e2e.get('images_all_selections_identical'), 'e2e_within_1e-3': e2e.get(within),
+            'e2e_gap_above_tie_bound': e2e.get('images_with_gap_above_tie_bound'),
+            'reference_vs_itself_lists_identical': [v.get('images_all_selections_identical') for v in selfv.values()],
+            'reference_vs_itself_within_1e-3': [v.get(within) for v in selfv.values()],
+            'same_candidates_lists_identical': same.get('images_all_selections_identical'), 'same_candidates_within_1e-3': same.get(within),
+            'same_candidates_gap_above_tie_bound': same.get('images_with_gap_above_tie_bound'),
+            'same_candidates_max_rel_gap': same.get('max_rel_score_gap_at_first_differences'),
+            'mpjpe_delta_mm': e2e.get('mpjpe_delta_mm_all'),
+            'fp64_referee_lists_within_reference_noise': g(par, 'fp64_referee', 'all_within_reference_noise'),
+            'fp64_referee_images_identical_hip_ref': [g(par, 'fp64_referee', 'images_identical_to_fp64_order'), g(par, 'fp64_referee', 'images_identical_to_fp64_order_fp32_reference')],
+            'sampler_err_ratio_hip_over_ref_max': [g(s64, 'hand', 'ratio_max'), g(s64, 'obj', 'ratio_max')],
+            'fp64_judge_within_1e-3_hip_ref': [f64j.get('images_within_1e-3_hip'), f64j.get('images_within_1e-3_oracle')] if f64j else None,
+        }
+    line['value_full_maps'] = g(full, 'value_full_maps', 'value')
+    line['opt_in_split_bf16x6_value'] = g(full, 'opt_in', 'split_bf16x6', 'value')
+    line['step_ms_min_median_max'] = full.get('step_ms_min_median_max')
+    line['host_busy_threads'] = g(full, 'host_cpu', 'busy_threads_equivalent')
+    line['metrics_rows_gathered'] = full.get('metrics_rows_gathered')
+    line['fabric'] = full.get('fabric')
+    return _r(line)
+
+
+def secondary_leg(args, model, batches, E, post, env, what):
+    """A secondary measurement, clearly separate from `value`: the same step through a fresh pipelined evaluator whose execution plans
+    are built under the environment switches `env` (read when a plan is built).  Used for the opt-in split-bf16 products (every fp32
+    product of the score head and of the direct convolutions from six exact bf16 x bf16 products, fp32 storage and accumulation:
+    DESIGN 4b, tests/test_gpu_split_head.py) and for the full-map FPN (`--no_roi_window`).  NOT the headline."""
     import torch
-    saved = {k: os.environ.get(k) for k in ('VPHO_SCORE_MFMA', 'VPHO_CONV_MFMA')}
-    os.environ['VPHO_SCORE_MFMA'] = os.environ['VPHO_CONV_MFMA'] = 'bf16x6'      # read when an execution plan is built
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         pipe = E.PipelinedPredictor(model, max(args.pipeline, 1))
         for f in [pipe.submit(batches[i % 2], post) for i in range(2 * max(args.pipeline, 1) + 1)]:
@@ -373,31 +493,39 @@ def opt_in_leg(args, model, batches, E, post):
                 os.environ.pop(key, None)
             else:
                 os.environ[key] = v
-    return {'split_bf16x6': {'value': k * args.bs / dt, 'unit': 'images/s', 'ms_per_step': dt / k * 1e3, 'steps': k,
-                             'what': 'same step, same evaluator; fp32 products of the score head and of the direct convolutions as 6 exact bf16 products each '
-                                     '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`'}}
+    return {'value': k * args.bs / dt, 'unit': 'images/s', 'ms_per_step': dt / k * 1e3, 'steps': k, 'what': what}
 
 
-PMC_ROUNDS = ('r05', 'r04', 'r03', 'r02', 'r01')
+PMC_ROUNDS = ('r06', 'r05', 'r04', 'r03', 'r02', 'r01')
+# counter passes are per workload: the README config (BASELINE cfg2) and the stress config (cfg4) each have their own file
+PMC_FILES = {'cfg2': '{rnd}_pmc_hbm_traffic.json', 'cfg4': '{rnd}_pmc_hbm_traffic_cfg4.json'}
 
 
-def pmc_traffic(kernel, per_kernel=False):
-    """HBM bytes per launch of the kernels whose name starts with `kernel`, LAUNCH-WEIGHTED over them (a profiling class such as
-    mano_fk covers several kernels: the matrix-core FK kernel and the packed-FMA ones), from the newest committed rocprofv3 --pmc
-    summary (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r0N_pmc_hbm_traffic.json by scripts/pmc_summary.py); None when
-    absent.  per_kernel: {'source': file, 'kernels': {name: bytes per launch, launches}} instead."""
+def workload_key(bs, sample_num, sampling_steps):
+    return {(64, 100, 50): 'cfg2', (128, 256, 100): 'cfg4'}.get((bs, sample_num, sampling_steps))
+
+
+def pmc_traffic(kernel, per_kernel=False, workload='cfg2', root=None):
+    """HBM bytes per launch of the kernels whose name starts with `kernel` (a name or a tuple of names), LAUNCH-WEIGHTED over them (a
+    profiling class covers several kernels: the one-tile and the persistent convolution, the matrix-core FK kernel and the packed-FMA
+    ones), from the newest committed rocprofv3 --pmc summary OF THIS WORKLOAD (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE;
+    profiles/rNN_pmc_hbm_traffic[_cfg4].json by scripts/pmc_summary.py); None when there is no pass for the workload.
+    per_kernel: {'source': file, 'kernels': {name: bytes per launch, launches}} instead."""
+    if workload not in PMC_FILES:
+        return None
+    names = (kernel,) if isinstance(kernel, str) else tuple(kernel)
     for rnd in PMC_ROUNDS:
-        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_hbm_traffic.json')
+        path = os.path.join(root or ROOT, 'profiles', PMC_FILES[workload].format(rnd=rnd))
         try:
             with open(path) as f:
                 tab = json.load(f)
         except Exception:
             continue
-        hit = {name: v for name, v in tab.items() if name.startswith(kernel) or kernel in name.split('(')[0]}
+        hit = {name: v for name, v in tab.items() if any(name.startswith(k) or k in name.split('(')[0] for k in names)}
         if not hit:
             continue
         if per_kernel:
-            return {'source': os.path.relpath(path, ROOT), 'kernels': {n: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'launches_in_pass': v['launches']} for n, v in hit.items()}}
+            return {'source': os.path.relpath(path, root or ROOT), 'kernels': {n: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'launches_in_pass': v['launches']} for n, v in hit.items()}}
         n = sum(v['launches'] for v in hit.values())
         return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit.values()) / max(n, 1)
     return None
