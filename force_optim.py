@@ -75,21 +75,43 @@ def main():
     ops.prof_enable('force_optim', False)
     if rank == 0:
         losses = out['losses'].mean(0).tolist()
-        # ALU-bound, not HBM / MFMA: 480 fp32 operations per (pair, anchor) item and iteration (counted in csrc/force_optim.hip) against
-        # the fp32 vector peak; the kernel is one 1024-thread workgroup per batch of 64 pairs -- a chain of dependent scalar arithmetic,
-        # half-wave reductions and one workgroup barrier per iteration.  The counted 480 operations are ~2 000 issued instructions (57 IEEE
-        # divisions and 20 square roots expand to ~10 each), and 157 workgroups leave 99 of the 256 CUs idle at the default 10 048 pairs
+        # ALU-bound, not HBM / MFMA: 480 fp32 operations per (pair, anchor) item and iteration (counted on the reference's arithmetic in
+        # csrc/force_optim.hip) against the fp32 vector peak (packed FMA).  One 1024-thread workgroup per batch of 64 pairs: a sample's 32
+        # anchors in one DPP row, two per lane in packed registers; ~640 issued instructions per thread and iteration (two items), of
+        # which ~70 are quarter-rate transcendentals (v_exp / v_rcp / v_sqrt / v_log); 157 workgroups leave 99 of the 256 CUs idle at the
+        # default 10 048 pairs.  VPHO_FORCE_EXACT=1: IEEE divisions / square roots and libm exp / log instead (2.8 x slower)
         tf = kprof['flops'] / kprof['total_ms'] / 1e9 if kprof['total_ms'] else None
-        roof = {'bound': 'valu', 'kernel': 'force_optim_kernel (3000 AdamW iterations per batch in one persistent workgroup)', 'achieved': tf, 'peak': 157.3,
-                'unit': 'TFLOP/s', 'frac': tf / 157.3 if tf else None, 'traffic': None, 'flop_per_pair_per_iteration': 480 * 32,
+        exact = os.environ.get('VPHO_FORCE_EXACT') == '1'
+        traffic, source = pmc_traffic('force_optim_kernel') if (args.pairs, args.batch_size, args.iters, exact) == (10048, 64, 3000, False) else (None, None)
+        roof = {'bound': 'valu', 'kernel': f'force_optim_kernel<{"true" if exact else "false"}> (3000 AdamW iterations per batch in one persistent workgroup)', 'achieved': tf, 'peak': 157.3,
+                'unit': 'TFLOP/s', 'frac': tf / 157.3 if tf else None, 'traffic': traffic, 'traffic_source': source, 'flop_per_pair_per_iteration': 480 * 32,
+                'algorithmic_bytes_per_launch': int(tot.item()) * (32 * (3 + 9 + 1 + 3 + 3 + 1 + 8) * 4 + 6 * 4 + 1),     # per pair: anchor points, frames, contact map in; two force labels, scale, cone weights out; gravity, centre of mass, flag
                 'kernel_ms': kprof['total_ms'], 'workgroups': (hi - lo), 'timing': 'HIP events around the launch on the launch stream',
-                'limited_by': 'vector-ALU issue: ~2 000 instructions per thread and iteration for the 480 counted operations (57 IEEE divisions, 20 square '
-                              'roots, 16 exp), 4 waves per SIMD; 157 workgroups for 256 CUs at 10 048 pairs'}
+                'limited_by': 'vector-ALU issue: ~640 instructions per thread (two items) and iteration for the 2 x 480 counted operations, ~70 of them '
+                              'quarter-rate transcendentals; 4 waves per SIMD; no scratch and no HBM traffic inside the loops; 157 workgroups for 256 CUs at 10 048 pairs'}
         print(json.dumps({'roofline': roof, 'metric': 'pseudo-force optimisation pairs/s (3000 AdamW iterations per pair)', 'value': float(tot.item() / dt.item()),
                           'unit': 'pairs/s', 'n_gpus': world, 'pairs': int(tot.item()), 'batch_size': args.batch_size, 'iters': args.iters,
                           'seconds': float(dt.item()), 'mean_losses_force_gravity_moment_dist': losses, 'data': 'synthetic'}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """(HBM bytes per launch, file) of `kernel` from the newest committed counter pass of THIS workload (profiles/rNN_force_pmc_hbm_traffic.json:
+    10 048 pairs, batches of 64, 3000 iterations; 2 x FETCH_SIZE + WRITE_SIZE), (None, None) when there is none."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rnd in ('r06', 'r05'):
+        path = os.path.join(root, 'profiles', f'{rnd}_force_pmc_hbm_traffic.json')
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except Exception:
+            continue
+        hit = [v for k, v in tab.items() if k.startswith(kernel)]
+        if hit:
+            # the pass holds the 10-iteration, one-batch warm-up launch too (a few hundred KB): the sum over launches IS the timed launch
+            return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit), os.path.relpath(path, root)
+    return None, None
 
 
 if __name__ == '__main__':

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 VPHO_API const char* vpho_last_error(void);
-VPHO_API int vpho_abi_version(void);   /* 9 */
+VPHO_API int vpho_abi_version(void);   /* 10 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,

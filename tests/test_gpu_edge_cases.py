@@ -136,6 +136,25 @@ def test_limit_free_kernels_agree_with_the_wavefront_kernels_and_with_torch(asse
         s_ = sc3[:, :, f].cpu()
         order = torch.stack([torch.tensor(sorted(range(1500), key=lambda c: (-float(s_[b, c]), c))[:10]) for b in range(4)])
         assert torch.equal(idx[:, f].cpu().long(), order) and torch.equal(val[:, f].cpu(), torch.gather(s_, 1, order))
+    # ---- the documented limits themselves: 16 384 candidates of a plain top-k = exactly 64 KB of dynamic LDS, and 16 000
+    # candidates of a cascade level (the 150-KB opt-in, per device since round 6)
+    big = torch.rand(2, 16384, generator=g)
+    big[0, 9000:9010] = big[0, 10:20]
+    big[1, 12345] = float('nan')                                   # ranks first; the value returned is the NaN itself (torch.topk)
+    val, idx = agg.topk(big.cuda(), 40)
+    bs_ = torch.where(torch.isnan(big), torch.full_like(big, float('inf')), big)
+    order = torch.sort(bs_, dim=1, descending=True, stable=True)[1][:, :40]
+    assert torch.equal(idx[:, 0].cpu().long(), order)
+    ev, gv = torch.gather(big, 1, order), val[:, 0].cpu()
+    assert torch.equal(torch.isnan(gv), torch.isnan(ev)) and bool(torch.isnan(gv[1, 0])) and torch.equal(gv[~torch.isnan(gv)], ev[~torch.isnan(ev)])
+    hv = torch.rand(1, 16000, 20, generator=g).cuda()
+    pose = (torch.randn(1, 16000, 48, generator=g) * 0.4).cuda()
+    val, idx, _, sc = agg.hand_fuse_level(hv, pose, 30, 2, want_scores=True)
+    for f in range(5):
+        s_ = sc[0, :, f].cpu()
+        order = torch.sort(s_, descending=True, stable=True)[1][:30]
+        assert torch.equal(idx[0, f].cpu().long(), order) and torch.equal(val[0, f].cpu(), s_[order])
+    assert torch.isfinite(pose).all()
     # ---- the cross module's attention over a batch of 300 images (sequence axis = batch axis, quirk Q3) against float64
     S, B, E, nh = 300, 65, 512, 2
     qkv = (torch.randn(S * B, 3 * E, generator=g) * 0.5).cuda()

@@ -77,7 +77,9 @@ def test_wavefront_topk_matches_a_stable_descending_sort(assets, n, F, k):
     xs = torch.where(torch.isnan(x), torch.full_like(x, float('inf')), x)
     sv, si = torch.sort(xs, dim=1, descending=True, stable=True)
     assert torch.equal(idx, si[:, :k].permute(0, 2, 1))
-    assert torch.equal(val, sv[:, :k].permute(0, 2, 1))
+    ev = torch.gather(x, 1, si[:, :k]).permute(0, 2, 1)      # a NaN ranks as +inf and is returned as itself (torch.topk's values)
+    assert torch.equal(torch.isnan(val), torch.isnan(ev)) and torch.equal(val[~torch.isnan(val)], ev[~torch.isnan(ev)])
+    assert (val[~torch.isnan(val)] == sv[:, :k].permute(0, 2, 1)[~torch.isnan(ev)]).all()
     assert idx.min() >= 0 and idx.max() < n
 
 

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(64) void topk_kernel(const float* __restrict__ scor
         v[s] = sc;
     }
     wave_topk(v, n, k, lane, val + (long long)row * k, idx + (long long)row * k);
+    // a NaN score was RANKED as +inf; the value torch.topk returns for it is the NaN itself (lane 0 wrote val / idx: same lane reads them)
+    if (lane == 0)
+        for (int r = 0; r < k; ++r)
+            if (val[(long long)row * k + r] == INFINITY) val[(long long)row * k + r] = scores[((long long)b * n + idx[(long long)row * k + r]) * F + f];
 }
 
 // Rows beyond 1024 candidates (sample_num > 512: the reference has no limit, aggregation.py:217,246,777): one 256-thread workgroup per row
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict_
         const float v = tk_v[c];
         int rank = 0;
         for (int j = 0; j < n; ++j) { const float o = tk_v[j]; rank += (o > v || (o == v && j < c)) ? 1 : 0; }
-        if (rank < k) { val[(long long)row * k + rank] = v; idx[(long long)row * k + rank] = c; }
+        // (a NaN score was ranked as +inf; the value written is the score itself, as torch.topk returns it)
+        if (rank < k) { val[(long long)row * k + rank] = v == INFINITY ? scores[((long long)b * n + c) * F + f] : v; idx[(long long)row * k + rank] = c; }
     }
 }
 
@@ -692,8 +697,7 @@ extern "C" int vpho_hand_fuse_level_f32(const float* hv, int n_obs, float* pose,
     if (C > 64 * TOPK_MAX_SLOTS || k > 64 || (any_env && atoi(any_env))) {
         const size_t lds = (size_t)(((C + 3) & ~3) + 7 * k) * sizeof(float);
         VPHO_REQUIRE(lds <= 150 * 1024, "vpho_hand_fuse_level_f32: %d candidates with k = %d do not fit LDS", C, k);
-        static bool opt_in = false;
-        if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hand_fuse_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
+        VPHO_DYN_LDS(hand_fuse_any_kernel, 150 * 1024);
         hipLaunchKernelGGL(hand_fuse_any_kernel, grid, dim3(FUSE_THREADS), lds, (hipStream_t)stream, a);
         return vpho::check_launch("hand_fuse_any_kernel");
     }
@@ -709,7 +713,8 @@ extern "C" int vpho_topk_f32(const float* scores, int rows_outer, int n, int F, 
     VPHO_REQUIRE(n <= 16384, "vpho_topk_f32: at most 16384 candidates per row (got %d)", n);
     if (n <= 512) hipLaunchKernelGGL(topk_kernel<8>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
     else if (n <= 64 * TOPK_MAX_SLOTS) hipLaunchKernelGGL(topk_kernel<16>, dim3(rows_outer * F), dim3(64), 0, (hipStream_t)stream, scores, n, F, k, val, idx);
-    else hipLaunchKernelGGL(topk_rank_kernel, dim3(rows_outer * F), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, scores, n, F, k, val, idx);
+    else VPHO_DYN_LDS(topk_rank_kernel, 16384 * sizeof(float));              // n = 16384 is exactly the 64-KB default limit: ask for it
+    if (n > 64 * TOPK_MAX_SLOTS) hipLaunchKernelGGL(topk_rank_kernel, dim3(rows_outer * F), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, scores, n, F, k, val, idx);
     return vpho::check_launch("topk_kernel");
 }
 

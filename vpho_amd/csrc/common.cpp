@@ -27,22 +27,19 @@ void prof_record(int cls, hipEvent_t a, hipEvent_t b, double flops, double bytes
     g_prof[cls].bytes += bytes;
 }
 
-// Arrival tickets of the in-launch reductions ("the workgroup that draws the last ticket of its group finishes the sum"): one zeroed
-// array of TICKET_SLOTS ints per (device, stream).  Launches of one stream run one after the other and every kernel puts its tickets
-// back to zero before it ends, so a stream needs one array; launches of different streams may overlap and never share one.
-static std::map<std::pair<int, hipStream_t>, int*> g_tickets;
-static std::mutex g_tickets_mu;
-int* tickets_for(hipStream_t s) {
+static std::map<std::pair<const void*, int>, int> g_dyn_lds;
+static std::mutex g_dyn_lds_mu;
+int dynamic_lds(const void* kernel, int bytes) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> l(g_tickets_mu);
-    auto it = g_tickets.find({dev, s});
-    if (it != g_tickets.end()) return it->second;
-    int* p = nullptr;
-    if (hipMalloc(&p, TICKET_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(p, 0, TICKET_SLOTS * sizeof(int), s) != hipSuccess) { (void)hipFree(p); return nullptr; }     // ordered before the first use, which is on s
-    g_tickets[{dev, s}] = p;
-    return p;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> l(g_dyn_lds_mu);
+    int& have = g_dyn_lds[{kernel, dev}];
+    if (have >= bytes) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", bytes, hipGetErrorString(e));
+    have = bytes;
+    return 0;
 }
 }  // namespace vpho
 
@@ -71,4 +68,4 @@ extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches,
 }
 
 extern "C" const char* vpho_last_error(void) { return vpho::err_slot(); }
-extern "C" int vpho_abi_version(void) { return 9; }
+extern "C" int vpho_abi_version(void) { return 10; }

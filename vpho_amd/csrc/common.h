@@ -28,12 +28,13 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(e1, s); prof_record(cls, e0, e1, flops, bytes); } }
 };
-// zeroed arrival-ticket array of a stream (common.cpp); nullptr when it cannot be allocated
-constexpr int TICKET_SLOTS = 4096;
-int* tickets_for(hipStream_t s);
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device): the attribute belongs to
+// the device's code object, so a process-wide flag would leave a second device's launches without it.
+int dynamic_lds(const void* kernel, int bytes);
 }  // namespace vpho
 
 #define VPHO_REQUIRE(cond, ...) do { if (!(cond)) return vpho::fail(__VA_ARGS__); } while (0)
+#define VPHO_DYN_LDS(kernel, bytes) do { if (vpho::dynamic_lds(reinterpret_cast<const void*>(kernel), (int)(bytes))) return 1; } while (0)
 #define VPHO_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return vpho::fail("%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 // Barrier that publishes `buffer_load ... lds` (LDS-DMA) tiles to the other waves of the workgroup: every wave first waits for ITS

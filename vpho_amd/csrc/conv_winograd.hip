@@ -763,13 +763,9 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     a.wins = wins; a.tile_base = tile_base; a.gate = gate; a.gate_slope = gate_slope; a.scatter = scatter;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     const size_t lds_staged = lds + (size_t)W_IN_PIXELS * 64;
-    static bool opt_in = false;
-    if (!opt_in) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
-        opt_in = true;
-    }
+    VPHO_DYN_LDS(conv_winograd_kernel<0>, lds);
+    VPHO_DYN_LDS(conv_winograd_kernel<1>, lds_staged);
+    VPHO_DYN_LDS(conv_winograd_kernel<2>, lds_staged);
     const int tbs = (a.T + W_TB - 1) / W_TB;
     // executed flops: 16 GEMMs of T x Cout x Cin (the direct 3x3 would be 2.25 x this)
     // (with windows: the live tiles when the caller knows them -- tiles_hint, profiling passes only --, else all)
@@ -800,11 +796,7 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
             hipLaunchKernelGGL(conv_winograd_kernel<0>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
         return vpho::check_launch("conv_winograd_kernel");
     }
-    static bool opt_in8 = false;
-    if (!opt_in8) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_winograd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opt_in8 = true;
-    }
+    VPHO_DYN_LDS(conv_winograd8_kernel, lds);
     hipLaunchKernelGGL(conv_winograd8_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, a);
     return vpho::check_launch("conv_winograd8_kernel");
 }

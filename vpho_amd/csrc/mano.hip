@@ -503,11 +503,7 @@ extern "C" int vpho_mano_fk_f32(const vpho_mano_tables* t, const float* pose, in
     // one 32-hand workgroup per CU takes ~95 us whatever the launch size: it pays from ~4 000 hands on (the packed-FMA kernel needs 61 us for
     // 1 920 hands, 166 us for 6 400)
     if (verts && t->posedirs_mfma && n_hands >= 4096 && hands_per_image >= MH / 2 && !no_mfma) {
-        static bool opt_in = false;
-        if (!opt_in) {
-            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mano_fk_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FkMfmaLds)));
-            opt_in = true;
-        }
+        VPHO_DYN_LDS(mano_fk_mfma_kernel, sizeof(FkMfmaLds));
         hipLaunchKernelGGL(mano_fk_mfma_kernel, dim3((unsigned)((n_hands + MH - 1) / MH)), dim3(512), sizeof(FkMfmaLds), (hipStream_t)stream, a);
         return vpho::check_launch("mano_fk_mfma_kernel");
     }

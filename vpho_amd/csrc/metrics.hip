@@ -2,6 +2,7 @@
 // (lib/engine/test.py:657-680) with the Procrustes alignment of transform_fn.rigid_transform_3D_AtoB (:43-58), so that the
 // evaluation loop ships 8 floats per image to the all-gather instead of copying (bs,S,778,3) candidates to the host.
 // One block per image; reductions and the 3x3 SVD (Jacobi on H^T H) in fp64.  HBM-bound: 24 B read per point.
+#include <type_traits>
 #include "common.h"
 #include "rot.h"
 #include <algorithm>
@@ -24,26 +25,43 @@ __device__ inline double block_sum(double v, double* red) {
 
 // eigen-decomposition of a symmetric 3x3 (cyclic Jacobi); eigenvalues descending, eigenvectors in the columns of V
 __device__ inline void sym3_eig(double A[3][3], double w[3], double V[3][3]) {
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j;
+    // all indices are compile-time constants (unrolled pairs, a three-element sorting network on whole columns): registers, no scratch
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j;
     for (int sweep = 0; sweep < 30; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
         if (!(off > 1e-300)) break;
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 if (!(fabs(A[p][q]) > 1e-300)) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
             }
     }
-    int order[3] = {0, 1, 2};
-    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (A[order[j]][order[j]] > A[order[i]][order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
-    double Vs[3][3];
-    for (int k = 0; k < 3; ++k) { w[k] = A[order[k]][order[k]]; for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][order[k]]; }
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = Vs[i][j];
+    // eigenvalues descending with their columns: the exchanges of the former index sort (0,1), (0,2), (1,2), each on a strict ">"
+    w[0] = A[0][0]; w[1] = A[1][1]; w[2] = A[2][2];
+    auto cswap = [&](auto I, auto J) {
+        constexpr int i = decltype(I)::value, j = decltype(J)::value;
+        const bool sw = w[j] > w[i];
+        const double wi = w[i], wj = w[j];
+        w[i] = sw ? wj : wi; w[j] = sw ? wi : wj;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double a = V[k][i], b = V[k][j]; V[k][i] = sw ? b : a; V[k][j] = sw ? a : b; }
+    };
+    cswap(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    cswap(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    cswap(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
 }
 
 __global__ __launch_bounds__(256) void hand_metrics_kernel(const float* __restrict__ pd, const float* __restrict__ gt, int n,

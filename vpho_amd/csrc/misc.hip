@@ -687,8 +687,7 @@ extern "C" int vpho_mha_dropout_f32(const float* qkv, int S, int B, int E, int n
     size_t lds = (size_t)(S * (hd + 1) + S * hd) * sizeof(float);
     const int use_lds = lds <= 150 * 1024;
     if (!use_lds) lds = 0;
-    static bool opt_in = false;
-    if (!opt_in) { VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); opt_in = true; }
+    VPHO_DYN_LDS(mha_generic_kernel, 150 * 1024);
     hipLaunchKernelGGL(mha_generic_kernel, dim3(B * nhead), dim3(256), lds, (hipStream_t)stream, qkv, S, B, E, nhead, use_lds, out);
     return vpho::check_launch("mha_kernel");
 }

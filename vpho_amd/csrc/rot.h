@@ -110,13 +110,23 @@ __device__ inline void mano_rodrigues(const float* aa, float* R) {
 // transform_fn.average_quaternion's torch.linalg.eigh(A)[1][..., -1]; sign fixed by the caller.
 template <typename T>
 __device__ inline void sym4_top_eigenvector(T A[4][4], T* v) {
+    // every index into A and V is a compile-time constant (the (p, q) pairs and the k loops are unrolled, the final column is picked by
+    // selects): the matrices stay in registers -- indexed by loop variables they lived in scratch (80-144 B per lane, 9 x the fuse
+    // kernels' algorithmic HBM bytes).  Same operations in the same order: bit-identical results.
     T V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     for (int sweep = 0; sweep < 12; ++sweep) {
         T off = 0, dg = 0;
-        for (int p = 0; p < 4; ++p) { dg += A[p][p] * A[p][p]; for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            dg += A[p][p] * A[p][p];
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        }
         // converged: a rotation by an angle below eps / 4 no longer changes a digit of A or V (c = 1, s * a < ulp(a))
         if (off < (T)1e-40 || off <= dg * (sizeof(T) == 4 ? (T)2e-16 : (T)1e-33)) break;
+#pragma unroll
         for (int p = 0; p < 3; ++p) {
+#pragma unroll
             for (int q = p + 1; q < 4; ++q) {
                 // exactly (or denormally) zero off-diagonal: nothing to rotate.  Matters for rank-deficient moment matrices
                 // (k identical quaternions): a second sweep would otherwise evaluate 0/0 between two zero eigenvalues.
@@ -124,15 +134,25 @@ __device__ inline void sym4_top_eigenvector(T A[4][4], T* v) {
                 const T theta = (A[q][q] - A[p][p]) / ((T)2 * A[p][q]);
                 const T t = (theta >= 0 ? (T)1 : (T)-1) / (t_abs(theta) + t_sqrt(theta * theta + (T)1));
                 const T c = (T)1 / t_sqrt(t * t + (T)1), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const T akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const T apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const T vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
             }
         }
     }
-    int best = 0;
-    for (int i = 1; i < 4; ++i) if (A[i][i] > A[best][best]) best = i;
-    for (int k = 0; k < 4; ++k) v[k] = V[k][best];
+    T top = A[0][0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = V[k][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const bool better = A[i][i] > top;                       // first of equal maxima, as before
+        top = better ? A[i][i] : top;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = better ? V[k][i] : v[k];
+    }
 }
 
 }  // namespace vpho

@@ -1488,11 +1488,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         vpho::ProfScope pe_prof(vpho::PROF_POSE_ENC, c.s, 2.0 * (double)c.R * 256.0 * (K1 + 256.0), 0.0);
         if (pe_ring) {
             const size_t pe_lds = (size_t)(PE_NST * PE_STAGE + PE_ROWS * PE_H_LD + 512 + PE_ROWS * (K1 + 4)) * sizeof(float);
-            static bool pe_opt_in = false;
-            if (!pe_opt_in) {
-                VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                pe_opt_in = true;
-            }
+            VPHO_DYN_LDS(pose_encoder_kernel, 150 * 1024);
             VPHO_REQUIRE(pe_lds <= 150 * 1024, "pose encoder: input dimension %d too large for the LDS tile", pa.Dp);
             hipLaunchKernelGGL(pose_encoder_kernel, pe_grid, dim3(512), pe_lds, c.s, pa);
         } else {
@@ -1516,12 +1512,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     // [2] stages | [256][4] epilogue table | per-image terms (3 x 257 of 1024 floats)
     size_t lds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 2 * 128 * 4) * sizeof(float);
     if (getenv("VPHO_HEAD_LDS")) lds = (size_t)atoi(getenv("VPHO_HEAD_LDS"));   // tuning aid: force 1 block/CU
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_opt_in = true;
-    }
+    VPHO_DYN_LDS(score_head_kernel<true>, lds);
+    VPHO_DYN_LDS(score_head_kernel<false>, lds);
     // Tile plan: 128-row tiles; when the last round of the launch would be less than half full, the rows beyond the last full round
     // become 32-row tail tiles (see head_tile).  VPHO_HEAD_TAIL=0: ordinary tiles only.
     static const int tail_on = getenv("VPHO_HEAD_TAIL") ? atoi(getenv("VPHO_HEAD_TAIL")) : 1;
@@ -1544,12 +1536,8 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
     a.w1p_split = (const unsigned short*)c.w->w1_p_split;
     if (c.w->w1_p_split && (c.w->split_terms == 6 || c.w->split_terms == 9)) {
         const size_t slds = (size_t)(2 * (3 * 256 * SP_K / 2 + 128 * SP_K) + 256 * 4 + 2 * 128 * 4) * sizeof(float);
-        static bool split_opt_in = false;
-        if (!split_opt_in) {
-            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_split_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-            VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_split_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-            split_opt_in = true;
-        }
+        VPHO_DYN_LDS(score_head_split_kernel<6>, slds);
+        VPHO_DYN_LDS(score_head_split_kernel<9>, slds);
         vpho::ProfScope prof(vpho::PROF_SCORE_HEAD, c.s, (double)c.R * c.w->nheads * (2.0 * 256 * 256 + 2.0 * 256 * 3));
         const dim3 grid((unsigned)(nheads * (a.full_tiles + a.tail_tiles)));
         if (c.w->split_terms == 6) hipLaunchKernelGGL(score_head_split_kernel<6>, grid, dim3(512), slds, c.s, a);
@@ -1571,11 +1559,7 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         const bool cb = c.S >= 64 && cb_env;
         if (pers && cb && (double)c.R * c.w->D * 4.0 < 3.9e9 && (double)c.w->nheads * 256 * 256 * 4.0 < 3.9e9) {
             const size_t plds = (size_t)(2 * (256 + 128) * HB_K + 256 * 4 + 1024 + 8 * 128 * 4) * sizeof(float);     // 72 KB: two workgroups per CU
-            static bool pers_opt_in = false;
-            if (!pers_opt_in) {
-                VPHO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_head_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-                pers_opt_in = true;
-            }
+            VPHO_DYN_LDS(score_head_pers_kernel<true>, plds);
             const dim3 pgrid((unsigned)std::min<long long>((long long)grid.x, (long long)slots));
             hipLaunchKernelGGL(score_head_pers_kernel<true>, pgrid, dim3(512), plds, c.s, a);       // sample_num >= 64 (the LDS copy of the per-image terms); smaller: the one-tile kernel
             return vpho::check_launch("score_head_pers_kernel");

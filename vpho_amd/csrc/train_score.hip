@@ -235,16 +235,9 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colArgs a) {
 // mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy * xhat) with xhat = (x - mean) * invstd
 struct BnRedArgs {
     const float* x; const float* dy; const float* mean; const float* invstd; long long rows; int C, ld, mode, rows_per_chunk; double* part;
-    // fin != 0: the workgroup that draws the LAST arrival ticket of its column block also finishes the block's channels -- the row chunks
-    // summed in the order of finish_sums below, so the results are those of the separate finishing kernels bit for bit -- and the
-    // launch that followed every reduction (140 + 140 + 45 of them in a training step, ~9 us each) is gone.  Opt-in: launch_col_reduce.
-    // fin 1: o0 = column sum (mode 2);  2: o0 = mean, o1 = invstd, running stats rm / rv (mode 0);  3: o0 = dbeta, o1 = dgamma (mode 1)
-    int fin; int* tickets; float* o0; float* o1; float* rm; float* rv; float eps, momentum;
 };
 // block = 8 column groups of V channels x 32 row groups over one chunk of rows; a thread walks rows g, g+32, ... of its chunk with
 // four loads in flight, fp64 partial sums; the 32 row groups are combined in a fixed order.  mode 2: plain column sum (s0 only).
-__device__ inline void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int V>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const BnRedArgs a) {
     __shared__ double p0[32][8 * V], p1[32][8 * V];
@@ -297,71 +290,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const BnRedArgs a) {
         if (cc < a.C) {
             double t0 = p0[0][threadIdx.x], t1 = p1[0][threadIdx.x];
             for (int k = 1; k < 32; ++k) { t0 += p0[k][threadIdx.x]; t1 += p1[k][threadIdx.x]; }
-            // write-through (sc1) stores: the partial sums are in memory, not in this XCD's L2, when the store completes -- the ticket
-            // below then needs no release fence (an agent-scope release writes back the XCD's whole L2: measured +9 ms per training step)
-            if (a.mode == 2) st_agent(a.part + (long long)blockIdx.y * a.C + cc, t0);
+            if (a.mode == 2) a.part[(long long)blockIdx.y * a.C + cc] = t0;
             else {
-                st_agent(a.part + ((long long)blockIdx.y * 2) * a.C + cc, t0);
-                st_agent(a.part + ((long long)blockIdx.y * 2 + 1) * a.C + cc, t1);
+                a.part[((long long)blockIdx.y * 2) * a.C + cc] = t0;
+                a.part[((long long)blockIdx.y * 2 + 1) * a.C + cc] = t1;
             }
-        }
-    }
-    if (!a.fin) return;
-    // ---- in-launch finish (cdna_hip_programming.md, split-K recipe, write-through form): partial sums stored sc1 -> every wave's
-    // stores complete -> barrier -> relaxed agent-scope ticket; the last arriver puts the ticket back to zero for the next launch of this
-    // stream and sums the chunks in the fixed order, reading every partial sum with an agent-scope (sc1) load.  Correct wherever the
-    // block's workgroups ran (any CU, any XCD); which workgroup finishes does not change the result.
-    const int chunks = gridDim.y;
-    int* last = reinterpret_cast<int*>(&p1[0][0]);           // p1 is dead once the block's sums are written (barrier below)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(a.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int is_last = t == chunks - 1;
-        if (is_last) __hip_atomic_store(a.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *last = is_last;
-    }
-    __syncthreads();
-    if (!*last) return;
-    __syncthreads();                                         // everybody has read the flag before p1 is reused
-    // the block's 8 * V channels x 8 chunk groups (chunks g, g + 8, ... per thread, the 8 group sums combined in order): finish_sums' order
-    constexpr int CB = 8 * V;
-    const int cl = threadIdx.x % CB, fg = threadIdx.x / CB, c1 = blockIdx.x * CB + cl;
-    if (fg < 8) {
-        double a0 = 0.0, a1 = 0.0;
-        if (c1 < a.C) {
-            // at most 256 chunks = 32 per thread: all loads in flight at once, summed in order afterwards
-            double v0[32], v1[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const int k = fg + 8 * j;
-                v0[j] = 0.0; v1[j] = 0.0;
-                if (k < chunks) {
-                    if (a.mode == 2) v0[j] = ld_agent(a.part + (long long)k * a.C + c1);
-                    else { v0[j] = ld_agent(a.part + ((long long)k * 2) * a.C + c1); v1[j] = ld_agent(a.part + ((long long)k * 2 + 1) * a.C + c1); }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 32; ++j) if (fg + 8 * j < chunks) { a0 += v0[j]; a1 += v1[j]; }
-        }
-        p0[fg][cl] = a0; p1[fg][cl] = a1;
-    }
-    __syncthreads();
-    if (fg != 0 || c1 >= a.C) return;
-    double s = p0[0][cl], ss = p1[0][cl];
-    for (int k = 1; k < 8; ++k) { s += p0[k][cl]; ss += p1[k][cl]; }
-    if (a.fin == 1) a.o0[c1] = (float)s;
-    else if (a.fin == 3) { a.o0[c1] = (float)s; a.o1[c1] = (float)ss; }
-    else {
-        const double m = s / (double)a.rows;
-        double var = ss / (double)a.rows - m * m;
-        if (var < 0.0) var = 0.0;
-        a.o0[c1] = (float)m;
-        a.o1[c1] = (float)(1.0 / sqrt(var + (double)a.eps));
-        if (a.rm) {
-            const double unbiased = a.rows > 1 ? var * (double)a.rows / (double)(a.rows - 1) : var;
-            a.rm[c1] = (float)((1.0 - a.momentum) * (double)a.rm[c1] + a.momentum * m);
-            a.rv[c1] = (float)((1.0 - a.momentum) * (double)a.rv[c1] + a.momentum * unbiased);
         }
     }
 }
@@ -400,28 +333,17 @@ int col_chunks(long long rows, int C, int V, int* rows_per_chunk) {
     *rows_per_chunk = (int)((rows + chunks - 1) / chunks);
     return (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
 }
-// launches the column reduction; returns the number of chunks written to the workspace
-// `fin` (see BnRedArgs): the caller's finishing step.  VPHO_COL_FINISH=fused does it inside this launch (when the stream's tickets cover
-// the column blocks); the DEFAULT is the separate finishing kernel: measured on MI355X (scripts/train_ab.sh, two boxes) the fused form
-// makes the training step 0.5-2 ms SLOWER -- the one-workgroup finishing kernels overlap the weight-gradient stream for free, whereas
-// the ticket (write-through store, wait, atomic round trip: ~2.5 us) lengthens every workgroup of a chip-filling launch that is one
-// round of workgroups long.  The return value is the number of chunks when the caller still has to launch its finishing kernel, 0 when
-// the results are already written, -1 when no tickets could be allocated.
+// launches the column reduction; returns the number of chunks written to the workspace (the caller launches its finishing kernel: the
+// in-launch finish by arrival tickets of round 5 made the training step 0.5-2 ms slower -- the one-workgroup finishing kernels overlap
+// the weight-gradient stream for free -- and was removed in round 6 together with its per-stream ticket allocation)
 int launch_col_reduce(BnRedArgs a, hipStream_t s) {
     const bool vec = a.C % 4 == 0 && a.ld % 4 == 0 && aligned16(a.x) && (a.mode != 1 || aligned16(a.dy));
     const int V = vec ? 4 : 1;
     const int chunks = col_chunks(a.rows, a.C, V, &a.rows_per_chunk);
     const dim3 grid((a.C + 8 * V - 1) / (8 * V), chunks);
-    const char* env = getenv("VPHO_COL_FINISH");                          // read per call
-    const bool separate = !(env && env[0] == 'f') || (int)grid.x > vpho::TICKET_SLOTS;
-    if (a.fin && !separate) {
-        a.tickets = vpho::tickets_for(s);
-        if (!a.tickets) return -1;
-    } else a.fin = 0;
-    const int fused = a.fin;
     if (vec) hipLaunchKernelGGL(col_reduce_kernel<4>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, s, a);
-    return fused ? 0 : chunks;
+    return chunks;
 }
 // statistics: mean, biased variance -> invstd = 1/sqrt(var + eps); running stats with the unbiased variance (torch semantics)
 __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
@@ -896,10 +818,9 @@ extern "C" int vpho_relu_bwd_f32(const float* dy, int ld_dy, const float* y, int
 
 extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols, float* out, void* workspace, void* stream) {
     VPHO_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
-    BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, cols, ld, 2, 0, (double*)workspace, 1, nullptr, out, nullptr, nullptr, nullptr, 0.f, 0.f};
+    BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, cols, ld, 2, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, (hipStream_t)stream);
-    VPHO_REQUIRE(chunks >= 0, "vpho_colsum_f32: no arrival tickets for this stream (hipMalloc failed)");
-    if (chunks > 0) hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
     return vpho::check_launch("colsum kernels");
 }
 
@@ -954,10 +875,9 @@ extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, 
     VPHO_REQUIRE(x && gamma && beta && save_mean && save_invstd && y && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_forward_f32: bad argument");
     VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_f32: running_mean/var must come together");
     hipStream_t s = (hipStream_t)stream;
-    BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace, 2, nullptr, save_mean, save_invstd, running_mean, running_var, eps, momentum};
+    BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, s);
-    VPHO_REQUIRE(chunks >= 0, "vpho_bn_train_forward_f32: no arrival tickets for this stream (hipMalloc failed)");
-    if (chunks > 0) hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
                        running_mean, running_var);
     if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd) &&
         (!res || aligned16(res)))
@@ -971,10 +891,9 @@ extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long 
                                           const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream) {
     VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C, "vpho_bn_train_backward_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    BnRedArgs ra{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace, 3, nullptr, dbeta, dgamma, nullptr, nullptr, 0.f, 0.f};
+    BnRedArgs ra{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, s);
-    VPHO_REQUIRE(chunks >= 0, "vpho_bn_train_backward_f32: no arrival tickets for this stream (hipMalloc failed)");
-    if (chunks > 0) hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
     if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
         aligned16(dbeta) && aligned16(dgamma))
         hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);

@@ -17,6 +17,10 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
+ABI_VERSION = 10                        # include/vpho_hip.h; a stale library must not be found out by a missing symbol halfway through a run
+if lib.vpho_abi_version() != ABI_VERSION:
+    raise ImportError(f'{LIB_PATH} implements ABI version {lib.vpho_abi_version()}, this binding expects {ABI_VERSION}: rebuild the '
+                      f'extension (python -m vpho_amd.build --force)')
 lib.vpho_obj_metrics_workspace_bytes.restype = C.c_longlong
 lib.vpho_bn_workspace_bytes.restype = C.c_longlong
 lib.vpho_conv2d_wgrad_workspace_bytes.restype = C.c_longlong
