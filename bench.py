@@ -452,6 +452,8 @@ def compact_line(full):
             'same_candidates_lists_identical': same.get('images_all_selections_identical'), 'same_candidates_within_1e-3': same.get(within),
             'same_candidates_gap_above_tie_bound': same.get('images_with_gap_above_tie_bound'),
             'same_candidates_max_rel_gap': same.get('max_rel_score_gap_at_first_differences'),
+            'same_candidates_gaps_all_within_2eps32_in_fp64': (all(g_['within_2_eps32'] for g_ in par['identical_candidates_gaps_above_tie_bound'])
+                                                               if par.get('identical_candidates_gaps_above_tie_bound') is not None else None),
             'mpjpe_delta_mm': e2e.get('mpjpe_delta_mm_all'),
             'fp64_referee_lists_within_reference_noise': g(par, 'fp64_referee', 'all_within_reference_noise'),
             'fp64_referee_images_identical_hip_ref': [g(par, 'fp64_referee', 'images_identical_to_fp64_order'), g(par, 'fp64_referee', 'images_identical_to_fp64_order_fp32_reference')],
@@ -464,7 +466,9 @@ def compact_line(full):
     line['host_busy_threads'] = g(full, 'host_cpu', 'busy_threads_equivalent')
     line['metrics_rows_gathered'] = full.get('metrics_rows_gathered')
     line['fabric'] = full.get('fabric')
-    return _r(line)
+    line = _r(line)
+    line['value'], line['ms_per_step'] = full.get('value'), full.get('ms_per_step')       # the contract's two numbers in full: value = images / (steps x ms_per_step)
+    return line
 
 
 def secondary_leg(args, model, batches, E, post, env, what):
@@ -580,7 +584,21 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
     given_same, _ = parity_summary(out, same_out, eng_info['agg'], same['dbg'], args.sample_num, bound=TIE_REL)
     # the judge of the top-k chain: every list of the HIP path re-scored in fp64 on the HIP path's own candidates (oracle/referee.py)
     from oracle import referee as RFE
-    ref_sum = RFE.summary(RFE.referee(assets, skeleton, RFE.record_from_hip(out, eng_info, data)))
+    rf = RFE.referee(assets, skeleton, RFE.record_from_hip(out, eng_info, data))
+    ref_sum = RFE.summary(rf)
+    # every first difference on identical candidates whose fp32 score gap is above TIE_REL, judged in float64: the distance of the exchanged
+    # candidates' fp64 scores against the rounding noise eps32 of the reference's own arithmetic on that very score vector -- within
+    # 2 eps32 both picks are picks the reference's arithmetic could have made (any top-k of scores within eps of the truth)
+    from oracle import judge_fp64 as JF
+    rsame = JF._report(eng_info['agg'], same['dbg'], args.sample_num)
+    fsame = JF.first_flip(rsame)
+    gaps_above = []
+    for b in (rsame['primary_gap_per_image'] > TIE_REL).nonzero().reshape(-1).tolist():
+        st = JF.STAGES[int(fsame[b])]
+        gb, eb = rf[st]['exchange_gap_bf'][b], rf[st]['eps32_bf'][b]
+        fi = int(gb.argmax())
+        gaps_above.append({'image': b, 'stage': st, 'rel_gap_of_the_fp32_scores': float(rsame['primary_gap_per_image'][b]), 'fp64_gap_of_the_exchanged_candidates_rel': float(gb[fi]),
+                           'eps32_of_that_score_vector_rel': float(eb[fi]), 'within_2_eps32': bool(gb[fi] <= 2 * eb[fi])})
     # the sampler's own referee: both ODEs solved in fp64 on the accepted step sequence (rows are independent on a fixed sequence: every
     # 4th hypothesis), each side against the exact solution of the same scheme on its own encoding (oracle/sampler_fp64.py)
     from oracle import sampler_fp64 as SF
@@ -632,7 +650,8 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                                                '|x - x_fp64|, ratio = HIP / oracle (<= 1: the kernels are at least as close to the exact scheme as the reference\'s fp32 arithmetic)'),
                        'reference_self_agreement': self_rep,
                        'end_to_end_vs_oracle': end_to_end,
-                       'aggregation_given_identical_candidates': given_same}}
+                       'aggregation_given_identical_candidates': given_same,
+                       'identical_candidates_gaps_above_tie_bound': gaps_above}}
 
 
 if __name__ == '__main__':

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 VPHO_API const char* vpho_last_error(void);
-VPHO_API int vpho_abi_version(void);   /* 10 */
+VPHO_API int vpho_abi_version(void);   /* 11 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -102,6 +102,14 @@ typedef struct {
      * form (sum, bias, add) by fp32 rounding. */
     const float* x2;
     int Cin2, x2_ld, stride2, H2, W2;
+    /* Optional (0 / 1 = off; ABI version 11): GROUPED launch -- group g = 0 .. groups-1 runs the same problem on x + g*x_group, w + g*w_group,
+     * bias + g*bias_group, y + g*y_group, res + g*res_group, x2 + g*x2_group, in_scale / in_shift + g*pre_group, res_up + g*ru_group (floats;
+     * multiples of 4; x_group = 0: every group reads the same input).  The hand and the object branch of the feature path are twins
+     * -- layer2 / layer3, FPN laterals, heat-map heads, encoders: same shapes, different weights (backbone_FPN_HFL.py:79-109, VPHO.py:131-149)
+     * -- and run as ONE launch each: twice the tiles, half the launches; every output element's k order is unchanged (bit-identical to
+     * the two single launches).  No splits / pixel list / gate / bf16 planes. */
+    int groups;
+    long long x_group, w_group, bias_group, y_group, res_group, x2_group, pre_group, ru_group;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 VPHO_API int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
@@ -118,6 +126,11 @@ VPHO_API int vpho_conv3x3_winograd_nhwc_f32(const float* x, const float* u, cons
  * COMPACT (rows, Cout) matrix vpho_roi_align_window_nhwc_f32 reads; x is the ordinary (N,H,W,x_ld) map, of which only the windows
  * dilated by one pixel need to hold data.  Device-side lists: the grid is sized for all tiles, blocks past the last live tile exit
  * (no host round trip, replays in a HIP graph with new boxes).  tiles_hint (0 = unknown) only feeds the profiling counters. */
+/* GROUPED form (ABI version 11): `groups` independent convolutions of the same shape in one launch (the twin hand / object branches):
+ * group g reads x + g*x_group (floats; 0 = every group reads the same input), u + g*16*Cout*Cin, bias + g*Cout and writes images
+ * [g*N, (g+1)*N) of y (groups*N, H, W, y_ld).  Bit-identical to `groups` single launches. */
+VPHO_API int vpho_conv3x3_winograd_grouped_nhwc_f32(const float* x, long long x_group, const float* u, const float* bias, int groups, int N, int H, int W,
+                                           int Cin, int x_ld, int Cout, float out_slope, float* y, int y_ld, void* stream);
 VPHO_API int vpho_winograd_window_tiles_i32(const int* wins, int N, int* tile_base, void* stream);
 /* ... and with the window pixels written IN PLACE into the ordinary (N,H,W,y_ld) map y, every other pixel of y left untouched (the
  * input gradient of an FPN smoothing convolution: non-zero only in the RoI windows dilated by the 3x3 halo; the caller zeroes y) */

@@ -182,8 +182,8 @@ def obj_heat_scores(ycb, pose6d, root, names, is_right, K, heatmap, bbox, dtype=
     return _bicubic_lookup(heatmap, pt2d, list(range(heatmap.shape[1]))).sum(-1)
 
 
-def obj_heat_topk(ycb, pose6d, root, names, is_right, K, heatmap, bbox, k):
-    hv = obj_heat_scores(ycb, pose6d, root, names, is_right, K, heatmap, bbox)
+def obj_heat_topk(ycb, pose6d, root, names, is_right, K, heatmap, bbox, k, dtype=torch.float32):
+    hv = obj_heat_scores(ycb, pose6d, root, names, is_right, K, heatmap, bbox, dtype=dtype)
     val, idx = topk_stable(hv, k, dim=1)
     return idx, (val + 1e-8) / (val.sum(dim=1, keepdim=True) + 1e-8), hv
 
@@ -211,8 +211,8 @@ def obj_physics_scores(ycb, pose6d, root, names, is_right, force_point, force_gl
     return -(score * L)
 
 
-def obj_physics_topk(ycb, pose6d, root, names, is_right, force_point, force_global, k):
-    score = obj_physics_scores(ycb, pose6d, root, names, is_right, force_point, force_global)
+def obj_physics_topk(ycb, pose6d, root, names, is_right, force_point, force_global, k, dtype=torch.float32):
+    score = obj_physics_scores(ycb, pose6d, root, names, is_right, force_point, force_global, dtype=dtype)
     val, idx = topk_stable(score, k, dim=1)
     return idx, torch.ones_like(val) / k, score
 
@@ -263,7 +263,9 @@ def hand_physics(mano, anchor, anchor_skeleton, pose58, root_flip, force_local, 
 # ------------------------------------------------------------------ HOI_Aggregator.__call__ (aggregation.py:1167-1353)
 def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, root_joint, is_right, force_local,
                   is_grasped, hand_pose_diff, hand_pose_regression, hand_shape, hand_heatmap, hand_bbox, hand_topk,
-                  obj_pose6d, obj_heatmap, obj_bbox, obj_topk, obj_name, phy_topk=5):
+                  obj_pose6d, obj_heatmap, obj_bbox, obj_topk, obj_name, phy_topk=5, dtype=torch.float32):
+    """dtype: the arithmetic of the object branch's scores (float32 = the reference, which casts the sampler's fp64 object poses with
+    .float(), aggregation.py:753; float64: the end-to-end judge of oracle/judge_fp64.py, every other input given in double too)."""
     mano, ycb, anchor = assets['mano'], assets['ycb'], assets['anchor']
     bs = root_joint.shape[0]
     S = hand_pose_diff.shape[0] // bs
@@ -273,7 +275,7 @@ def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, ro
     agg_mano = torch.cat([h['fused_pose'], betas], -1)
     fpnt, fglob = local_to_global(anchor, anchor_skeleton, force_local, h['agg_vert'] + root_joint_flip[:, None])
 
-    common = dict(root=root_joint, names=obj_name, is_right=is_right)
+    common = dict(root=root_joint, names=obj_name, is_right=is_right, dtype=dtype)
     t_idx, t_w, t_hv = obj_heat_topk(ycb, obj_pose6d, K=cam_intrinsic, heatmap=obj_heatmap, bbox=obj_bbox, k=obj_topk, **common)
     transl = fuse_topk(obj_pose6d, t_idx, t_w)[:, 6:]
     upd = obj_pose6d.clone()
@@ -288,7 +290,7 @@ def hoi_aggregate(assets, anchor_skeleton, *, cam_intrinsic, root_joint_flip, ro
     new_idx = torch.where(is_grasped[:, None], p_idx, m_idx)
     new_w = torch.where(is_grasped[:, None], p_w, m_w)
     obj_fused = fuse_topk(cand, new_idx, new_w)
-    p = obj_fused.clone().float()
+    p = obj_fused.clone().to(dtype)
     p[..., 6:] = p[..., 6:] + root_joint
     obj_vert = flip_x(object_points(ycb, p, obj_name, 'verts_sampled'), is_right)
 

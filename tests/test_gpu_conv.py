@@ -358,3 +358,74 @@ def test_persistent_multi_tile_convolution_is_bit_identical_to_the_one_tile_kern
     finally:
         os.environ.pop('VPHO_CONV_PERS', None)
     assert torch.equal(wide[..., 32:32 + Cout], out['0']) and float(wide[..., :32].min()) == 7.0 and float(wide[..., 32 + Cout:].max()) == 7.0
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,k,stride,opt', [
+    (64, 16, 256, 1024, 1, 1, 'res'),          # conv3 of a layer3 bottleneck: both branches = 2048 tiles (persistent walk per group)
+    (64, 16, 1024, 256, 1, 1, ''),             # conv1: 256 tiles per branch -- half the slots alone, one full round together
+    (64, 32, 256, 128, 1, 1, 'shared'),        # the first block of layer2: both branches read the SAME block input
+    (64, 32, 128, 512, 1, 2, 'x2shared'),      # ... and its conv3 with the merged projection shortcut of that shared input
+    (64, 32, 128, 128, 3, 2, ''),              # the strided 3x3 of a stage-opening block (direct kernel)
+    (64, 8, 2048, 256, 1, 1, 'res_up'),        # FPN lateral with the top-down add in its epilogue
+    (5, 32, 284, 256, 1, 1, ''),               # encoder projection: 284 input channels (not a multiple of 32), odd batch
+    (5, 16, 128, 64, 1, 1, 'pre'),             # encoder block conv1: pre-activation affine per group, Cout 64
+    (3, 2, 128, 256, 1, 1, 'res'),             # a 2 x 2 map: 12 pixels per group, one ragged tile each
+])
+def test_grouped_launch_is_bit_identical_to_one_launch_per_group(N, H, Cin, Cout, k, stride, opt):
+    """vpho_conv_desc.groups (round 6): the twin hand / object branches as ONE launch, blockIdx.y = group.  Whatever tile class the doubled
+    tile count selects, every output element's k order is unchanged: the grouped result equals the two single launches bit for bit."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(N * 11 + Cin + Cout)
+    G = 2
+    shared = opt == 'shared'
+    x = torch.randn((N if shared else G * N), H, H, Cin, generator=g).cuda()
+    K = k * k * Cin
+    kw, kw_g = {}, [{}, {}]
+    OH = (H + 2 * (k // 2) - k) // stride + 1
+    if opt == 'x2shared':
+        x2 = torch.randn(N, stride * OH, stride * OH, 256, generator=g).cuda()
+        K += 256
+        kw = dict(x2=x2, stride2=stride, x2_shared=True)
+        kw_g = [dict(x2=x2, stride2=stride)] * 2
+    w = (torch.randn(G, Cout, K, generator=g) * (1.0 / K) ** 0.5).cuda()
+    b = torch.randn(G, Cout, generator=g).cuda()
+    if opt == 'res':
+        r = torch.randn(G * N, OH, OH, Cout, generator=g).cuda()
+        kw = dict(res=r)
+        kw_g = [dict(res=r[:N]), dict(res=r[N:])]
+    if opt == 'res_up':
+        ru = torch.randn(G * N, H // 2, H // 2, Cout, generator=g).cuda()
+        kw = dict(res_up=ru)
+        kw_g = [dict(res_up=ru[:N].contiguous()), dict(res_up=ru[N:].contiguous())]
+    if opt == 'pre':
+        sc, sh = torch.rand(G, Cin, generator=g).cuda() + 0.5, torch.randn(G, Cin, generator=g).cuda()
+        kw = dict(in_scale=sc, in_shift=sh, in_slope=0.01)
+        kw_g = [dict(in_scale=sc[i].contiguous(), in_shift=sh[i].contiguous(), in_slope=0.01) for i in range(G)]
+    conv = dict(kh=k, kw=k, stride=(1 if opt == 'x2shared' else stride), pad=k // 2, out_slope=0.01)
+    if opt == 'x2shared':
+        x = torch.randn(G * N, OH, OH, Cin, generator=g).cuda()       # conv3's own input is already at the block's output resolution
+    got = ops.conv2d_nhwc(x, w, b, groups=G, x_shared=shared, **conv, **kw)
+    torch.cuda.synchronize()
+    assert got.shape[0] == G * N and torch.isfinite(got).all() and float(got.abs().max()) > 0
+    for i in range(G):
+        xi = x if shared else x[i * N:(i + 1) * N]
+        one = ops.conv2d_nhwc(xi, w[i].contiguous(), b[i].contiguous(), **conv, **kw_g[i])
+        assert torch.equal(got[i * N:(i + 1) * N], one), (i, float((got[i * N:(i + 1) * N] - one).abs().max()))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,shared', [(64, 32, 32, 128, 128, False), (64, 16, 16, 256, 256, False), (5, 8, 8, 256, 256, False), (3, 4, 6, 128, 128, False),
+                                                   (5, 2, 2, 128, 128, False), (4, 32, 32, 256, 256, True)])
+def test_grouped_winograd_is_bit_identical_to_one_launch_per_group(N, H, W, Cin, Cout, shared):
+    """the same for the Winograd kernel (vpho_conv3x3_winograd_grouped_nhwc_f32): tile blocks of a group never hold another group's tiles"""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(N + H + Cin)
+    G = 2
+    x = torch.randn((N if shared else G * N), H, W, Cin, generator=g).cuda()
+    w = (torch.randn(G, Cout, 9 * Cin, generator=g) * (1.0 / (9 * Cin)) ** 0.5).cuda()
+    b = torch.randn(G, Cout, generator=g).cuda()
+    got = ops.conv3x3(x, w, b, out_slope=0.01, groups=G, x_shared=shared)
+    torch.cuda.synchronize()
+    for i in range(G):
+        xi = x if shared else x[i * N:(i + 1) * N]
+        one = ops.conv3x3(xi, w[i].contiguous(), b[i].contiguous(), out_slope=0.01)
+        assert torch.equal(got[i * N:(i + 1) * N], one), (i, float((got[i * N:(i + 1) * N] - one).abs().max()))

@@ -212,3 +212,37 @@ def test_device_prior_switch_is_seeded_and_off_by_default(model_cpu, assets):
         assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all()) and not torch.equal(outs[0], ref)
     finally:
         cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = saved
+
+
+@pytest.mark.parametrize('bs,roi_window', [(5, '1'), (8, '0'), (64, '1')])
+def test_grouped_twin_branches_are_bit_identical_to_one_launch_per_branch(model_contrast_cpu, assets, bs, roi_window):
+    """round 6 (vpho_conv_desc.groups): hand | object layer2 / layer3, the FPN top layer and coarse laterals, the heat-map heads and both
+    encoders run as ONE grouped launch each (Engine._features_grouped).  Every output element keeps its k order, so the whole feature path
+    -- heat-maps, encodings, the cross modules' stage inputs, the regression head, the forces -- equals the per-branch plan bit for bit."""
+    import copy
+    import os
+    from vpho_amd.model.engine import Engine
+    from vpho_amd.synth import synth_batch
+    m = copy.deepcopy(model_contrast_cpu).cuda().eval()
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(bs, assets, seed=40 + bs).items()}
+    feats = {}
+    saved = {k: os.environ.get(k) for k in ('VPHO_GROUPED', 'VPHO_ROI_WINDOW', 'VPHO_GRAPHS')}
+    try:
+        os.environ['VPHO_ROI_WINDOW'], os.environ['VPHO_GRAPHS'] = roi_window, '0'
+        for mode in ('0', '1'):
+            os.environ['VPHO_GROUPED'] = mode
+            eng = Engine(m)
+            assert eng.grouped == (mode == '1')
+            f = eng.features(data)
+            torch.cuda.synchronize()
+            feats[mode] = {k: v.clone() for k, v in f.items() if torch.is_tensor(v)}
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for k in ('hand_heatmap', 'obj_heatmap', 'encoding_hand', 'encoding_obj', 'stage_hand', 'stage_obj', 'mano_pose', 'mano_shape', 'reg_hand_joint',
+              'tok_hand', 'tok_obj', 'force_local', 'hf_hr', 'hm_hand_nhwc', 'hm_obj_nhwc'):
+        a, b = feats['0'][k], feats['1'][k]
+        assert a.shape == b.shape and torch.equal(a, b), (k, float((a - b).abs().max()))
+    # the encoder inputs: 277 / 283 channels of data; the grouped plan pads both to 284 (the per-branch plan 280 / 284)
+    assert torch.equal(feats['0']['enc_in_hand'][..., :277], feats['1']['enc_in_hand'][..., :277]) and float(feats['1']['enc_in_hand'][..., 277:].abs().max()) == 0.0
+    assert torch.equal(feats['0']['enc_in_obj'], feats['1']['enc_in_obj'])

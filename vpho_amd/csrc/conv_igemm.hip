@@ -30,7 +30,8 @@ struct Geo {
     vpho_conv_desc d;
     int M, K, tiles_m, tiles_n, ntiles;
     int w_ld;                       // floats between consecutive weight rows (K unless the launch reduces a K-slice)
-    long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions; 0 for ordinary launches)
+    long long x_zs, w_zs, y_zs;     // per blockIdx.y advance of x / w / y (split reductions, groups; 0 for ordinary launches)
+    long long b_zs, r_zs, x2_zs, pre_zs, ru_zs;   // ... and of bias / res / x2 / in_scale + in_shift / res_up (groups only)
     int y_linear, r_linear, vec_epilogue;
     int uni;   // Cin % 32 == 0: wave-uniform taps (direct-to-LDS kernel)
     int dbg;   // A/B switches whose results are bit-identical (VPHO_CONV_DBG, read per call): 8 = residual tile requested in the epilogue
@@ -38,6 +39,16 @@ struct Geo {
                // The timing ablations that produce WRONG results (skip global loads / barriers / LDS stores) are compile-time only:
                // -DCONV_ABLATE=<mask> in a diagnostic build (scripts/kernel_ablate.sh), never in the product library
 };
+
+// blockIdx.y = slice of a split reduction or group of a grouped launch: the same problem on advanced operands
+__device__ __forceinline__ void advance_group(vpho_conv_desc& d, const Geo& g, const unsigned by) {
+    d.x += by * g.x_zs; d.w += by * g.w_zs; d.y += by * g.y_zs;
+    if (d.bias) d.bias += by * g.b_zs;
+    if (d.res) d.res += by * g.r_zs;
+    if (d.x2) d.x2 += by * g.x2_zs;
+    if (d.in_scale) { d.in_scale += by * g.pre_zs; d.in_shift += by * g.pre_zs; }
+    if (d.res_up) d.res_up += by * g.ru_zs;
+}
 
 // VEC = number of consecutive 16-byte pieces (of one tile row) a thread moves per pass: 2 halves the per-K-step address
 // arithmetic and bounds checks (needs Cin % 8 == 0 so that a 32-byte piece never straddles two filter taps)
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
 
     vpho_conv_desc d = g.d;
-    d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
+    advance_group(d, g, blockIdx.y);
     // XCD-aware renumbering: hardware block b runs on XCD (b % 8); give each XCD a contiguous run of logical tiles
     int per_xcd = gridDim.x >> 3, ntiles = g.ntiles, M_live = g.M;
     if (d.row_map) {
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
     VPHO_STAMP_INIT();
 
     vpho_conv_desc d = g.d;
-    d.x += blockIdx.y * g.x_zs; d.w += blockIdx.y * g.w_zs; d.y += blockIdx.y * g.y_zs;
+    advance_group(d, g, blockIdx.y);
     int per_xcd = gridDim.x >> 3, ntiles = g.ntiles, M_live = g.M;
     if (d.row_map) {
         // pixel-list launch: the live row count is device data.  The grid was sized for every pixel; the live tiles are spread
@@ -716,7 +727,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE + NW * EPI + 2 * BN];
     VPHO_STAMP_INIT();
 
-    const vpho_conv_desc& d = g.d;
+    vpho_conv_desc d = g.d;
+    advance_group(d, g, blockIdx.y);                  // grouped launches: every group is its own persistent walk over gridDim.x slots
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -1186,6 +1198,19 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     const int splits = d.splits > 1 ? d.splits : 1;
     g.w_ld = d.w_ld > 0 ? d.w_ld : g.K;
     g.x_zs = splits > 1 ? d.x_split : 0; g.w_zs = splits > 1 ? d.w_split : 0; g.y_zs = splits > 1 ? d.y_split : 0;
+    g.b_zs = g.r_zs = g.x2_zs = g.pre_zs = g.ru_zs = 0;
+    // grouped launch (ABI 11): blockIdx.y = group; the twin hand / object branches of the feature path (same shapes, different weights,
+    // backbone_FPN_HFL.py:79-109) as ONE launch -- twice the tiles, half the launches, every output's k order unchanged
+    const int groups = d.groups > 1 ? d.groups : 1;
+    if (groups > 1) {
+        VPHO_REQUIRE(splits == 1 && !d.row_map && !d.gate && !d.w_planes, "vpho_conv2d_nhwc_f32: grouped launches take no splits / pixel list / gate / bf16 planes");
+        VPHO_REQUIRE(d.x_group >= 0 && d.w_group > 0 && d.y_group > 0 && d.x_group % 4 == 0 && d.w_group % 4 == 0 && d.y_group % 4 == 0 && d.bias_group % 4 == 0 &&
+                     d.res_group % 4 == 0 && d.x2_group % 4 == 0 && d.pre_group % 4 == 0 && d.ru_group % 4 == 0,
+                     "vpho_conv2d_nhwc_f32: group strides must be non-negative multiples of 4 floats (x_group may be 0: a shared input)");
+        g.x_zs = d.x_group; g.w_zs = d.w_group; g.y_zs = d.y_group; g.b_zs = d.bias_group; g.r_zs = d.res_group; g.x2_zs = d.x2_group;
+        g.pre_zs = d.pre_group; g.ru_zs = d.ru_group;
+    }
+    const int ny = splits * groups;                               // grid.y (at most one of the two is > 1)
     VPHO_REQUIRE(g.w_ld >= g.K && g.w_ld % 4 == 0 && g.x_zs % 4 == 0 && g.w_zs % 4 == 0, "vpho_conv2d_nhwc_f32: w_ld / split strides must be multiples of 4, w_ld >= K");
     VPHO_REQUIRE(splits == 1 || (!d.res && !d.bias && !d.in_scale && !d.gate), "vpho_conv2d_nhwc_f32: split launches produce plain partial sums (no bias / residual / prologue / gate)");
     g.y_linear = (d.y_sy == d.y_sx * d.OW && d.y_sn == d.y_sy * d.OH) ? 1 : 0;
@@ -1223,15 +1248,15 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         VPHO_REQUIRE(4.0 * d.N * d.ru_H * d.ru_W * (double)d.ru_ld < 3.9e9, "vpho_conv2d_nhwc_f32: res_up map too large");
     }
     hipStream_t s = (hipStream_t)stream;
-    const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * splits;
+    const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * ny;
     const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes
-    const double flops = 2.0 * m_acc * d.Cout * g.K * splits;
+    const double flops = 2.0 * m_acc * d.Cout * g.K * ny;
     // algorithmic HBM bytes: input, packed weights and output once each (+ residual, + bias)
-    const double bytes = 4.0 * ((double)d.N * d.H * d.W * d.Cin + (d.x2 ? (double)d.N * d.OH * d.OW * d.Cin2 : 0.0) + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout + (d.res_up ? (double)d.N * d.ru_H * d.ru_W * d.Cout : 0.0));
+    const double bytes = groups * 4.0 * ((double)d.N * d.H * d.W * d.Cin + (d.x2 ? (double)d.N * d.OH * d.OW * d.Cin2 : 0.0) + (double)d.Cout * g.K + m_acc * d.Cout * (d.res ? 2 : 1) + d.Cout + (d.res_up ? (double)d.N * d.ru_H * d.ru_W * d.Cout : 0.0));
     static const int force_tile = getenv("VPHO_CONV_TILE") ? atoi(getenv("VPHO_CONV_TILE")) : 0;   // tuning aid
     // tile choice (measured on MI355X, scripts/conv_tune.py): 8-wave 128x128 when it still gives >= 2 tiles per CU,
     // 8-wave 128x64 when that gives >= 1 tile per CU, else the 4-wave 64x64 tile (small feature maps, narrow heads)
-    const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64) * splits;
+    const long long tiles_12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64) * ny;
     int variant = 64;
     if (big_tiles >= 256 && d.Cout % 128 == 0) variant = 1288;
     else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
@@ -1240,13 +1265,13 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         vpho::ProfScope prof(cls, s, flops, bytes);
         g.tiles_m = (int)((M + bm - 1) / bm); g.tiles_n = (d.Cout + bn - 1) / bn;
         g.ntiles = g.tiles_m * g.tiles_n;
-        hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8, splits), dim3(threads), 0, s, g);
+        hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8, ny), dim3(threads), 0, s, g);
     };
     static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
     // the direct-to-LDS kernels address x and w by 32-bit byte offsets: both extents (all splits included) must stay below 4 GB
     // (the largest activation of the reference's configurations is 0.27 GB)
-    const double x_extent = 4.0 * (((double)d.N * d.H * d.W - 1) * d.x_ld + d.Cin + (double)(splits - 1) * (double)g.x_zs);
-    const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(splits - 1) * (double)g.w_zs);
+    const double x_extent = 4.0 * (((double)d.N * d.H * d.W - 1) * d.x_ld + d.Cin + (double)(ny - 1) * (double)g.x_zs);
+    const double w_extent = 4.0 * (((double)d.Cout - 1) * g.w_ld + g.K + (double)(ny - 1) * (double)g.w_zs);
     VPHO_REQUIRE(x_extent < 3.9e9 && w_extent < 3.9e9 && g.x_zs >= 0 && g.w_zs >= 0,
                  "vpho_conv2d_nhwc_f32: input (%.2f GB) and weights (%.2f GB) must each stay below 3.9 GB", x_extent * 1e-9, w_extent * 1e-9);
     static const int no_uni = getenv("VPHO_CONV_NO_UNI") ? atoi(getenv("VPHO_CONV_NO_UNI")) : 0;          // tuning aid
@@ -1303,8 +1328,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
             vpho::ProfScope prof(vpho::PROF_CONV128, s, flops, bytes);
             g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (d.Cout + 127) / 128;
             g.ntiles = g.tiles_m * g.tiles_n;
-            const int grid = (int)std::min<long long>((g.ntiles + 7) / 8 * 8, slots / 8 * 8);
-            hipLaunchKernelGGL((conv_igemm_pers_kernel<128, 128, 4, 2>), dim3(grid), dim3(512), 0, s, g);
+            const int grid = (int)std::min<long long>((g.ntiles + 7) / 8 * 8, std::max(8, slots / groups / 8 * 8));      // the groups share the slots
+            hipLaunchKernelGGL((conv_igemm_pers_kernel<128, 128, 4, 2>), dim3(grid, groups), dim3(512), 0, s, g);
             return vpho::check_launch("conv_igemm_pers_kernel");
         }
     }

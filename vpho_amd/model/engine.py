@@ -82,6 +82,36 @@ class Engine:
 
         self.enc = dict(hand=encoder('encoder_hand', 277), obj=encoder('encoder_obj', 283))
 
+        # ---- the twin branches as GROUPS (vpho_conv_desc.groups): hand | object layer2 / layer3, FPN top layer and the laterals above the
+        # stride-4 level, heat-map heads up to the last 1x1 (21 / 27 output maps), both encoders (277 / 283 inputs, both padded to 284): same
+        # shapes, different weights (backbone_FPN_HFL.py:79-109, VPHO.py:131-149, encoding.py:58-73) -> stacked (2, Cout, K) and run as ONE
+        # launch each.  VPHO_GROUPED=0: one launch per branch (A/B aid; bit-identical, tests/test_gpu_predict.py)
+        self.grouped = os.environ.get('VPHO_GROUPED', '1') != '0'
+        if self.grouped:
+            pair = lambda a, b: (torch.stack([a[0], b[0]]).contiguous(), torch.stack([a[1], b[1]]).contiguous())
+
+            def pair_blocks(name_h, name_o):
+                out = []
+                for bh, bo in zip(self.layers[name_h], self.layers[name_o]):
+                    blk = dict(c1=pair(bh['c1'], bo['c1']), c2=pair(bh['c2'], bo['c2']), c3=pair(bh['c3'], bo['c3']), stride=bh['stride'], down=None)
+                    if bh['down'] is not None:
+                        blk['down'] = pair(bh['down'], bo['down'])
+                        blk['c3_down'] = pair(bh['c3_down'], bo['c3_down'])
+                    out.append(blk)
+                return out
+
+            self.g_layers = dict(layer2=pair_blocks('layer2_h', 'layer2_o'), layer3=pair_blocks('layer3_h', 'layer3_o'))
+            self.g_fpn = {k: pair(self.fpn[k + '_h'], self.fpn[k + '_o']) for k in ('toplayer', 'latlayer1', 'latlayer2')}
+            hh, ho = self.hm['hand'], self.hm['obj']
+            self.g_hm = dict(c0=pair(hh['c0'], ho['c0']), c1=pair(hh['c1'], ho['c1']), deconv_b=torch.stack([hh['deconv_b'], ho['deconv_b']]).contiguous(),
+                             deconv={k: (torch.stack([hh['deconv'][k][0], ho['deconv'][k][0]]).contiguous(), hh['deconv'][k][1], hh['deconv'][k][2]) for k in hh['deconv']})
+            e2 = dict(hand=encoder('encoder_hand', 283), obj=self.enc['obj'])          # the hand encoder's 277 inputs padded to 284 like the object's 283
+            assert e2['hand']['cin_pad'] == e2['obj']['cin_pad']
+            self.g_enc = dict(project=pair(e2['hand']['project'], e2['obj']['project']), cin_pad=e2['obj']['cin_pad'],
+                              blocks=[dict(pre=(torch.stack([a['pre'][0], b['pre'][0]]).contiguous(), torch.stack([a['pre'][1], b['pre'][1]]).contiguous()),
+                                           c1=pair(a['c1'], b['c1']), c2=pair(a['c2'], b['c2']), c3=pair(a['c3'], b['c3']))
+                                      for a, b in zip(e2['hand']['blocks'], e2['obj']['blocks'])])
+
         lin = lambda p: (d(sd[p + '.weight']), d(sd[p + '.bias']))
         self.head_mano = dict(l0=lin('head_mano.base_layer.0'), l2=lin('head_mano.base_layer.2'), pose=lin('head_mano.fc_pose'),
                               shape=lin('head_mano.fc_shape'))
@@ -264,10 +294,131 @@ class Engine:
         ff = ops.linear(ops.linear(x, *c['l1'], out_slope=0.0), *c['l2'])
         return ops.add_layernorm(x, ff, *c['n2'])                                       # (bs*65, 512)
 
+    # ---- the same blocks on the two branches at once: tensors hold the hand images [0, N) and the object images [N, 2N)
+    def _bottleneck_g(self, x, b, out=None, x_shared=False):
+        y = ops.conv2d_nhwc(x, *b['c1'], out_slope=0.01, groups=2, x_shared=x_shared)
+        if b['stride'] == 1:
+            y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd, groups=2)
+        else:
+            y = ops.conv2d_nhwc(y, *b['c2'], kh=3, kw=3, stride=b['stride'], pad=1, out_slope=0.01, groups=2)
+        if b['down'] is not None and self.down_fuse and x.shape[-1] % 32 == 0 and y.shape[-1] % 32 == 0:
+            return ops.conv2d_nhwc(y, *b['c3_down'], x2=x, stride2=b['stride'], out_slope=0.01, out=out, groups=2, x2_shared=x_shared)
+        r = x if b['down'] is None else ops.conv2d_nhwc(x, *b['down'], stride=b['stride'], groups=2, x_shared=x_shared)
+        return ops.conv2d_nhwc(y, *b['c3'], res=r, out_slope=0.01, out=out, groups=2)
+
+    def _layer_g(self, x, name, x_shared=False):
+        for i, b in enumerate(self.g_layers[name]):
+            x = self._bottleneck_g(x, b, x_shared=x_shared and i == 0)
+        return x
+
+    def _hm_head_g(self, x):
+        h = self.g_hm
+        y = ops.conv3x3(x, *h['c0'], winograd=self.winograd, groups=2)
+        y = ops.conv3x3(y, *h['c1'], winograd=self.winograd, groups=2)                     # BN folded; LeakyReLU(1.0) = identity (Q1)
+        N2, H, W, _ = y.shape
+        co = h['deconv_b'].shape[1]
+        up = torch.empty((N2, 2 * H, 2 * W, co), device=y.device)
+        for (py, px), (w, pady, padx) in h['deconv'].items():
+            ops.conv2d_nhwc(y, w, h['deconv_b'], kh=2, kw=2, pad_y=pady, pad_x=padx, out_hw=(H, W), out_slope=0.0, groups=2,
+                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co))
+        n = N2 // 2                                                                          # the last 1x1 has 21 / 27 output maps: one launch per branch
+        return ops.conv2d_nhwc(up[:n], *self.hm['hand']['final']), ops.conv2d_nhwc(up[n:], *self.hm['obj']['final'])
+
+    def _encoder_g(self, x):
+        e = self.g_enc
+        x = ops.conv2d_nhwc(x, *e['project'], groups=2)
+        stages = []
+        for i, b in enumerate(e['blocks']):
+            y = ops.conv2d_nhwc(x, *b['c1'], in_scale=b['pre'][0], in_shift=b['pre'][1], in_slope=0.01, out_slope=0.01, groups=2)
+            y = ops.conv3x3(y, *b['c2'], out_slope=0.01, winograd=self.winograd, groups=2)
+            x = ops.conv2d_nhwc(y, *b['c3'], res=x, groups=2)
+            if i % 2 == 1:
+                x = ops.maxpool_nhwc(x, 2, 2, 0)
+                stages.append(x)
+        N2 = x.shape[0]
+        return ops.nhwc_to_nchw(x).view(N2, -1), stages
+
     def features(self, data):
         """VPHO.py:112-172.  Returns a dict of device tensors (NHWC unless noted)."""
         with ops.conv_split(self.conv_terms):
-            return self._features(data)
+            return self._features_grouped(data) if (self.grouped and self.conv_terms == 0) else self._features(data)
+
+    def _features_grouped(self, data):
+        """_features with the twin branches as grouped launches (one stream; results bit-identical to _features)"""
+        rgb = data['rgb'].float().contiguous()
+        bs = rgb.shape[0]
+        f32 = lambda k: data[k].float().contiguous()
+        is_right = data['is_right'].bool()
+        left_u8 = (~is_right).to(torch.uint8).contiguous()
+        R = cfg.roi_size
+        bb_h, bb_o, bb_hr, bb_or = f32('bbox_hand'), f32('bbox_obj'), f32('bbox_hand_rect'), f32('bbox_obj_rect')
+        win_h = win_o = halo_h = halo_o = None
+        if self.roi_window:
+            fh, fw = rgb.shape[2] // 4, rgb.shape[3] // 4
+            win_h = ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25)
+            win_o = ops.roi_windows(bb_or, None, bs, fh, fw, 0.25)
+            halo_h, halo_o = ops.roi_windows(bb_h, bb_hr, bs, fh, fw, 0.25, dilate=1), ops.roi_windows(bb_or, None, bs, fh, fw, 0.25, dilate=1)
+        grav = f32('gravity').view(bs, 3)
+        # ---- trunk: shared stem / layer1, the two layer2 / layer3 stacks as groups, shared layer4 on the batch of 2N images (quirk Q6)
+        x = ops.nchw_to_nhwc(rgb, 4)
+        c1 = ops.maxpool_nhwc(ops.conv2d_nhwc(x, *self.stem, kh=7, kw=7, stride=2, pad=3, out_slope=0.01), 3, 2, 1)
+        c2 = self._layer(c1, 'layer1_h')
+        c3 = self._layer_g(c2, 'layer2', x_shared=True)                                       # (2N,32,32,512)
+        c4 = self._layer_g(c3, 'layer3')                                                       # (2N,16,16,1024)
+        c5 = self._layer(c4, 'layer4_h')                                                       # (2N,8,8,2048)
+        # ---- top-down path: top layer and the two coarse laterals as groups; the stride-4 level per branch (its windows differ)
+        p = ops.conv2d_nhwc(c5, *self.g_fpn['toplayer'], groups=2)
+        if self.fpn_fuse:
+            p = ops.conv2d_nhwc(c4, *self.g_fpn['latlayer1'], groups=2, res_up=p)
+            p = ops.conv2d_nhwc(c3, *self.g_fpn['latlayer2'], groups=2, res_up=p)
+        else:
+            for lat, c in (('latlayer1', c4), ('latlayer2', c3)):
+                q = ops.conv2d_nhwc(c, *self.g_fpn[lat], groups=2)
+                p = ops.resize_bilinear_nhwc(p, q.shape[1], q.shape[2], out=q, accumulate=True)
+        feats = {}
+        for br, pb, halo, win in (('h', p[:bs], halo_h, win_h), ('o', p[bs:], halo_o, win_o)):
+            if self.fpn_fuse:
+                q = ops.conv2d_nhwc(c2, *self.fpn[f'latlayer3_{br}'], rows=halo, rows_scatter=halo is not None, res_up=pb)
+            else:
+                q = ops.conv2d_nhwc(c2, *self.fpn[f'latlayer3_{br}'], rows=halo, rows_scatter=halo is not None)
+                q = ops.resize_bilinear_nhwc(pb, q.shape[1], q.shape[2], out=q, accumulate=True, rows=halo)
+            feats[br] = ops.conv3x3(q, *self.fpn[f'smooth3_{br}'], winograd=self.winograd, rows=win)
+        hand_feat, obj_feat = feats['h'], feats['o']
+        # ---- RoI crops of both branches in one buffer each: the heads' inputs (2N,32,32,256), the encoders' inputs (2N,32,32,284)
+        crop = torch.empty((2 * bs, R, R, 256), device=self.dev)
+        enc_in = torch.zeros((2 * bs, R, R, self.g_enc['cin_pad']), device=self.dev)
+        in_h, in_o = enc_in[:bs], enc_in[bs:]
+        hf_hr = ops.roi_align_nhwc(hand_feat, bb_h, R, 0.25, win=win_h, out=crop[:bs])
+        ops.roi_align_nhwc(hand_feat, bb_hr, R, 0.25, out=in_h, win=win_h)
+        if win_o is not None:                                                                # one pooling pass, two destinations (VPHO.py:126-138)
+            ops.roi_align_dual_nhwc(obj_feat, bb_or, R, 0.25, win_o, in_o, flip_w2=left_u8, out=crop[bs:])
+        else:
+            ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, out=crop[bs:])
+            ops.roi_align_nhwc(obj_feat, bb_or, R, 0.25, flip_w=left_u8, out=in_o)                # VPHO.py:138
+        hm_hand, hm_obj = self._hm_head_g(crop)                                              # (bs,64,64,21), (bs,64,64,27)
+        ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_hand, bb_h, bb_hr), R, R, out=in_h, c_off=256)
+        ops.resize_bilinear_nhwc(ops.align_heatmap_nhwc(hm_obj, bb_o, bb_or, flip_w=left_u8), R, R, out=in_o, c_off=256)
+        enc, st = self._encoder_g(enc_in)
+        enc_h, enc_o = enc[:bs], enc[bs:]
+        st_h, st_o = [t[:bs] for t in st], [t[bs:] for t in st]
+        hand_heatmap, obj_heatmap = ops.nhwc_to_nchw(hm_hand), ops.nhwc_to_nchw(hm_obj)
+        tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
+        hmn = self.head_mano
+        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01), *hmn['l2'], out_slope=0.01)
+        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose']), 16)                      # (bs,48)
+        shape = ops.linear(h, *hmn['shape'])                                                 # (bs,10)
+        ctx = self.mano.shape(shape)
+        ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
+        reg_vert, reg_joint = self.mano.fk(pose, ctx, 1, True, ho3d)
+        tok_h = self._cross(self.cross['hand'], st_h[1], st_o[1], grav, left_u8)
+        ph = self.phys
+        scale = ops.linear(ops.linear(tok_h, *ph['s0'], out_slope=0.01), *ph['s2'])          # (bs*65,1)
+        logits = ops.linear(ops.linear(tok_o, *ph['w0'], out_slope=0.01), *ph['w2'])         # (bs*65,8)
+        force_local = ops.force_local(scale, logits, ph['anchor'], bs * 32, 32, 65, 0, 32).view(bs, 32, 3)
+        return dict(hand_feat=hand_feat, obj_feat=obj_feat, roi_win_hand=win_h, roi_win_obj=win_o, hf_hr=hf_hr, enc_in_hand=in_h, enc_in_obj=in_o,
+                    hm_hand_nhwc=hm_hand, hm_obj_nhwc=hm_obj, hand_heatmap=hand_heatmap, obj_heatmap=obj_heatmap,
+                    encoding_hand=enc_h, encoding_obj=enc_o, stage_hand=st_h[1], stage_obj=st_o[1], mano_pose=pose, mano_shape=shape,
+                    mano_ctx=ctx, reg_hand_vert=reg_vert, reg_hand_joint=reg_joint, tok_hand=tok_h, tok_obj=tok_o, force_local=force_local)
 
     def _features(self, data):
         rgb = data['rgb'].float().contiguous()

@@ -17,7 +17,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
-ABI_VERSION = 10                        # include/vpho_hip.h; a stale library must not be found out by a missing symbol halfway through a run
+ABI_VERSION = 11                        # include/vpho_hip.h; a stale library must not be found out by a missing symbol halfway through a run
 if lib.vpho_abi_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} implements ABI version {lib.vpho_abi_version()}, this binding expects {ABI_VERSION}: rebuild the '
                       f'extension (python -m vpho_amd.build --force)')
@@ -67,7 +67,9 @@ class ConvDesc(C.Structure):
                 ('row_map', C.c_void_p), ('row_count', C.c_void_p), ('rows_hint', C.c_int), ('rows_scatter', C.c_int),
                 ('w_planes', C.c_void_p), ('plane_terms', C.c_int),
                 ('res_up', C.c_void_p), ('ru_H', C.c_int), ('ru_W', C.c_int), ('ru_ld', C.c_int),
-                ('x2', C.c_void_p), ('Cin2', C.c_int), ('x2_ld', C.c_int), ('stride2', C.c_int), ('H2', C.c_int), ('W2', C.c_int)]
+                ('x2', C.c_void_p), ('Cin2', C.c_int), ('x2_ld', C.c_int), ('stride2', C.c_int), ('H2', C.c_int), ('W2', C.c_int),
+                ('groups', C.c_int), ('x_group', C.c_longlong), ('w_group', C.c_longlong), ('bias_group', C.c_longlong), ('y_group', C.c_longlong),
+                ('res_group', C.c_longlong), ('x2_group', C.c_longlong), ('pre_group', C.c_longlong), ('ru_group', C.c_longlong)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -116,8 +118,11 @@ def _planes_of(w):
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
                 out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None,
-                rows=None, rows_scatter=False, res_up=None, x2=None, stride2=1):
+                rows=None, rows_scatter=False, res_up=None, x2=None, stride2=1, groups=1, x_shared=False, x2_shared=False):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
+    ``groups`` = G > 1: G convolutions of one shape in ONE launch (the twin hand / object branches, vpho_conv_desc.groups): w (G,Cout,K),
+    bias (G,Cout), in_scale / in_shift (G,Cin); x, res, x2, res_up and the result hold the groups' images one after the other
+    ((G*N,...): group g = images [g*N, (g+1)*N)); ``x_shared`` / ``x2_shared``: that input is ONE (N,...) tensor read by every group.
     ``res_up`` = a coarser (N,h,w,Cout) map added after bilinear up-sampling to the output grid (the FPN's top-down add fused into the
     lateral convolution, backbone_FPN_HFL.py:66-68; bit-identical to ``resize_bilinear_nhwc(..., accumulate=True)`` after the convolution).
     ``x2`` = a second (N,H2,W2,C2) input of a 1x1 convolution, read at stride ``stride2`` and concatenated behind x along the channels
@@ -130,9 +135,16 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     matrix whose first ``rows.count`` rows are live (``roi_align_nhwc(..., win=rows)`` reads it); with ``rows_scatter`` the listed
     pixels are written at their own positions of the ordinary (N,OH,OW,Cout) output and the other pixels are left untouched."""
     N, H, W, x_ld = x.shape
+    G = groups
+    if G > 1:
+        assert w.dim() == 3 and w.shape[0] == G and w.is_contiguous() and (bias is None or (bias.shape == (G, w.shape[1]) and bias.is_contiguous()))
+        assert rows is None and split is None and gate is None and x.is_contiguous()
+        if not x_shared:
+            assert N % G == 0, (N, G)
+            N //= G
     cin = x_ld if cin is None else cin
-    cout = w.shape[0]
-    assert split is not None or w.shape[1] == kh * kw * cin + (0 if x2 is None else x2.shape[-1]), (w.shape, kh, kw, cin)
+    cout = w.shape[-2]
+    assert split is not None or w.shape[-1] == kh * kw * cin + (0 if x2 is None else x2.shape[-1]), (w.shape, kh, kw, cin)
     py = pad if pad_y is None else pad_y
     px = pad if pad_x is None else pad_x
     if out_hw is None:
@@ -165,8 +177,9 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
             d.gate, d.gate_slope = _ptr(gate[0], torch.float32).value + 4 * off, gate[1]
     else:
         if out is None:
-            out = torch.empty((N, OH, OW, cout), device=x.device, dtype=torch.float32)
+            out = torch.empty((G * N, OH, OW, cout), device=x.device, dtype=torch.float32)
         _ptr(out, torch.float32)
+        assert out.shape[0] == G * N
         ld = out.shape[-1]
         d.y, d.y_sx, d.y_sy, d.y_sn = out.data_ptr(), ld, ld * OW, ld * OW * OH
         ret = out
@@ -174,50 +187,71 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
             assert gate[0].shape == out.shape
             d.gate, d.gate_slope = _ptr(gate[0], torch.float32).value, gate[1]
     if res is not None:
-        assert res.shape == (N, OH, OW, cout)
+        assert res.shape == (G * N, OH, OW, cout)
         d.r_sx, d.r_sy, d.r_sn = cout, cout * OW, cout * OW * OH
     if x2 is not None:
-        assert kh == kw == 1 and rows is None and split is None and in_scale is None and x2.shape[0] == N and x2.is_contiguous()
+        assert kh == kw == 1 and rows is None and split is None and in_scale is None and x2.shape[0] == (N if (G == 1 or x2_shared) else G * N) and x2.is_contiguous()
         d.x2, d.Cin2, d.x2_ld, d.stride2, d.H2, d.W2 = _ptr(x2, torch.float32).value, x2.shape[3], x2.shape[3], stride2, x2.shape[1], x2.shape[2]
     if res_up is not None:
-        assert res is None and res_up.shape[0] == N and res_up.shape[3] == cout and res_up.is_contiguous()
+        assert res is None and res_up.shape[0] == G * N and res_up.shape[3] == cout and res_up.is_contiguous()
         d.res_up, d.ru_H, d.ru_W, d.ru_ld = _ptr(res_up, torch.float32).value, res_up.shape[1], res_up.shape[2], res_up.shape[3]
+    if G > 1:
+        assert in_scale is None or (in_scale.shape == (G, cin) and in_shift.shape == (G, cin) and in_scale.is_contiguous() and in_shift.is_contiguous())
+        d.groups = G
+        d.x_group = 0 if x_shared else N * H * W * x_ld
+        # a strided destination (out_view: transposed-convolution phases) holds the groups' images one after the other as well
+        d.w_group, d.bias_group, d.y_group = w.shape[1] * w.shape[2], cout, (ret.numel() // G if out_view is not None else N * OH * OW * ret.shape[-1])
+        d.res_group = N * OH * OW * cout
+        d.x2_group = 0 if (x2 is None or x2_shared) else N * x2.shape[1] * x2.shape[2] * x2.shape[3]
+        d.pre_group = cin
+        d.ru_group = 0 if res_up is None else N * res_up.shape[1] * res_up.shape[2] * res_up.shape[3]
     d.N, d.H, d.W, d.Cin, d.x_ld = N, H, W, cin, x_ld
     d.Cout, d.KH, d.KW, d.stride, d.pad_y, d.pad_x, d.OH, d.OW = cout, kh, kw, stride, py, px, OH, OW
     d.in_slope, d.out_slope = in_slope, out_slope
     if split is not None:                                   # (splits, w_ld, x_split, w_split, y_split): see vpho_conv_desc
         d.splits, d.w_ld, d.x_split, d.w_split, d.y_split = split
     terms = getattr(_conv_split, 'terms', 0)
-    if terms and split is None and in_scale is None and gate is None and res_up is None and x2 is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
+    if terms and G == 1 and split is None and in_scale is None and gate is None and res_up is None and x2 is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
         planes = _planes_of(w)                              # kept alive by the cache
         d.w_planes, d.plane_terms = planes.data_ptr(), terms
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
     return ret
 
 
-def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None):
+def conv3x3(x, w, bias=None, out_slope=1.0, winograd=True, rows=None, groups=1, x_shared=False):
     """3x3 / stride 1 / pad 1 convolution + bias + LeakyReLU of the inference plan: the Winograd F(2x2,3x3) kernel where its shape
     conditions hold (even H and W, Cin % 16 == 0, Cout % 64 == 0), else the direct implicit GEMM.  The transformed weights live on the
     weight tensor object and follow its version.  ``rows`` = a ``RoiWindows``: only the window pixels, as the compact (N*H*W, Cout)
-    matrix (see conv2d_nhwc)."""
+    matrix (see conv2d_nhwc).  ``groups``: see conv2d_nhwc (w (G,Cout,9*Cin))."""
     N, H, W, x_ld = x.shape
-    cout, k9 = w.shape
+    cout, k9 = w.shape[-2:]
     cin = k9 // 9
     if not winograd or H % 2 or W % 2 or cin % 16 or cout % 64 or x_ld != cin:
-        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, rows=rows)
+        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, rows=rows, groups=groups, x_shared=x_shared)
     c = getattr(w, '_vpho_wino', None)
     if c is None or c[0] != w._version:
         from .model.pack import winograd_weights
-        c = (w._version, winograd_weights(w))
+        c = (w._version, winograd_weights(w) if groups == 1 else torch.stack([winograd_weights(w[g]) for g in range(groups)]).contiguous())
         w._vpho_wino = c
-    return conv3x3_winograd(x, c[1], bias, out_slope, rows=rows)
+    return conv3x3_winograd(x, c[1], bias, out_slope, rows=rows, groups=groups, x_shared=x_shared)
 
 
-def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None, rows=None):
-    """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (Cin/8, 16, Cout, 8)"""
+def conv3x3_winograd(x, u, bias=None, out_slope=1.0, out=None, rows=None, groups=1, x_shared=False):
+    """3x3 / stride 1 / pad 1 convolution in Winograd F(2x2,3x3) form; u = pack.winograd_weights(packed weights) (Cin/8, 16, Cout, 8);
+    groups = G > 1: u (G, Cin/8, 16, Cout, 8), bias (G, Cout), x (G*N,H,W,Cin) or one shared (N,H,W,Cin) -> (G*N,H,W,Cout)"""
     N, H, W, x_ld = x.shape
-    cout, cin = u.shape[2], u.shape[0] * 8
-    assert u.shape[1] == 16 and u.shape[3] == 8
+    cout, cin = u.shape[-2], u.shape[-4] * 8
+    assert u.shape[-3] == 16 and u.shape[-1] == 8
+    if groups > 1:
+        assert rows is None and u.dim() == 5 and u.shape[0] == groups and u.is_contiguous() and x.is_contiguous() and (bias is None or bias.shape == (groups, cout))
+        if not x_shared:
+            assert N % groups == 0
+            N //= groups
+        if out is None:
+            out = torch.empty((groups * N, H, W, cout), device=x.device, dtype=torch.float32)
+        _call('vpho_conv3x3_winograd_grouped_nhwc_f32', _f32(x), C.c_longlong(0 if x_shared else N * H * W * x_ld), _f32(u), _f32(bias), I(groups), I(N), I(H), I(W),
+              I(cin), I(x_ld), I(cout), F(out_slope), _f32(out), I(out.shape[-1]))
+        return out
     if rows is not None:
         assert rows.shape == (N, H, W)
         if out is None:
@@ -578,12 +612,14 @@ def roi_align_nhwc(feat, boxes, out_size, spatial_scale, flip_w=None, out=None, 
     return out
 
 
-def roi_align_dual_nhwc(feat, boxes, out_size, spatial_scale, win, out2, flip_w2=None, c_off2=0):
-    """one pooling pass over the compact window matrix, two destinations: returns the plain crop (new tensor) and writes the same values
-    into ``out2`` at channel offset ``c_off2`` under ``flip_w2`` (vpho_roi_align_window_dual_nhwc_f32)"""
+def roi_align_dual_nhwc(feat, boxes, out_size, spatial_scale, win, out2, flip_w2=None, c_off2=0, out=None):
+    """one pooling pass over the compact window matrix, two destinations: returns the plain crop (new tensor, or ``out``) and writes the
+    same values into ``out2`` at channel offset ``c_off2`` under ``flip_w2`` (vpho_roi_align_window_dual_nhwc_f32)"""
     N, H, W = win.shape
     Cc = feat.shape[-1]
-    out = _new((N, out_size, out_size, Cc), feat)
+    if out is None:
+        out = _new((N, out_size, out_size, Cc), feat)
+    assert out.shape == (N, out_size, out_size, Cc) and out.is_contiguous()
     _call('vpho_roi_align_window_dual_nhwc_f32', _f32(feat), _ptr(win.wins, torch.int32), I(N), I(H), I(W), I(Cc), _f32(boxes),
           F(spatial_scale), I(out_size), _u8(None), _f32(out), I(Cc), I(0), _u8(flip_w2), _f32(out2), I(out2.shape[-1]), I(c_off2),
           I(int(win.count.item()) if _prof_on else 0))
