@@ -429,3 +429,4 @@ def test_grouped_winograd_is_bit_identical_to_one_launch_per_group(N, H, W, Cin,
         xi = x if shared else x[i * N:(i + 1) * N]
         one = ops.conv3x3(xi, w[i].contiguous(), b[i].contiguous(), out_slope=0.01)
         assert torch.equal(got[i * N:(i + 1) * N], one), (i, float((got[i * N:(i + 1) * N] - one).abs().max()))
+

@@ -434,249 +434,6 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// PERSISTENT tile walk (round 6) for the staged full-map geometry of conv_winograd_kernel<1>: a workgroup keeps its output-channel
-// block (the XCD decides it, as above) and walks the tile blocks slot, slot + nslot, ... of its XCD.  In-kernel stamps of the one-tile
-// kernel (profiles/r05_inkernel_clock.txt, 256 -> 256): of a workgroup's 82 us, 2.9 are set-up + the wait for the first fills, 8.7 the
-// epilogue, 0.3 the hand-over of the CU -- 14 % with the matrix pipe idle, once per tile.  Here the LAST super-stage of a tile prepares
-// the FIRST stage of the next one instead of repeating its own prefetch (the one-tile kernel's branch-free loop fetches the last
-// super-stage twice): the even stage brings the next tile's pixels of super-stage 0 into IN, the odd stage transforms them into V of
-// buffer 0 and fills U of stage 0 -- buffer parity works out because a tile has an even number of stages.  The epilogue then runs with
-// everything the next main loop starts from already in LDS; its stores drain under the next tile's first stage.  Same operations in the
-// same order per output: bit-identical to the one-tile kernel (tests/test_gpu_conv.py).
-// The destination records of a tile's rows (s_row / s_pitch) are triple-buffered: tile i + 1's are written during tile i, while a slow
-// wave may still read tile i - 1's in its epilogue only until the first stage barrier of tile i.
-constexpr int WP_IN_PIXELS = 448;              // IN of the persistent kernel (the staged geometries in use need <= 400 pixels)
-inline bool wino_pers_ok(int TH, int TW, int W) {
-    if (!wino_staged_ok(TH, TW, W)) return false;
-    const int NR = W_TB / TW, rpp = NR < TH ? NR : TH, ipb = NR / rpp;
-    return ipb * (2 * rpp + 2) * (W + 2) <= WP_IN_PIXELS;
-}
-__global__ __launch_bounds__(256) void conv_winograd_pers_kernel(const WinoArgs a_) {
-    const WinoArgs a = wino_group(a_, blockIdx.y);
-    extern __shared__ __attribute__((aligned(1024))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
-    const int wt = wave & 1, wc = wave >> 1;
-    // tile schedule: hardware workgroup b runs on XCD b % 8; XCD x takes the channel block x % ncb and every G-th tile block (G = 8 / ncb),
-    // its nslot workgroups take the logical slots s, s + nslot, ...
-    const int ncb = a.Cout / W_CB, G = 8 / ncb;
-    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-    const int cb = xcd % ncb, c0 = cb * W_CB;
-    const int tbs = (a.T + W_TB - 1) / W_TB;
-    int slot = blockIdx.x >> 3;
-    auto tile_block = [&](int sl) { return sl * G + xcd / ncb; };
-    if (tile_block(slot) >= tbs) return;
-    __shared__ int s_row[3][W_TB], s_pitch[3][W_TB];
-    __shared__ float s_bias[W_CB];
-    if (tid >= 64 && tid < 64 + W_CB) s_bias[tid - 64] = (a.bias && c0 + tid - 64 < a.Cout) ? a.bias[c0 + tid - 64] : 0.f;
-    auto write_rows = [&](int t0, int par) {                      // the 64 destination records of tile block t0 (threads 0..63)
-        if (tid < W_TB) {
-            int n, ty, tx, row = 0, pitch = (a.W << 4);
-            if (wino_tile(a, t0 + tid, n, ty, tx)) { row = (n * a.H + 2 * ty) * a.W + 2 * tx; pitch = (a.W << 4) | 0xF; }
-            s_row[par][tid] = row; s_pitch[par][tid] = pitch;
-        }
-    };
-    const int tl = wave * 16 + (lane >> 2), cp = lane & 3;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0xFFFFFFF0u, 0x00020000);
-    // ---- block geometry (see conv_winograd_kernel<1>): NR whole tile rows of one image, or all rows of ipb images
-    float* INb = smem + 2 * W_STAGE;
-    const int NR = W_TB / a.TW, rpp = NR < a.TH ? NR : a.TH, ipb = NR / rpp;
-    const int RR = 2 * rpp + 2, RC = a.W + 2, P = ipb * RR * RC;
-    const int in_ni = (P + 15) >> 4;
-    // this wave's DMA instructions j = wave, wave + 4, ...: region pixel q -> (image k of the block, region row rr, region column rc)
-    int qg[8];                                                     // packed: image k of the block | region row << 4 | (column + 1) << 12; -1 = no pixel
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int q = 16 * (wave + 4 * j) + (lane >> 2);
-        const int k = q / (RR * RC), r2 = q - k * RR * RC, rr = r2 / RC;
-        qg[j] = q < P ? (k | (rr << 4) | ((r2 - rr * RC) << 12)) : -1;
-    }
-    auto block_offsets = [&](int t0, int (&doff)[8]) {
-        const int n0 = t0 / (a.TH * a.TW), ty0 = (t0 - n0 * a.TH * a.TW) / a.TW;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = n0 + (qg[j] & 15), iy = 2 * ty0 - 1 + ((qg[j] >> 4) & 255), ix = (qg[j] >> 12) - 1;
-            const bool in = qg[j] >= 0 && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            doff[j] = in ? (int)((((long long)(n * a.H + iy) * a.W + ix) * a.x_ld + 4 * (lane & 3)) * 4) : -1;
-        }
-    };
-    int rowb[4];                                                   // LDS float offset of this lane's patch rows: the same for every block
-    {
-        const int k = tl / (rpp * a.TW), rem = tl - k * rpp * a.TW, tyl = rem / a.TW, txl = rem - tyl * a.TW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rowb[i] = ((k * RR + 2 * tyl + i) * RC + 2 * txl) * 16 + 4 * cp;
-    }
-    auto fill_in = [&](const int (&doff)[8], int ss, int j0, int j1) {
-#pragma unroll
-        for (int j = j0; j < j1; ++j)
-            if (wave + 4 * j < in_ni)                               // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(INb + (wave + 4 * j) * 256), 16, doff[j], ss * 64, 0, 0);
-    };
-    f32x4 pc[16];
-    auto read_patch = [&](int i0, int i1) {
-#pragma unroll
-        for (int i = i0; i < i1; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pc[4 * i + j] = *reinterpret_cast<const f32x4*>(INb + rowb[i] + 16 * j);
-    };
-    f32x2 r[16];
-    auto row_transform = [&](int e) {
-        f32x2 patch[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) patch[p] = e ? f32x2{pc[p][2], pc[p][3]} : f32x2{pc[p][0], pc[p][1]};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            r[0 * 4 + c] = patch[0 * 4 + c] - patch[2 * 4 + c];
-            r[1 * 4 + c] = patch[1 * 4 + c] + patch[2 * 4 + c];
-            r[2 * 4 + c] = patch[2 * 4 + c] - patch[1 * 4 + c];
-            r[3 * 4 + c] = patch[1 * 4 + c] - patch[3 * 4 + c];
-        }
-    };
-    const int sw = (tl >> 3) & 1;
-    auto store_v_row = [&](int buf, int fy) {
-        float* V = smem + buf * W_STAGE;
-        const f32x2 v0 = r[fy * 4 + 0] - r[fy * 4 + 2];
-        const f32x2 v1 = r[fy * 4 + 1] + r[fy * 4 + 2];
-        const f32x2 v2 = r[fy * 4 + 2] - r[fy * 4 + 1];
-        const f32x2 v3 = r[fy * 4 + 1] - r[fy * 4 + 3];
-        const f32x2 vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-        for (int fx = 0; fx < 4; ++fx) {
-            const int f = fy * 4 + fx;
-            *reinterpret_cast<f32x2*>(V + (f * 64 + tl) * WK + (((cp >> 1) ^ sw) * 4) + (cp & 1) * 2) = vv[fx];
-        }
-    };
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, 0xFFFFFFF0u, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    const int ustage = 16 * a.Cout * WK * 4;
-    int uoff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int fr = (wave * 8 + j) * 32 + (lane >> 1);
-        const int f = fr >> 6, r_ = fr & 63;
-        const int ch = (lane & 1) ^ ((r_ >> 3) & 1);
-        const int co = c0 + r_;
-        uoff[j] = co < a.Cout ? (int)((((long long)f * a.Cout + co) * WK + ch * 4) * 4) : -1;
-    }
-    auto fill_u = [&](int buf, int kc, int j0, int j1) {
-        float* U = smem + buf * W_STAGE + 16 * 64 * WK + wave * 8 * 32 * WK;
-#pragma unroll
-        for (int j = j0; j < j1; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_ptr)(U + j * 32 * WK), 16, uoff[j], kc * ustage, 0, 0);
-    };
-
-    f32x16 acc[16];
-    const int nss = a.Cin / (2 * WK);
-    const int fsw = (li >> 3) & 1;
-    // one k stage (see conv_winograd_kernel's stage): kc computes from buffer e; it fills U of stage `kn` into the other buffer; the even
-    // stage requests the pixels `dsel` / super-stage `ssf` into IN, the odd stage reads the lane's patch from IN and transforms it
-    auto stage = [&](int e, int kn, const int (&dsel)[8], int ssf) {
-        const int buf = e;
-        const float* V = smem + buf * W_STAGE + (wt * 32 + li) * WK + ((lh ^ fsw) * 4);
-        const float* U = smem + buf * W_STAGE + 16 * 64 * WK + (wc * 32 + li) * WK + ((lh ^ fsw) * 4);
-        f32x4 av[2], bv[2];
-        av[0] = *reinterpret_cast<const f32x4*>(V);
-        bv[0] = *reinterpret_cast<const f32x4*>(U);
-#pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            if (f < 15) {
-                av[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(V + (f + 1) * 64 * WK);
-                bv[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(U + (f + 1) * 64 * WK);
-            }
-            if (f < 2) fill_u(buf ^ 1, kn, 4 * f, 4 * f + 4);
-            if (e == 0 && f >= 2 && f < 6) fill_in(dsel, ssf, 2 * (f - 2), 2 * (f - 2) + 2);
-            if (e == 1 && f >= 2 && f < 10 && !(f & 1)) read_patch((f - 2) >> 1, ((f - 2) >> 1) + 1);
-            if (f == 11) row_transform(e == 0 ? 1 : 0);
-            if (f >= 12) store_v_row(buf ^ 1, f - 12);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f & 1][q], bv[f & 1][q], acc[f], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        VPHO_SYNC_LDS_DMA();
-    };
-
-    // ---- first tile: the one-tile kernel's prologue
-    int doff[8];
-    int t0 = tile_block(slot) * W_TB, par = 0;
-    write_rows(t0, 0);
-    block_offsets(t0, doff);
-    fill_in(doff, 0, 0, 8);
-    fill_u(0, 0, 0, 8);
-    VPHO_SYNC_LDS_DMA();
-    read_patch(0, 4);
-    row_transform(0);
-#pragma unroll
-    for (int fy = 0; fy < 4; ++fy) store_v_row(0, fy);
-    VPHO_SYNC_LDS_DMA();
-    const int co = c0 + wc * 32 + li;
-    for (;;) {
-        const int nslot_next = slot + nslot;
-        const bool has_next = tile_block(nslot_next) < tbs;       // workgroup-uniform
-        const int t1 = tile_block(nslot_next) * W_TB;
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
-        for (int ss = 0; ss < nss; ++ss) {
-            const bool last = ss + 1 == nss;
-            // behind its last pixel request (issued in the even stage of the super-stage before the last) a tile needs its offsets no more:
-            // they become the NEXT tile's; its destination records go to buffer (par + 1) % 3 -- whose last readers, the epilogue two
-            // tiles ago, are behind at least one stage barrier of the previous tile
-            if (last && has_next) { block_offsets(t1, doff); write_rows(t1, par == 2 ? 0 : par + 1); }
-            // even stage: pixels of the super-stage after this one -- of the next tile's first one behind the last; odd stage: U of the
-            // stage after it -- stage 0 of the next tile behind the last (no next tile: the one-tile kernel's harmless repeat)
-            stage(0, 2 * ss + 1, doff, last ? (has_next ? 0 : ss) : ss + 1);
-            stage(1, last ? (has_next ? 0 : 2 * ss + 1) : 2 * ss + 2, doff, 0);
-        }
-        // ---- output transform on the accumulators (conv_winograd_kernel's epilogue)
-        {
-            const float bias = s_bias[wc * 32 + li];
-            int pm_e[16], row_e[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                pm_e[e] = s_pitch[par][trow]; row_e[e] = s_row[par][trow];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float s0[4], s1[4];
-#pragma unroll
-                for (int fx = 0; fx < 4; ++fx) {
-                    s0[fx] = acc[0 * 4 + fx][e] + acc[1 * 4 + fx][e] + acc[2 * 4 + fx][e];
-                    s1[fx] = acc[1 * 4 + fx][e] - acc[2 * 4 + fx][e] - acc[3 * 4 + fx][e];
-                }
-                const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-                const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-                const int pm = pm_e[e];
-                if ((pm & 0xF) && co < a.Cout) {
-                    const int pitch = pm >> 4;
-                    float* yp = a.y + (long long)row_e[e] * a.y_ld + co;
-                    const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
-                    const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
-                    const float* gp = a.gate ? a.gate + (long long)row_e[e] * a.y_ld + co : nullptr;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
-                        float v = o[p];
-                        if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
-                        yp[offs[p]] = v > 0.f ? v : v * a.out_slope;
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-        slot = nslot_next; t0 = t1; par = par == 2 ? 0 : par + 1;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
 // Round 4 experiment, used for the short-K layers only (see wino_launch): the same arithmetic with TWO waves per SIMD.  conv_winograd_kernel keeps all 16 frequencies of a 32 x 32 (tile, channel) block
 // in one wave: 256 accumulator registers, ONE wave per SIMD -- whatever that wave does besides matrix instructions (patch loads, the
 // input transform, V stores, waits) is time the matrix pipe idles (PMC: 0.61 busy; the floor of a pure MFMA loop is 0.79 of the kernel's
@@ -1051,28 +808,10 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
         // bit-identity test; read per call)
         const char* st = getenv("VPHO_WINO_STAGED");
         const bool staged = st ? atoi(st) != 0 : true;
-        // persistent tile walk (round 6): full maps in the staged geometry with more tile blocks than CUs.  VPHO_WINO_PERS: 0 = never
-        // (the one-tile kernel: A/B aid, same bits), 1 = default, 2 = also launches of at most one round
-        const char* pe = getenv("VPHO_WINO_PERS");
-        const int pers = pe ? atoi(pe) : 1;
-        if (pers && staged && !wins && ncb <= 8 && (8 % ncb) == 0 && wino_pers_ok(a.TH, a.TW, W)) {
-            static int cus_of[64] = {0};
-            int dev = 0;
-            VPHO_HIP(hipGetDevice(&dev));
-            int& cus = cus_of[dev & 63];
-            if (!cus) {
-                hipDeviceProp_t prop;
-                VPHO_HIP(hipGetDeviceProperties(&prop, dev));
-                cus = prop.multiProcessorCount;
-            }
-            const unsigned slots = (unsigned)std::max(8, cus / std::max(groups, 1) / 8 * 8);       // one 158-KB workgroup per CU; groups share the CUs
-            if (blocks > slots || pers >= 2) {
-                const size_t lds_pers = lds + (size_t)WP_IN_PIXELS * 64;
-                VPHO_DYN_LDS(conv_winograd_pers_kernel, lds_pers);
-                hipLaunchKernelGGL(conv_winograd_pers_kernel, dim3(std::min(blocks, slots), groups), dim3(256), lds_pers, (hipStream_t)stream, a);
-                return vpho::check_launch("conv_winograd_pers_kernel");
-            }
-        }
+        // (Round 6, built and NOT kept: a persistent tile walk like conv_igemm_pers_kernel's -- the last super-stage of a tile prepares pixels, V and U of
+        // the next tile's first stage, the epilogue runs with them in LDS -- bit-identical, and 1-6 % SLOWER on seven of nine layers (64 x 64 x 64 images
+        // 256 -> 256: 1 233 against 1 220 us; 64 x 32 x 32 128 -> 128: 95.8 against 90.0), +1 % on two; docs/LOG.md round 6.  The one-tile kernel's
+        // hand-over costs less than the walk's per-tile bookkeeping and its stage-end wait on the previous tile's stores.)
         if (staged && wins)
             hipLaunchKernelGGL(conv_winograd_kernel<2>, dim3(blocks, groups), dim3(256), lds_staged, (hipStream_t)stream, a);
         else if (staged && wino_staged_ok(a.TH, a.TW, W))
