@@ -4,7 +4,8 @@ import json, shutil, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 tag = sys.argv[2] if len(sys.argv) > 2 else rnd + 'b'
 g = 'gpurun_out/'
-seq, pipe = json.load(open(g + tag + '_seq.json')), json.load(open(g + tag + '_pipe.json'))
+# the bench prints a compact line (<= 6 KB) since round 6; the numbers quoted in the headers come from the full record of the same run
+seq, pipe = json.load(open(g + tag + '_seq_detail.json')), json.load(open(g + tag + '_pipe_detail.json'))
 A, As, B = open(g + tag + '_seq_all.txt').read(), open(g + tag + '_seq_ss.txt').read(), open(g + tag + '_pipe_ss.txt').read()
 r = seq['roofline']
 txt = f"""# (A) rocprofv3 --kernel-trace --stats -- python3 bench.py --no_cpu_baseline --no_opt_in --pipeline 1 --steps 10   (MI355X, {rnd}, default plan: Winograd F(2x2,3x3) for the 3x3 / stride-1 convolutions incl. the RoI-windowed FPN ones, score-head tail tiles; sequential steps: 3 warm-up + 10 timed + the instrumented repeats that feed the roofline / hbm blocks; README config bs=64, sample_num=100, sampling_steps=50, T0=0.65; weights = vpho_amd.synth.bench_state_dict: nfev 51/51)
@@ -26,8 +27,9 @@ import os
 if os.path.exists(g + tag + '_exposed.txt'):
     open(f'profiles/{rnd}_exposed_time.txt', 'w').write(f"# time of the pipelined steps (trace B of the kernel-stats file, same window) in which no convolution / score-head kernel executes, by the kernels that run there ({rnd}; scripts/rocpd_exposed.py)\n" + open(g + tag + '_exposed.txt').read())
 shutil.copy(g + tag + '_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic.json')
-shutil.copy(g + tag + '_bench_default.json', f'profiles/{rnd}_bench_default.json')
-d = json.load(open(g + tag + '_bench_default.json'))
+shutil.copy(g + tag + '_bench_default.json', f'profiles/{rnd}_bench_default.json')              # the line as the driver parses it
+shutil.copy(g + tag + '_bench_default_detail.json', f'profiles/{rnd}_bench_detail.json')          # the full record of the same run
+d = json.load(open(g + tag + '_bench_default_detail.json'))
 print('default bench:', d['value'], d['ms_per_step'], 'roofline frac', d['roofline']['frac'], 'traffic', d['roofline']['traffic'])
 print('head:', d['roofline']['score_head'])
 print('hbm:', {k: (round(v['GB/s']), round(v['frac'], 3), round(v['avg_launch_us'], 1)) for k, v in d['hbm']['kernels'].items()})
@@ -46,7 +48,12 @@ def _copy(src, dst, header=None):
 if _copy(tag + '_bench_cfg4.json', f'{rnd}_bench_cfg4.json'):
     _copy(tag + '_cfg4_stats.txt', f'{rnd}_kernel_stats_bench_cfg4.txt',
           f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --bs 128 --sample_num 256 --sampling_steps 100 --steps 4 --warmup 2 --no_cpu_baseline --no_opt_in --no_kernel_timing --pipeline 1   (MI355X, {rnd}; BASELINE configs[3]; bench line: profiles/{rnd}_bench_cfg4.json)')
-    c4 = json.load(open(g + tag + '_bench_cfg4.json'))
+    _copy(tag + '_bench_cfg4_detail.json', f'{rnd}_bench_cfg4_detail.json')
+    if os.path.exists(g + tag + '_cfg4_pmc_hbm.json'):
+        shutil.copy(g + tag + '_cfg4_pmc_hbm.json', f'profiles/{rnd}_pmc_hbm_traffic_cfg4.json')
+        _copy(tag + '_cfg4_pmc_hbm.txt', f'{rnd}_pmc_hbm_traffic_cfg4.txt', f'# HBM traffic per launch at BASELINE configs[3] (two rocprofv3 --pmc passes: FETCH_SIZE; WRITE_SIZE) of  VPHO_GRAPHS=0 python3 bench.py --bs 128 --sample_num 256 --sampling_steps 100 --steps 1 --warmup 1 --no_cpu_baseline --no_opt_in --no_kernel_timing --pipeline 1  ({rnd})')
+    _copy(tag + '_cfg4_ab.txt', f'{rnd}_cfg4_switch_ab.txt', f'# interleaved A/B on ONE box at BASELINE configs[3] (bs 128, 256 hypotheses, 100 stamps; 6 steps, pipelined): a = switch off, b = on (the default); scripts/ab.sh ({rnd})')
+    c4 = json.load(open(g + tag + '_bench_cfg4_detail.json'))
     print('cfg4:', c4['metric'], round(c4['value'], 1), round(c4['ms_per_step'], 2), 'head', c4['roofline']['score_head']['samplers_serialised'], 'pose encoder', c4['roofline'].get('pose_encoder'))
 for bs_tag in ('', '_bs32'):
     if _copy(tag + f'_train_step{bs_tag}.json', f'{rnd}_train_step{bs_tag}.json'):

@@ -18,8 +18,8 @@ B="python3 $R/bench.py --no_cpu_baseline --no_opt_in"
 cd $R
 if has cfg2; then
   scrub ${T}_seq ${T}_pipe ${T}_pmc_f ${T}_pmc_w ${T}_pmc_m
-  prof ${T}_seq --kernel-trace --stats -d $O/${T}_seq -o s -- $B --pipeline 1 --steps 10 && grep '^{' $O/${T}_seq.log > $O/${T}_seq.json &&
-  prof ${T}_pipe --kernel-trace --stats -d $O/${T}_pipe -o p -- $B --no_kernel_timing --steps 10 && grep '^{' $O/${T}_pipe.log > $O/${T}_pipe.json &&
+  prof ${T}_seq --kernel-trace --stats -d $O/${T}_seq -o s -- $B --pipeline 1 --steps 10 && grep '^{' $O/${T}_seq.log > $O/${T}_seq.json && cp $O/bench_detail.json $O/${T}_seq_detail.json &&
+  prof ${T}_pipe --kernel-trace --stats -d $O/${T}_pipe -o p -- $B --no_kernel_timing --steps 10 && grep '^{' $O/${T}_pipe.log > $O/${T}_pipe.json && cp $O/bench_detail.json $O/${T}_pipe_detail.json &&
   VPHO_GRAPHS=0 prof ${T}_pmc_f --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_f -o f -- $B --steps 2 --warmup 1 --no_kernel_timing --pipeline 1 &&
   VPHO_GRAPHS=0 prof ${T}_pmc_w --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_w -o w -- $B --steps 2 --warmup 1 --no_kernel_timing --pipeline 1 &&
   VPHO_GRAPHS=0 prof ${T}_pmc_m --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/${T}_pmc_m -o m -- $B --steps 2 --warmup 1 --no_kernel_timing --pipeline 1 &&
@@ -27,7 +27,7 @@ if has cfg2; then
   python3 scripts/rocpd_stats.py $(db ${T}_pipe) 30 --pipelined > $O/${T}_pipe_ss.txt && python3 scripts/rocpd_exposed.py $(db ${T}_pipe) --pipelined > $O/${T}_exposed.txt &&
   python3 scripts/pmc_summary.py $(csv ${T}_pmc_f counter_collection) $(csv ${T}_pmc_w counter_collection) $O/${T}_pmc_hbm.json > $O/${T}_pmc_hbm.txt &&
   python3 scripts/pmc_mfma_summary.py $(csv ${T}_pmc_m counter_collection) $(csv ${T}_pmc_m kernel_trace) > $O/${T}_pmc_mfma.txt &&
-  gstep 400 $O/${T}_bench_default.log python3 bench.py && grep '^{' $O/${T}_bench_default.log > $O/${T}_bench_default.json
+  gstep 400 $O/${T}_bench_default.log python3 bench.py && grep '^{' $O/${T}_bench_default.log > $O/${T}_bench_default.json && cp $O/bench_detail.json $O/${T}_bench_default_detail.json
   scrub ${T}_seq ${T}_pipe ${T}_pmc_f ${T}_pmc_w ${T}_pmc_m; head -12 $O/${T}_seq_ss.txt | cut -c1-160
 fi
 if has exposed; then
@@ -37,11 +37,18 @@ if has exposed; then
   scrub ${T}_pipe; head -12 $O/${T}_exposed.txt
 fi
 if has cfg4; then
+  # the stress config: bench line, kernel stats, ITS OWN counter passes (a line must never quote another workload's traffic), and interleaved
+  # A/Bs of the three switches that could explain a drift between rounds (all bit-identical alternatives)
   C4="--bs 128 --sample_num 256 --sampling_steps 100 --warmup 2"
-  gstep 500 $O/${T}_bench_cfg4.log $B $C4 --steps 6 && grep '^{' $O/${T}_bench_cfg4.log > $O/${T}_bench_cfg4.json &&
+  scrub ${T}_cfg4_prof ${T}_cfg4_pmc_f ${T}_cfg4_pmc_w
+  gstep 500 $O/${T}_bench_cfg4.log $B $C4 --steps 6 && grep '^{' $O/${T}_bench_cfg4.log > $O/${T}_bench_cfg4.json && cp $O/bench_detail.json $O/${T}_bench_cfg4_detail.json &&
   prof ${T}_cfg4_prof --kernel-trace --stats -d $O/${T}_cfg4_prof -o c -- $B $C4 --steps 4 --no_kernel_timing --pipeline 1 &&
-  python3 scripts/rocpd_stats.py $(db ${T}_cfg4_prof) 30 > $O/${T}_cfg4_stats.txt
-  scrub ${T}_cfg4_prof; head -8 $O/${T}_cfg4_stats.txt | cut -c1-150
+  python3 scripts/rocpd_stats.py $(db ${T}_cfg4_prof) 30 > $O/${T}_cfg4_stats.txt &&
+  VPHO_GRAPHS=0 prof ${T}_cfg4_pmc_f --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_cfg4_pmc_f -o f -- $B $C4 --steps 1 --warmup 1 --no_kernel_timing --pipeline 1 &&
+  VPHO_GRAPHS=0 prof ${T}_cfg4_pmc_w --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_cfg4_pmc_w -o w -- $B $C4 --steps 1 --warmup 1 --no_kernel_timing --pipeline 1 &&
+  python3 scripts/pmc_summary.py $(csv ${T}_cfg4_pmc_f counter_collection) $(csv ${T}_cfg4_pmc_w counter_collection) $O/${T}_cfg4_pmc_hbm.json > $O/${T}_cfg4_pmc_hbm.txt
+  { for sw in VPHO_HEAD_CB VPHO_CONV_PERS VPHO_WINO_STAGED; do bash scripts/ab.sh cfg4_$sw "$sw=0" "$sw=1" 2 -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing $C4 --steps 6 2>&1 | grep run; done; } > $O/${T}_cfg4_ab.txt 2>&1
+  scrub ${T}_cfg4_prof ${T}_cfg4_pmc_f ${T}_cfg4_pmc_w; head -8 $O/${T}_cfg4_stats.txt | cut -c1-150; cat $O/${T}_cfg4_ab.txt
 fi
 if has train; then
   gstep 300 $O/${T}_train_step.log python3 train.py --steps 10 --warmup 3 && grep '^{' $O/${T}_train_step.log > $O/${T}_train_step.json &&
