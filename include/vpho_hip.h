@@ -258,6 +258,11 @@ VPHO_API int vpho_roi_align_window_dual_nhwc_f32(const float* feat_rows, const i
 VPHO_API int vpho_align_heatmap_nhwc_f32(const float* hm, int N, int size, int C, const float* bbox, const float* bbox_rect,
                                 const unsigned char* flip_w, float* out, void* stream);
 /* NeRF embedding of gravity (cross_module.py:8-46), x negated where flip_x (VPHO.py:167); out (N,64), column 63 = 0 */
+/* y = act(x . w^T + bias) of a SMALL linear layer with the products and the sum in double, rounded to fp32 once (ABI version 11): the
+ * regression head head_mano.py:61-70, whose output is normalised into half of the cascade's candidates (aggregation.py:120-126) -- see
+ * csrc/misc.hip.  x (rows, ld_x >= cin), w (cout, cin) packed, y (rows, ld_y >= cout); cin <= 4096. */
+VPHO_API int vpho_linear_acc64_f32(const float* x, int rows, int cin, int ld_x, const float* w, const float* bias, int cout, float out_slope,
+                          float* y, int ld_y, void* stream);
 VPHO_API int vpho_nerf_embed_f32(const float* g, int N, const unsigned char* flip_x, float* out, void* stream);
 /* (bs,65,512) token tensor of CrossModule.forward (cross_module.py:124-133) incl. the positional code of the BATCH index */
 VPHO_API int vpho_cross_tokens_f32(const float* proj_hand, const float* proj_obj, const float* grav_emb, const float* pe,

@@ -76,7 +76,7 @@ def predict_fp64(sd, assets, anchor_skeleton, data, *, sample_num, sample_T0, sa
 def _cat_dbg(dbgs):
     """concatenate the per-chunk ``dbg`` dicts of oracle.aggregation.hoi_aggregate along the image axis (the keys the comparisons read)"""
     cat = lambda xs: torch.cat(xs, 0)
-    h = {k: [cat([d['hand'][k][l] for d in dbgs]) for l in range(4)] for k in ('topk', 'score')}
+    h = {k: [cat([d['hand'][k][l] for d in dbgs]) for l in range(4)] for k in ('topk', 'score', 'val')}
     hp = {k: cat([d['hand_phys'][k] for d in dbgs]) for k in ('topk', 'score', 'cand')}
     out = dict(hand=h, hand_phys=hp)
     if 'state' in dbgs[0]['hand']:
@@ -190,6 +190,28 @@ def fused_rotation_errors(states_side, states64, rep, S):
     return out
 
 
+def topk_value_errors(vals_side, vals64, rep):
+    """the scores of the k picks of every cascade level (they become the fusion weights, aggregation.py:219-221,249) against the float64
+    scores of the same picks, on the images whose lists up to that level are the float64 lists: relative to the largest score of the
+    vector -> {level: (images, rms, max)}.  vals_side: [(bs, F, k)] x 4 (HIP layout) ; vals64: [(bs, k) | (bs, k, F)] (oracle layout)"""
+    out = {}
+    bs = vals64[0].shape[0]
+    ok = torch.ones(bs, dtype=torch.bool)
+    for lvl in range(4):
+        ok &= rep['_n_diff'][f'hand_level{lvl}'] == 0
+        b = vals64[lvl].double()
+        b = b[:, :, None] if b.dim() == 2 else b                                  # (bs, k, F)
+        a = torch.as_tensor(vals_side[lvl]).detach().cpu().double()
+        a = a.permute(0, 2, 1) if a.shape != b.shape else a
+        if a.shape != b.shape or not bool(ok.any()):
+            out[f'level{lvl}'] = None
+            continue
+        # lists are equal as sets (levels 0-2) -- sort both by the float64 value so that picks pair up
+        e = ((torch.sort(a, dim=1).values - torch.sort(b, dim=1).values).abs() / b.abs().amax(1, keepdim=True).clamp(min=1e-300))[ok]
+        out[f'level{lvl}'] = dict(images=int(ok.sum()), rms=float(e.pow(2).mean().sqrt()), max=float(e.max()))
+    return out
+
+
 def judge(out_hip, agg_hip, out_or, dbg_or, out64_hip, dbg64_hip, out64_or, dbg64_or, S, bar=1e-3):
     """The table of one batch.  out_* / *_dbg: outputs and selections of the HIP path (agg_hip = Engine.last_info['agg']), of the fp32
     oracle, and of the float64 predicts on either side's step sequences."""
@@ -223,7 +245,19 @@ def judge(out_hip, agg_hip, out_or, dbg_or, out64_hip, dbg64_hip, out64_or, dbg6
     if 'cascade_state' in agg_hip and 'state' in dbg_or['hand'] and 'state' in dbg64_hip['hand']:
         fused = dict(hip=fused_rotation_errors(agg_hip['cascade_state'], dbg64_hip['hand']['state'], r_hip, S),
                      oracle=fused_rotation_errors(dbg_or['hand']['state'], dbg64_or['hand']['state'], r_or, S))
-    return dict(images=bs, bar=bar, fused_rotation_abs_err_vs_fp64=fused,
+    cands = None
+    if fused is not None:
+        def cand_err(st, st64):
+            a, b = torch.as_tensor(st[0]).detach().cpu().double(), st64[0].double()          # (bs, 2S, 48): [S diffusion | S regression copies]
+            e = (a - b).abs()
+            return {'diffusion_hypotheses': {'rms': float(e[:, :S].pow(2).mean().sqrt()), 'max': float(e[:, :S].max())},
+                    'regression_copies_joints_1_15': {'rms': float(e[:, S:, 3:].pow(2).mean().sqrt()), 'max': float(e[:, S:, 3:].max())}}
+        cands = dict(hip=cand_err(agg_hip['cascade_state'], dbg64_hip['hand']['state']), oracle=cand_err(dbg_or['hand']['state'], dbg64_or['hand']['state']))
+    vals = None
+    if 'hand_val' in agg_hip and 'val' in dbg64_hip['hand']:
+        vals = dict(hip=topk_value_errors(agg_hip['hand_val'], dbg64_hip['hand']['val'], r_hip),
+                    oracle=topk_value_errors([v if v.dim() == 3 else v[:, :, None] for v in dbg_or['hand']['val']], dbg64_or['hand']['val'], r_or))
+    return dict(images=bs, bar=bar, fused_rotation_abs_err_vs_fp64=fused, topk_value_rel_err_vs_fp64=vals, candidate_pose_abs_err_vs_fp64=cands,
                 images_within_1e3_of_fp64={'hip': int((w_hip <= bar).sum()), 'oracle': int((w_or <= bar).sum())},
                 images_lists_identical_to_fp64={'hip': clean(r_hip), 'oracle': clean(r_or)},
                 first_differing_stage_vs_fp64={'hip': hist(f_hip), 'oracle': hist(f_or)},

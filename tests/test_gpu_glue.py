@@ -212,3 +212,22 @@ def test_features_with_and_without_roi_windows_are_identical(model_cpu, assets):
     for k in ('hf_hr', 'enc_in_hand', 'enc_in_obj', 'hm_hand_nhwc', 'hm_obj_nhwc', 'encoding_hand', 'encoding_obj', 'mano_pose', 'mano_shape',
               'reg_hand_vert', 'tok_hand', 'tok_obj', 'force_local'):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('rows,cin,cout,slope', [(64, 1024, 1024, 0.01), (5, 1024, 512, 0.01), (64, 512, 96, 1.0), (3, 512, 10, 1.0), (130, 100, 7, 0.0)])
+def test_linear_with_fp64_accumulation_is_the_correctly_rounded_product(rows, cin, cout, slope):
+    """vpho_linear_acc64_f32 (round 6, the regression head): products and sum in double, one rounding -- equal to torch's float64 result
+    rounded to fp32 up to one ulp of the output, batch-invariant, and closer to float64 than the fp32-MFMA GEMM of the same layer."""
+    from vpho_amd import ops
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, generator=g) * (1.0 / cin) ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y = ops.linear(x, w, b, out_slope=slope, acc64=True)
+    ref = torch.nn.functional.leaky_relu(x.double() @ w.double().t() + b.double(), slope)
+    err = (y.double() - ref).abs().max().item()
+    assert err <= 1.2e-7 * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(y[:1], ops.linear(x[:1].contiguous(), w, b, out_slope=slope, acc64=True))            # a row does not depend on the batch
+    if cin % 4 == 0:
+        y32 = ops.linear(x, w, b, out_slope=slope)
+        assert err <= (y32.double() - ref).abs().max().item()

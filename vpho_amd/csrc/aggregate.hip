@@ -51,8 +51,50 @@ __device__ inline void project_norm(const float* p3, const float* K, const float
     gy = 2.f * py / (bbox[3] - bbox[1]) - 1.f;
 }
 
+// Round 6: the same look-up with the coordinate chain in DOUBLE -- root + joint, pinhole projection, normalisation to the box, grid
+// coordinate, the eight cubic weights and the 16-tap sum; the result is rounded to fp32 once.  Why: the end-to-end fp64 judge
+// (oracle/judge_fp64.py) found the scores of the cascade's picks 1.5 x farther (rms) from the float64 scores than the reference's own
+// fp32 arithmetic at every level (1.6e-6 against 1.1e-6 of the score scale at level 0, 5.0e-6 against 3.2e-6 at level 1), and the lists
+// flipping against the float64 order more often (32 against 19 of 256 images).  The noise is born where a 0.7-m camera coordinate is
+// projected to a pixel of a 64 x 64 map in fp32 (each rounding of u = fx X + cx Z is 1e-5 px; mul + add without contraction round five
+// times where torch's matmul rounds three) and multiplied by the heat-map's slope; ~40 fp64 operations per look-up beside 16 loads cost
+// nothing.  VPHO_SCORE_FP32=1 keeps the fp32 chain (A/B aid for the judge).
+__device__ inline double cubic1d(double x) { const double A = -0.75; return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0; }
+__device__ inline double cubic2d(double x) { const double A = -0.75; return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A; }
+__device__ inline float bicubic_zero_d(const float* __restrict__ plane, int H, int W, double gx, double gy) {
+    const double ix = ((gx + 1.0) * (double)W - 1.0) / 2.0, iy = ((gy + 1.0) * (double)H - 1.0) / 2.0;
+    const double fx = floor(ix), fy = floor(iy);
+    const double tx = ix - fx, ty = iy - fy;
+    // (a point far outside the map: every tap is outside, the value is 0 -- and the casts below stay in range)
+    if (!(fx > -4.0 && fx < (double)W + 4.0 && fy > -4.0 && fy < (double)H + 4.0)) return 0.f;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const double cx[4] = {cubic2d(tx + 1.0), cubic1d(tx), cubic1d(1.0 - tx), cubic2d(2.0 - tx)};
+    const double cy[4] = {cubic2d(ty + 1.0), cubic1d(ty), cubic1d(1.0 - ty), cubic2d(2.0 - ty)};
+    double acc = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const int yy = y0 - 1 + i;
+        double r = 0.0;
+        for (int j = 0; j < 4; ++j) {
+            const int xx = x0 - 1 + j;
+            const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? plane[yy * W + xx] : 0.f;
+            r += (double)v * cx[j];
+        }
+        acc += r * cy[i];
+    }
+    return (float)acc;
+}
+__device__ inline void project_norm_d(const double* p3, const float* K, const float* bbox, double& gx, double& gy) {
+    const double u = p3[0] * (double)K[0] + p3[1] * (double)K[1] + p3[2] * (double)K[2];
+    const double v = p3[0] * (double)K[3] + p3[1] * (double)K[4] + p3[2] * (double)K[5];
+    const double w = p3[0] * (double)K[6] + p3[1] * (double)K[7] + p3[2] * (double)K[8];
+    const double px = u / w - (double)bbox[0], py = v / w - (double)bbox[1];
+    gx = 2.0 * px / ((double)bbox[2] - (double)bbox[0]) - 1.0;
+    gy = 2.0 * py / ((double)bbox[3] - (double)bbox[1]) - 1.0;
+}
+
 // hand: hv[b][c][i] = bicubic(heatmap[b][obs[i]], project(joint[b][c][obs[i]] + root[b]))          (aggregation.py:196-213)
 struct ObsList { int n; int idx[21]; };
+template <bool F64>
 __global__ void hand_heat_kernel(const float* __restrict__ joints, const float* __restrict__ root, const float* __restrict__ Kmat,
                                  const float* __restrict__ bbox, const float* __restrict__ heatmap, int bs, int C, int J, int H, int W,
                                  ObsList obs, float* __restrict__ out) {
@@ -63,6 +105,13 @@ __global__ void hand_heat_kernel(const float* __restrict__ joints, const float* 
     const int b = (int)(bc / C);
     const int j = obs.idx[o];
     const float* p = joints + (bc * 21 + j) * 3;
+    if (F64) {
+        const double p3[3] = {(double)p[0] + (double)root[b * 3 + 0], (double)p[1] + (double)root[b * 3 + 1], (double)p[2] + (double)root[b * 3 + 2]};
+        double gx, gy;
+        project_norm_d(p3, Kmat + b * 9, bbox + b * 4, gx, gy);
+        out[i] = bicubic_zero_d(heatmap + ((long long)b * J + j) * H * W, H, W, gx, gy);
+        return;
+    }
     const float p3[3] = {p[0] + root[b * 3 + 0], p[1] + root[b * 3 + 1], p[2] + root[b * 3 + 2]};
     float gx, gy;
     project_norm(p3, Kmat + b * 9, bbox + b * 4, gx, gy);
@@ -71,6 +120,10 @@ __global__ void hand_heat_kernel(const float* __restrict__ joints, const float* 
 
 // object: score[b][c] = sum_i bicubic(heatmap[b][i], project(flip(R(pose) kpt_i + t + root)))        (aggregation.py:742-776)
 // pose: (bs, n, 9) fp64; optional per-image translation override (bs,3) fp64 (aggregation.py:1219-1220)
+// F64: the poses are fp64 already (quirk Q5: the sampler returns float64 object poses, the reference casts them with .float(), :753):
+// rotation from the 6-D columns, key-point transform, translation + root, flip, projection, look-up and the sum over the key-points all
+// in double, one rounding at the end
+template <bool F64>
 __global__ void obj_heat_kernel(const double* __restrict__ pose, const double* __restrict__ transl_override, const float* __restrict__ root,
                                 const float* __restrict__ kpt_tab, const int* __restrict__ obj_id, const unsigned char* __restrict__ is_right,
                                 const float* __restrict__ Kmat, const float* __restrict__ bbox, const float* __restrict__ heatmap,
@@ -79,11 +132,28 @@ __global__ void obj_heat_kernel(const double* __restrict__ pose, const double* _
     if (i >= (long long)bs * n) return;
     const int b = (int)(i / n);
     const double* pp = pose + i * 9;
+    const float* kp = kpt_tab + (long long)obj_id[b] * J * 3;
+    if (F64) {
+        double R[9], t[3];
+        vpho::rot6d_to_matrix<double>(pp, R);
+        for (int k = 0; k < 3; ++k) t[k] = (transl_override ? transl_override[b * 3 + k] : pp[6 + k]) + (double)root[b * 3 + k];
+        const double sgn = is_right[b] ? 1.0 : -1.0;
+        double acc = 0.0;
+        for (int j = 0; j < J; ++j) {
+            double p3[3];
+            for (int r = 0; r < 3; ++r) p3[r] = ((double)kp[j * 3 + 0] * R[r * 3 + 0] + (double)kp[j * 3 + 1] * R[r * 3 + 1] + (double)kp[j * 3 + 2] * R[r * 3 + 2]) + t[r];
+            p3[0] = p3[0] * sgn;
+            double gx, gy;
+            project_norm_d(p3, Kmat + b * 9, bbox + b * 4, gx, gy);
+            acc += (double)bicubic_zero_d(heatmap + ((long long)b * J + j) * H * W, H, W, gx, gy);
+        }
+        out[i] = (float)acc;
+        return;
+    }
     float p6[6], R[9], t[3];
     for (int k = 0; k < 6; ++k) p6[k] = (float)pp[k];
     for (int k = 0; k < 3; ++k) t[k] = (float)(transl_override ? transl_override[b * 3 + k] : pp[6 + k]) + root[b * 3 + k];
     vpho::rot6d_to_matrix(p6, R);
-    const float* kp = kpt_tab + (long long)obj_id[b] * J * 3;
     const float sgn = is_right[b] ? 1.f : -1.f;
     float acc = 0.f;
     for (int j = 0; j < J; ++j) {
@@ -659,7 +729,9 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, long long ld_src
 }  // namespace
 
 #define LAUNCH1D(kernel, total, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__)
+    hipLaunchKernelGGL((kernel), dim3(nblocks(total)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__)
+// VPHO_SCORE_FP32=1: the heat-map scores' coordinate chain in fp32 as until round 5 (A/B aid of the fp64 judge; read per call)
+static bool score_fp32() { const char* e = getenv("VPHO_SCORE_FP32"); return e && e[0] == '1'; }
 
 extern "C" int vpho_hand_candidates_f32(const float* diff_pose, int ld_diff, const float* reg_pose, int bs, int S, float* pose, void* stream) {
     VPHO_REQUIRE(diff_pose && reg_pose && pose && bs > 0 && S > 0 && ld_diff >= 48, "vpho_hand_candidates_f32: bad argument");
@@ -674,7 +746,8 @@ extern "C" int vpho_hand_heat_f32(const float* joints, const float* root, const 
     ObsList ol;
     ol.n = n_obs;
     for (int i = 0; i < n_obs; ++i) { VPHO_REQUIRE(observe_host[i] >= 0 && observe_host[i] < 21, "vpho_hand_heat_f32: joint index out of range"); ol.idx[i] = observe_host[i]; }
-    LAUNCH1D(hand_heat_kernel, (long long)bs * C * n_obs, stream, joints, root, Kmat, bbox, heatmap, bs, C, J, H, W, ol, out);
+    if (score_fp32()) LAUNCH1D(hand_heat_kernel<false>, (long long)bs * C * n_obs, stream, joints, root, Kmat, bbox, heatmap, bs, C, J, H, W, ol, out);
+    else LAUNCH1D(hand_heat_kernel<true>, (long long)bs * C * n_obs, stream, joints, root, Kmat, bbox, heatmap, bs, C, J, H, W, ol, out);
     return vpho::check_launch("hand_heat_kernel");
 }
 
@@ -728,7 +801,8 @@ extern "C" int vpho_obj_heat_score(const double* pose, int n, const double* tran
                                    const int* obj_id, const unsigned char* is_right, const float* Kmat, const float* bbox,
                                    const float* heatmap, int bs, int H, int W, float* score, void* stream) {
     VPHO_REQUIRE(pose && root && t && t->kpt && obj_id && is_right && Kmat && bbox && heatmap && score && bs > 0 && n > 0, "vpho_obj_heat_score: bad argument");
-    LAUNCH1D(obj_heat_kernel, (long long)bs * n, stream, pose, transl_override, root, t->kpt, obj_id, is_right, Kmat, bbox, heatmap, bs, n, t->n_kpt, H, W, score);
+    if (score_fp32()) LAUNCH1D(obj_heat_kernel<false>, (long long)bs * n, stream, pose, transl_override, root, t->kpt, obj_id, is_right, Kmat, bbox, heatmap, bs, n, t->n_kpt, H, W, score);
+    else LAUNCH1D(obj_heat_kernel<true>, (long long)bs * n, stream, pose, transl_override, root, t->kpt, obj_id, is_right, Kmat, bbox, heatmap, bs, n, t->n_kpt, H, W, score);
     return vpho::check_launch("obj_heat_kernel");
 }
 

@@ -87,6 +87,9 @@ class Engine:
         # shapes, different weights (backbone_FPN_HFL.py:79-109, VPHO.py:131-149, encoding.py:58-73) -> stacked (2, Cout, K) and run as ONE
         # launch each.  VPHO_GROUPED=0: one launch per branch (A/B aid; bit-identical, tests/test_gpu_predict.py)
         self.grouped = os.environ.get('VPHO_GROUPED', '1') != '0'
+        # regression head (head_mano's four linear layers on one row per image) with fp64 products and sums: its rounding noise is what the
+        # cascade's regression copies inherit, amplified by the 6-D normalisation (VPHO_HEAD_F64=0: the fp32-MFMA GEMM kernel; A/B aid)
+        self.head64 = os.environ.get('VPHO_HEAD_F64', '1') != '0'
         if self.grouped:
             pair = lambda a, b: (torch.stack([a[0], b[0]]).contiguous(), torch.stack([a[1], b[1]]).contiguous())
 
@@ -404,9 +407,10 @@ class Engine:
         hand_heatmap, obj_heatmap = ops.nhwc_to_nchw(hm_hand), ops.nhwc_to_nchw(hm_obj)
         tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
         hmn = self.head_mano
-        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01), *hmn['l2'], out_slope=0.01)
-        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose']), 16)                      # (bs,48)
-        shape = ops.linear(h, *hmn['shape'])                                                 # (bs,10)
+        a64 = self.head64                                                                    # the regression head with fp64 accumulation (ops.linear)
+        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01, acc64=a64), *hmn['l2'], out_slope=0.01, acc64=a64)
+        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose'], acc64=a64), 16)                      # (bs,48)
+        shape = ops.linear(h, *hmn['shape'], acc64=a64)                                      # (bs,10)
         ctx = self.mano.shape(shape)
         ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
         reg_vert, reg_joint = self.mano.fk(pose, ctx, 1, True, ho3d)
@@ -463,9 +467,10 @@ class Engine:
         with self._side():
             tok_o = self._cross(self.cross['obj'], st_h[1], st_o[1], grav, left_u8)
         hmn = self.head_mano
-        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01), *hmn['l2'], out_slope=0.01)
-        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose']), 16)                  # (bs,48)
-        shape = ops.linear(h, *hmn['shape'])                                             # (bs,10)
+        a64 = self.head64                                                                    # the regression head with fp64 accumulation (ops.linear)
+        h = ops.linear(ops.linear(enc_h, *hmn['l0'], out_slope=0.01, acc64=a64), *hmn['l2'], out_slope=0.01, acc64=a64)
+        pose = ops.rot6d_to_axis_angle(ops.linear(h, *hmn['pose'], acc64=a64), 16)                  # (bs,48)
+        shape = ops.linear(h, *hmn['shape'], acc64=a64)                                  # (bs,10)
         ctx = self.mano.shape(shape)
         ho3d = data['is_ho3d'].to(torch.uint8).contiguous() if 'is_ho3d' in data else None
         reg_vert, reg_joint = self.mano.fk(pose, ctx, 1, True, ho3d)

@@ -380,9 +380,15 @@ def conv3x3_dgrad_winograd(dy, w, gate=None, rows=None):
     return out
 
 
-def linear(x, w, bias=None, out_slope=1.0, out=None):
-    """x: (rows, cin) fp32, w: (cout, cin) -> (rows, cout).  Same kernel as conv2d_nhwc (1x1)."""
+def linear(x, w, bias=None, out_slope=1.0, out=None, acc64=False):
+    """x: (rows, cin) fp32, w: (cout, cin) -> (rows, cout).  Same kernel as conv2d_nhwc (1x1).  ``acc64``: products and sum in double,
+    one rounding (vpho_linear_acc64_f32: the regression head, whose rounding noise the 6-D normalisation amplifies into the candidates)"""
     rows, cin = x.shape
+    if acc64:
+        assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == cin
+        y = torch.empty((rows, w.shape[0]), device=x.device, dtype=torch.float32) if out is None else out
+        _call('vpho_linear_acc64_f32', _f32(x), I(rows), I(cin), I(cin), _f32(w), _f32(bias), I(w.shape[0]), F(out_slope), _f32(y), I(y.shape[-1]))
+        return y
     y = conv2d_nhwc(x.view(rows, 1, 1, cin), w, bias, out_slope=out_slope,
                     out=None if out is None else out.view(rows, 1, 1, w.shape[0]))
     return y.view(rows, w.shape[0])
