@@ -108,6 +108,11 @@ def test_trainer_eval_consumes_any_iterable_of_batch_dicts(assets):
         torch.manual_seed(11)
         got = t.eval(loader=iter(batches))
         assert got[:, 0].tolist() == [100.0, 101.0, 102.0, 103.0, 104.0, 105.0] and torch.equal(got[:, 1:], want[:, 1:])
+        for i, b in enumerate(batches):                        # a shuffled loader: the indices are kept image by image
+            b['index'] = torch.tensor([[905, 17], [3, 4400], [12, 11]][i])
+        torch.manual_seed(11)
+        got = t.eval(loader=iter(batches))
+        assert got[:, 0].tolist() == [905.0, 17.0, 3.0, 4400.0, 12.0, 11.0] and torch.equal(got[:, 1:], want[:, 1:])
         for b in batches:
             del b['index']
         with pytest.raises(ValueError, match='no batch on any rank'):

@@ -190,13 +190,16 @@ class Trainer:
         seen = 0
         for b in loader:
             # column 0 of the metric rows, decided on the HOST batch (a device tensor here would cost two syncs per batch inside the
-            # three-deep pipeline): the data set's own index where the batch is a run of it, else rank-unique NEGATIVE ids
+            # three-deep pipeline): the data set's own indices (one arange when the batch is a run of them, else the index tensor itself); batches WITHOUT an `index` key get rank-unique NEGATIVE ids
             # -(rank + world * running count) - 1 per image -- they can collide neither with another rank's fallback nor with a real data-set index
             idx = b.get('index')
-            if torch.is_tensor(idx) and idx.numel() and loader_indices_are_consecutive(idx.cpu() if idx.is_cuda else idx):
-                first = int(idx.reshape(-1)[0])
-            else:
-                first = None
+            first = ids = None
+            if torch.is_tensor(idx) and idx.numel():
+                hidx = (idx.cpu() if idx.is_cuda else idx).reshape(-1)
+                if loader_indices_are_consecutive(hidx):
+                    first = int(hidx[0])
+                else:
+                    ids = hidx.clone()            # a shuffled loader / DistributedSampler: the data set's own indices, image by image
             b = self._to_device(b)
             missing = [k for k in ('gt_joint', 'gt_hand_vert') if k not in b]
             if missing:
@@ -205,7 +208,7 @@ class Trainer:
                 from . import ops
                 b['gt_obj_rt'] = ops.obj_9d_to_rt(b['gt_obj'].double().contiguous(), b['root_joint'].float().contiguous()).float()
             n = b['rgb'].shape[0]
-            yield b, (b['gt_joint'].float(), b['gt_hand_vert'].float()), (first if first is not None else -(self.rank + self.world * (seen + torch.arange(n))) - 1)
+            yield b, (b['gt_joint'].float(), b['gt_hand_vert'].float()), (first if first is not None else ids if ids is not None else -(self.rank + self.world * (seen + torch.arange(n))) - 1)
             seen += n
 
     @torch.no_grad()
