@@ -1,11 +1,15 @@
 """End-to-end fp64 judge over several (data, prior) seeds at the README config (oracle/judge_fp64.py): per seed one 64-image batch through
 the HIP path, the fp32 oracle, and the float64 predict on either side's accepted step sequences.
-    python scripts/e2e_fp64.py [--images 64] [--out gpurun_out/r06_e2e_fp64.json] [seed ...]      (default seeds 777 1 2 3; ~4 min of CPU per seed)
+    python scripts/e2e_fp64.py [--images 64] [--out gpurun_out/r06_e2e_fp64.json] [seed ...]      (default seeds 777 1 2 3; ~2 min of CPU per seed)
+    python scripts/e2e_fp64.py --images 128 --sample_num 256 --sampling_steps 100 --chunk 4 5      (BASELINE cfg4, one seed: ~15 min)
 -> one JSON line per seed (progress) and the file: per seed the table of oracle.judge_fp64.judge, plus the totals over the seeds
 (profiles/r06_e2e_fp64.json is this file)."""
 import argparse, json, os, sys, time
 ap = argparse.ArgumentParser()
 ap.add_argument('--images', type=int, default=64)
+ap.add_argument('--sample_num', type=int, default=100)
+ap.add_argument('--sampling_steps', type=int, default=50)
+ap.add_argument('--chunk', type=int, default=8, help='images per aggregation call of the float64 predict (memory)')
 ap.add_argument('--out', default=os.path.join('gpurun_out', 'r06_e2e_fp64.json'))
 ap.add_argument('seeds', nargs='*', type=int)
 args = ap.parse_args()
@@ -19,7 +23,7 @@ from vpho_amd.synth import bench_state_dict, synth_batch
 from vpho_amd.hostcpu import usable_cpus
 from oracle import vpho as OV, judge_fp64 as J
 torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))
-S, steps, KH, KO, T0, n = 100, 50, 30, 10, 0.65, args.images
+S, steps, KH, KO, T0, n = args.sample_num, args.sampling_steps, 30, 10, 0.65, args.images
 cfg.sample_num, cfg.sampling_steps, cfg.topk_hand, cfg.topk_obj, cfg.sample_T0 = S, steps, KH, KO, T0
 kw = dict(sample_num=S, sample_T0=T0, sampling_steps=steps, topk_hand=KH, topk_obj=KO)
 assets = synthetic_assets(0)
@@ -45,8 +49,8 @@ for seed in seeds:
     f64 = J.features64(sd, assets, data)
     t_feat = time.time() - t0
     t0 = time.time()
-    o64h, d64h = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=gi['hand_ode']['steps'], steps_obj=gi['obj_ode']['steps'], feat64=f64, **kw)
-    o64o, d64o = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=info['hand_ode']['steps'], steps_obj=info['obj_ode']['steps'], feat64=f64, **kw)
+    o64h, d64h = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=gi['hand_ode']['steps'], steps_obj=gi['obj_ode']['steps'], feat64=f64, chunk=args.chunk, **kw)
+    o64o, d64o = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=info['hand_ode']['steps'], steps_obj=info['obj_ode']['steps'], feat64=f64, chunk=args.chunk, **kw)
     t_64 = time.time() - t0
     rep = J.judge(out, gi['agg'], ref, info['agg'], o64h, d64h, o64o, d64o, S)
     rep['hypotheses_max_abs_vs_fp64'] = {'hip_hand': float((gi['hand_x6d'].cpu().double() - o64h['hand_x6d']).abs().max()), 'oracle_hand': float((info['hand_x6d'].double() - o64o['hand_x6d']).abs().max()),
@@ -62,7 +66,8 @@ for seed in seeds:
             t = by.setdefault(st, {k: 0 for k in d})
             for k, v in d.items():
                 t[k] += v
-    summary = {'what': 'README config, %d images per seed; within 1e-3 (21 joints, 778 vertices, object 6-DoF) of the float64 predict on the side\'s own accepted step '
+    summary = {'config': {'images': n, 'sample_num': S, 'sampling_steps': steps, 'topk_hand': KH, 'topk_obj': KO, 'sample_T0': T0},
+               'what': '%d images per seed; within 1e-3 (21 joints, 778 vertices, object 6-DoF) of the float64 predict on the side\'s own accepted step '
                        'sequences (oracle/judge_fp64.py); by_first_stage: the images on which the two fp32 sides differ by more than 1e-3, by the first selection '
                        'that differs, and which side\'s list there the float64 order agrees with' % n,
                'seeds': list(per_seed), 'images_within_1e-3_of_fp64_per_seed': tot,
