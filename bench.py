@@ -51,6 +51,7 @@ def parse():
     p.add_argument('--sample_T0', type=float, default=0.65)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_kernel_timing', action='store_true')
+    p.add_argument('--no_fp64_judge', action='store_true', help='skip the end-to-end float64 judge of the parity leg (~75 s of CPU on 16 cores)')
     p.add_argument('--no_opt_in', action='store_true', help='skip the secondary measurement of the opt-in split-bf16 product path (N=1 only)')
     p.add_argument('--cpu_images', type=int, default=64, help='images of the oracle / parity leg (one batch)')
     p.add_argument('--weights', choices=('conditioned', 'random'), default='conditioned', help='synthetic weight set (vpho_amd.synth)')
@@ -459,6 +460,7 @@ def compact_line(full):
             'fp64_referee_images_identical_hip_ref': [g(par, 'fp64_referee', 'images_identical_to_fp64_order'), g(par, 'fp64_referee', 'images_identical_to_fp64_order_fp32_reference')],
             'sampler_err_ratio_hip_over_ref_max': [g(s64, 'hand', 'ratio_max'), g(s64, 'obj', 'ratio_max')],
             'fp64_judge_within_1e-3_hip_ref': [f64j.get('images_within_1e-3_hip'), f64j.get('images_within_1e-3_oracle')] if f64j else None,
+            'fp64_judge_lists_identical_hip_ref': [g(f64j, 'images_lists_identical_to_fp64', 'hip'), g(f64j, 'images_lists_identical_to_fp64', 'oracle')] if f64j else None,
         }
     line['value_full_maps'] = g(full, 'value_full_maps', 'value')
     line['opt_in_split_bf16x6_value'] = g(full, 'opt_in', 'split_bf16x6', 'value')
@@ -623,6 +625,20 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
         eo = (info['features'][k][:n64].double() - f64[k]).abs()
         feat64[k] = {'err_hip_max': float(eh.max()), 'err_oracle_max': float(eo.max()), 'err_hip_rms': float(eh.pow(2).mean().sqrt()),
                      'err_oracle_rms': float(eo.pow(2).mean().sqrt()), 'scale': float(f64[k].abs().max())}
+    # the end-to-end float64 judge (oracle/judge_fp64.py): ONE predict in double on either side's accepted step sequences -- which fp32 side is
+    # within 1e-3 of what the algorithm computes in exact arithmetic, image by image
+    judge64 = None
+    if not args.no_fp64_judge:
+        from oracle import judge_fp64 as J64
+        kw64 = dict(sample_num=args.sample_num, sample_T0=args.sample_T0, sampling_steps=args.sampling_steps, topk_hand=args.topk_hand, topk_obj=args.topk_obj,
+                    noise_hand=nh, noise_obj=no)
+        tj = time.perf_counter()
+        f64j = J64.features64(sd, assets, data)
+        o64h, d64h = J64.predict_fp64(sd, assets, skeleton, data, steps_hand=eng_info['hand_ode']['steps'], steps_obj=eng_info['obj_ode']['steps'], feat64=f64j, **kw64)
+        o64o, d64o = J64.predict_fp64(sd, assets, skeleton, data, steps_hand=info['hand_ode']['steps'], steps_obj=info['obj_ode']['steps'], feat64=f64j, **kw64)
+        judge64 = J64.judge({k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in out.items()}, eng_info['agg'], ref, info['agg'], o64h, d64h, o64o, d64o, args.sample_num)
+        judge64['images_within_1e-3_hip'], judge64['images_within_1e-3_oracle'] = judge64['images_within_1e3_of_fp64']['hip'], judge64['images_within_1e3_of_fp64']['oracle']
+        judge64['seconds'] = time.perf_counter() - tj
     # how well the REFERENCE reproduces itself (committed fixture written by the reference's own forward under other thread counts /
     # oneDNN off, tests/golden/make_golden_readme.py --variant): the yardstick for end_to_end_vs_oracle's list counts
     from oracle.compare import reference_self_agreement
@@ -651,7 +667,8 @@ def cpu_baseline_leg(args, cfg, model, sd, assets, skeleton, dev):
                        'reference_self_agreement': self_rep,
                        'end_to_end_vs_oracle': end_to_end,
                        'aggregation_given_identical_candidates': given_same,
-                       'identical_candidates_gaps_above_tie_bound': gaps_above}}
+                       'identical_candidates_gaps_above_tie_bound': gaps_above,
+                       'fp64_judge': judge64}}
 
 
 if __name__ == '__main__':
