@@ -33,9 +33,12 @@ for seed in seeds:
     data = synth_batch(n, assets, seed=seed)
     torch.manual_seed(99 + seed)
     nh, no = torch.randn(n * S, 96), torch.randn(n * S, 9)
+    say = lambda what: print(f'[seed {seed}] {time.strftime("%H:%M:%S")} {what}', file=sys.stderr, flush=True)      # a long silent phase looks hung to a watchdog
+    say('fp32 oracle ...')
     t0 = time.time()
     ref, info = OV.predict(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, **kw)
     t_or = time.time() - t0
+    say('HIP predict ...')
     gdata = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
     m(gdata, mode='predict')                                   # builds the engine
     eng = m._engine
@@ -45,11 +48,14 @@ for seed in seeds:
     gi = eng.last_info
     eng.keep_states = False
     out = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
+    say('float64 feature path ...')
     t0 = time.time()
     f64 = J.features64(sd, assets, data)
     t_feat = time.time() - t0
+    say('float64 predict on the HIP step sequences ...')
     t0 = time.time()
     o64h, d64h = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=gi['hand_ode']['steps'], steps_obj=gi['obj_ode']['steps'], feat64=f64, chunk=args.chunk, **kw)
+    say('float64 predict on the oracle step sequences ...')
     o64o, d64o = J.predict_fp64(sd, assets, ANCHOR_SKELETON, data, noise_hand=nh, noise_obj=no, steps_hand=info['hand_ode']['steps'], steps_obj=info['obj_ode']['steps'], feat64=f64, chunk=args.chunk, **kw)
     t_64 = time.time() - t0
     rep = J.judge(out, gi['agg'], ref, info['agg'], o64h, d64h, o64o, d64o, S)
