@@ -115,7 +115,7 @@ __global__ __launch_bounds__(FO_THREADS) void force_optim_kernel(const FoArgs a)
     using M_ = Fm<EXACT>;
     __shared__ __align__(16) float s_red[2][FO_MAXB];
     __shared__ __align__(16) float s_g[FO_MAXB][4];
-    __shared__ float s_fin[4][FO_MAXB];
+    __shared__ __align__(16) float s_fin[4][FO_MAXB];      // row 0 is read 16 bytes at a time (batch_mean)
     __shared__ __align__(8) float s_tab[FO_TAB][2];         // per iteration: AdamW step size lr / (1 - beta1^n), and (1 - beta2^n)^(+-1/2)
     extern __shared__ __align__(16) float s_mom[];          // [9 parameters][thread] x (m item 0, m item 1, v item 0, v item 1)
     const int batch = blockIdx.x, B = a.B, tid = threadIdx.x;
