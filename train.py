@@ -158,7 +158,7 @@ def pmc_traffic(kernel, source=False):
     """HBM bytes per launch of `kernel` (launch-weighted over its instantiations' rows) from the newest committed rocprofv3 --pmc summary of
     the training step (profiles/r0N_train_pmc_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, scripts/profile_round.sh PART=train); None when absent"""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rnd in ('r05', 'r04'):
+    for rnd in ('r06', 'r05', 'r04'):
         path = os.path.join(root, 'profiles', f'{rnd}_train_pmc_hbm_traffic.json')
         try:
             with open(path) as f:
