@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 VPHO_API const char* vpho_last_error(void);
-VPHO_API int vpho_abi_version(void);   /* 11 */
+VPHO_API int vpho_abi_version(void);   /* 12 */
 
 /* Opt-in timing of one kernel class with HIP events recorded on the launch stream around every launch
  * (0 = conv_igemm 128x128 tile, 1 = conv_igemm 64x64 tile, 2 = fused score head, 3 = conv_igemm 128x64 tile; HBM-bound kernels,
@@ -110,6 +110,29 @@ typedef struct {
      * the two single launches).  No splits / pixel list / gate / bf16 planes. */
     int groups;
     long long x_group, w_group, bias_group, y_group, res_group, x2_group, pre_group, ru_group;
+    /* Optional (NULL = off; ABI version 12): the reductions of a train-mode BatchNorm next to this convolution, taken in its epilogue
+     * while the output tile is still on the chip (nn.BatchNorm2d under model.train() behind every convolution of Bottleneck / Residual /
+     * HeadHeatmap2: backbone_FPN_HFL.py:330-350, encoding.py:21-36, head_inplane.py:40-58; train_diff_hand_obj.py:171,181).
+     *   stats      device, [stats_cap][2][Cout] floats: row t = the partial sums over the output rows of M-tile t of the values this launch
+     *              STORES (after bias / residual / activation / gate): plane 0 = sum v, plane 1 = sum v * v -- the statistics pass of
+     *              the BatchNorm that FOLLOWS the convolution (vpho_bn_train_forward_stats_f32 finishes them in fp64).  Plain stores, one
+     *              writer per element, fixed order: bit-reproducible.
+     *   stats_rows HOST pointer, written before the call returns: the number of partial rows the launch writes (= its M-tiles), or 0 when
+     *              the kernel chosen for this shape does not produce them (the caller then runs the stand-alone reduction).  A launch that
+     *              needs more than stats_cap rows writes none and reports 0.
+     *   bn_x != NULL (input-gradient convolutions): the launch's output is the gradient at the OUTPUT of act(BatchNorm(bn_x)), bn_x laid
+     *              out like y.  The epilogue recomputes xhat = (bn_x - bn_mean) * bn_invstd and the activation's sign from
+     *              xhat * bn_gamma + bn_beta (the expression of the forward pass: the same bits), applies the activation's backward
+     *              (y = t > 0 ? y : y * gate_slope, as `gate` would with the stored activation), and plane 1 becomes sum y * xhat:
+     *              the two sums of the BatchNorm backward (d beta, d gamma; vpho_bn_train_backward_stats_f32).  With `gate` set as well
+     *              the sign comes from the stored activation as usual and only xhat is recomputed (bn_gamma / bn_beta unused): the
+     *              closing activation of a residual block, lrelu(BatchNorm(x) + shortcut), whose sign bn_x alone does not determine.
+     * Served by the direct-to-LDS kernels' 16-byte epilogue: no splits / pixel list / groups / bf16 planes; with bn_x the call fails on
+     * other shapes instead of dropping the gate. */
+    float* stats;
+    int* stats_rows;
+    int stats_cap;
+    const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
 } vpho_conv_desc;
 /* Limits: Cin, x_ld multiples of 4, 16-byte aligned x / w; x and w (all splits included) below 3.9 GB each (32-bit buffer offsets). */
 VPHO_API int vpho_conv2d_nhwc_f32(const vpho_conv_desc* d, void* stream);
@@ -149,6 +172,15 @@ VPHO_API int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin,
 VPHO_API int vpho_winograd_weights_multi_f32(const void* segments, int n_segments, long long total_blocks, void* stream);
 VPHO_API int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* u, const float* gate, float gate_slope, int N, int H, int W, int Cin,
                                         int x_ld, int Cout, float* y, int y_ld, void* stream);
+/* Full-map Winograd convolution with the BatchNorm reductions of vpho_conv_desc.stats in its epilogue (ABI version 12): stats =
+ * [ceil(N*H*W/256)][2][Cout] floats, row t = the sums over the 256 output pixels of tile block t (64 tiles of 2 x 2); returns the number of
+ * rows through *stats_rows (host).  bn_x == NULL: the forward convolution (bias, out_slope as above; sum v | sum v^2 of the stored values).
+ * bn_x != NULL: the input-gradient convolution of the gate variant with the gate recomputed from bn_x (laid out like y, leading dimension
+ * y_ld) and the BatchNorm vectors -- y = (xhat * gamma + beta > 0) ? y : gate_slope * y, sums y | y * xhat -- see vpho_conv_desc. */
+VPHO_API int vpho_conv3x3_winograd_stats_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+                                         float out_slope, float* y, int y_ld, float* stats, int stats_cap, int* stats_rows, const float* bn_x,
+                                         const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                         float gate_slope, void* stream);
 VPHO_API int vpho_conv3x3_winograd_rows_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
                                         float out_slope, const int* wins, const int* tile_base, int tiles_hint, float* y_rows, int y_ld,
                                         void* stream);
@@ -506,6 +538,16 @@ VPHO_API int vpho_bn_train_forward_f32(const float* x, long long rows, int C, in
                               float* y, void* workspace, void* stream);
 VPHO_API int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
                                const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
+/* The same two calls when the reductions were taken by the producing convolution's epilogue (ABI version 12; vpho_conv_desc.stats,
+ * vpho_conv3x3_winograd_stats_nhwc_f32): stats = [stats_rows][2][C] float partial sums (forward: sum x | sum x^2 of x's rows; backward:
+ * sum dy | sum dy * xhat), combined here in fp64 in a fixed order -- the pass over x (and dy) that vpho_bn_train_*_f32 start with is
+ * not run.  Everything else as above. */
+VPHO_API int vpho_bn_train_forward_stats_f32(const float* x, long long rows, int C, int ld, const float* stats, int stats_rows, const float* gamma,
+                                    const float* beta, float eps, float momentum, float slope, float* running_mean, float* running_var,
+                                    float* save_mean, float* save_invstd, const float* res, float* y, void* workspace, void* stream);
+VPHO_API int vpho_bn_train_backward_stats_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, const float* stats, int stats_rows, float* dx, float* dgamma, float* dbeta,
+                                     void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
 VPHO_API int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
 /* nn.MaxPool2d backward (backbone_FPN_HFL.py:209): dx[n,iy,ix,c] = sum of dy over the windows whose first maximum (row-major)

@@ -5,6 +5,7 @@
 #   exposed  only the pipelined kernel trace + exposed-time analysis
 #   cfg4     bench line + kernel stats of the stress config (bs 128, 256 hypotheses, 100 stamps)
 #   train    training-step bench lines (bs 64 and cfg3's own bs 32) + kernel trace on one stream + idle gaps + PMC traffic passes
+#   traintrace  only the training step's one-stream kernel trace + statistics
 #   force    force-optimisation bench line (cfg5) + PMC traffic passes
 # Every GPU step runs under its own timeout; a step that had to be killed ends its chain (scripts/gstep.sh).
 T=${T:-r05a}; PART=${PART:-cfg2}
@@ -49,6 +50,13 @@ if has cfg4; then
   python3 scripts/pmc_summary.py $(csv ${T}_cfg4_pmc_f counter_collection) $(csv ${T}_cfg4_pmc_w counter_collection) $O/${T}_cfg4_pmc_hbm.json > $O/${T}_cfg4_pmc_hbm.txt
   { for sw in VPHO_HEAD_CB VPHO_CONV_PERS VPHO_WINO_STAGED; do bash scripts/ab.sh cfg4_$sw "$sw=0" "$sw=1" 2 -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing $C4 --steps 6 2>&1 | grep run; done; } > $O/${T}_cfg4_ab.txt 2>&1
   scrub ${T}_cfg4_prof ${T}_cfg4_pmc_f ${T}_cfg4_pmc_w; head -8 $O/${T}_cfg4_stats.txt | cut -c1-150; cat $O/${T}_cfg4_ab.txt
+fi
+if has traintrace; then
+  # only the one-stream kernel trace of the training step + statistics + idle gaps (quick look between kernel changes)
+  scrub ${T}_train_prof
+  VPHO_WGRAD_STREAM=0 prof ${T}_train_prof --kernel-trace --stats -d $O/${T}_train_prof -o t -- python3 $R/train.py --steps 5 --warmup 2 --no_roofline &&
+  { python3 scripts/rocpd_stats.py $(db ${T}_train_prof) 40 --last-ms 370; python3 scripts/rocpd_gaps.py $(db ${T}_train_prof); } > $O/${T}_train_stats.txt 2>&1
+  scrub ${T}_train_prof; head -34 $O/${T}_train_stats.txt | cut -c1-150
 fi
 if has train; then
   gstep 300 $O/${T}_train_step.log python3 train.py --steps 10 --warmup 3 && grep '^{' $O/${T}_train_step.log > $O/${T}_train_step.json &&

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vpho_hip.h but not exported'
     lib.vpho_abi_version.restype = ctypes.c_int
-    assert lib.vpho_abi_version() == 11
+    assert lib.vpho_abi_version() == 12
 
 
 def test_library_exports_nothing_but_the_header():

@@ -144,18 +144,21 @@ def _derived(w_packed, key, builder):
     return builder(w_packed) if _ACTIVE is None else _ACTIVE.get(w_packed, key, builder)
 
 
-def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None, rows=None):
+def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x=None, gate=None, res=None, rows=None, bn=None):
     """dy (N,OH,OW,Cout), w_packed (Cout, kh*kw*Cin) -> dx (N,H,W,Cin) for y = conv2d(x, w, stride, pad) (pad_y / pad_x: the
     asymmetric top/left paddings of the transposed-convolution phases, stride 1 only).  ``gate`` = (y, slope): the result is
     additionally passed through the backward of the LeakyReLU that produced y = lrelu(x) (fused into the kernel's epilogue).
-    ``res`` (stride 1): a gradient of the same shape added to the result (the other branch of a residual sum)."""
+    ``res`` (stride 1): a gradient of the same shape added to the result (the other branch of a residual sum).
+    ``bn`` (with gate; an ``ops.BnFuse`` holding the BatchNorm input / statistics / affine whose activation produced y): where the
+    kernel of the shape allows (stride 1), the gate is recomputed from the BatchNorm input and the two sums of the BatchNorm backward are
+    taken in the epilogue (``bn.live()`` afterwards); elsewhere ``gate`` is used as is."""
     N, OH, OW, cout = dy.shape
     H, W = in_hw
     cin = w_packed.shape[1] // (kh * kw)
     if kh == 3 and kw == 3 and stride == 1 and pad == 1 and pad_y is None and pad_x is None and res is None and (OH, OW) == (H, W) and dy.is_contiguous():
         # Winograd F(2x2,3x3) on the flipped / transposed weights where the shape allows; rows (RoiWindows dilated by the halo): dy is
         # zero outside the windows, so only their pixels are computed (the rest of dx is zero)
-        dx = ops.conv3x3_dgrad_winograd(dy, w_packed, gate, rows=rows)
+        dx = ops.conv3x3_dgrad_winograd(dy, w_packed, gate, rows=rows, bn=bn)
         if dx is not None:
             return dx
     if cout % 4:                                          # the GEMM kernel wants a reduction length that is a multiple of 4
@@ -166,7 +169,8 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     px = pad if pad_x is None else pad_x
     if stride == 1:
         wt = _derived(w_packed, ('s1', kh, kw), lambda w, c=cout: _flip_transpose(_pad_rows4(w), c, cin, kh, kw))
-        return ops.conv2d_nhwc(dy, wt, None, kh=kh, kw=kw, stride=1, pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate, res=res)
+        return ops.conv2d_nhwc(dy, wt, None, kh=kh, kw=kw, stride=1, pad_x=kw - 1 - px, pad_y=kh - 1 - py, out_hw=(H, W), gate=gate, res=res,
+                               bn=bn if (gate is not None and bn is not None and bn.x is not None) else None)
     assert py == px == pad and res is None
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
     dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)

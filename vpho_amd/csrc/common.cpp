@@ -68,4 +68,4 @@ extern "C" int vpho_prof_collect(int cls, double* total_ms, long long* launches,
 }
 
 extern "C" const char* vpho_last_error(void) { return vpho::err_slot(); }
-extern "C" int vpho_abi_version(void) { return 11; }
+extern "C" int vpho_abi_version(void) { return 12; }

@@ -331,6 +331,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const Geo g) {
 // Geo::uni (Cin % 32 == 0): the 32 k of a stage lie in ONE tap: the tap is wave-uniform, the k / tap advance rides in the buffer
 // instruction's scalar offset and the per-lane offsets are loop constants (only the padding test of a 3x3 stays per stage; for 1x1
 // unpadded convolutions the loop has no per-lane address work at all).
+// x summed over the 8 lanes that differ in lane bits 3, 4, 5 (the 8 rows of an epilogue pass), on the vector ALU alone: a DPP rotate
+// inside the 16-lane row, then the gfx950 row / half swaps (v_permlane16_swap: odd rows of the first register <-> even rows of the second;
+// v_permlane32_swap: upper half of the first <-> lower half of the second; both registers start as x, so their sum is the exchange sum).
+// Every lane of the group ends with the same bits (a + b is commutative).  Inline assembly, both registers in / out: the builtins of this
+// hipcc return their second result equal to the first (scripts/microbench/lane_sum.hip prints what the hardware does).
+__device__ __forceinline__ float sum_lane_bit_4(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float sum_lane_bit_5(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float sum_lane_bits_345(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));       // row_ror:8
+    return sum_lane_bit_5(sum_lane_bit_4(x));
+}
 template <int BM, int BN, int WM, int WN, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const Geo g) {
     constexpr int NT = 64 * WM * WN;
@@ -649,6 +668,18 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
                 }
         __syncthreads();
         if (!res_early) { if (d.res_up) load_res_up(); else load_res(); }
+        // BatchNorm reductions in the epilogue (vpho_conv_desc.stats / bn_x): a thread's items all lie in ONE channel quad (NT % V_PER_ROW == 0),
+        // so its share of the column sums stays in two registers quads until the tile is out
+        static_assert(NT % V_PER_ROW == 0 && NT >= 2 * BN, "stats layout");
+        f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bn_m = st0, bn_i = st0, bn_g = st0, bn_b = st0;
+        if (d.bn_x) {
+            const int c = n0 + 4 * (tid % V_PER_ROW);
+            if (c < d.Cout) {
+                bn_m = *reinterpret_cast<const f32x4*>(d.bn_mean + c); bn_i = *reinterpret_cast<const f32x4*>(d.bn_invstd + c);
+                if (!d.gate) { bn_g = *reinterpret_cast<const f32x4*>(d.bn_gamma + c); bn_b = *reinterpret_cast<const f32x4*>(d.bn_beta + c); }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             long long yoff, ro;
@@ -666,7 +697,49 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = gt[k] > 0.f ? o[k] : o[k] * d.gate_slope;
             }
+            if (d.bn_x) {
+                // the gate from the BatchNorm INPUT: t = the forward pass's own expression (bn_apply_kernel, train_score.hip: the same bits,
+                // hence the same sign as the stored activation); sums of dy and dy * xhat for d beta / d gamma
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(d.bn_x + yoff);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - bn_m[k]) * bn_i[k];
+                    if (!d.gate) {                                   // (with a stored gate -- residual blocks -- the sign came from it above)
+                        const float t = xh * bn_g[k] + bn_b[k];
+                        o[k] = t > 0.f ? o[k] : o[k] * d.gate_slope;
+                    }
+                    st0[k] += o[k]; st1[k] += o[k] * xh;
+                }
+            } else if (d.stats) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { st0[k] += o[k]; st1[k] += o[k] * o[k]; }
+            }
             *reinterpret_cast<f32x4*>(d.y + yoff) = o;
+        }
+        if (d.stats) {
+            // a wave's lanes with the same channel quad (lane bits >= log2 V_PER_ROW) are added on the vector ALU, the waves' sums in a fixed
+            // order through LDS; one partial row per M-tile: [tile_m][2][Cout]
+            static_assert(V_PER_ROW == 16 || V_PER_ROW == 32, "lane layout of the epilogue items");
+            constexpr int NWAVES = NT / 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (V_PER_ROW == 16) { st0[k] = sum_lane_bit_4(st0[k]); st1[k] = sum_lane_bit_4(st1[k]); }
+                st0[k] = sum_lane_bit_5(st0[k]); st1[k] = sum_lane_bit_5(st1[k]);
+            }
+            __syncthreads();                                        // every thread has read its items of Cs
+            float* R = smem;                                        // [wave][2][BN]
+            if (lane < V_PER_ROW) {
+                *reinterpret_cast<f32x4*>(R + (wave * 2 + 0) * BN + 4 * lane) = st0;
+                *reinterpret_cast<f32x4*>(R + (wave * 2 + 1) * BN + 4 * lane) = st1;
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int pl = tid / BN, c = tid - pl * BN;
+                float t = R[pl * BN + c];
+#pragma unroll
+                for (int k = 1; k < NWAVES; ++k) t += R[(k * 2 + pl) * BN + c];
+                if (n0 + c < d.Cout) d.stats[((long long)tile_m * 2 + pl) * d.Cout + n0 + c] = t;
+            }
         }
         VPHO_STAMP_AT(4);
         VPHO_STAMP_WRITE(conv, blockIdx.x);
@@ -713,8 +786,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_glds_kernel(const 
 // Served: Cin % 32 == 0, 1x1, unpadded, 16-byte epilogue, optional bias / residual / second input (x2); no pixel list, no up-sampled
 // residual, no gate, no splits, no prologue -- everything else stays on conv_igemm_glds_kernel.
 #define VPHO_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const Geo g) {
+template <int BM, int BN, int WM, int WN, bool STATS>
+__device__ __forceinline__ void conv_pers_body(const Geo& g) {
     constexpr int NT = 64 * WM * WN, NW = WM * WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int ROWS = NT / 8;
@@ -856,6 +929,26 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         }
     };
 
+    // ---- BatchNorm reductions (vpho_conv_desc.stats, forward form): a wave leaves the column sums of its 32 x 64 block in the first 128
+    // floats of its staging slice at the end of the epilogue; the four row blocks of a column are added -- fixed order -- behind the NEXT
+    // tile's first barrier (or the closing one), so the epilogue stays free of workgroup barriers.  The slice is not written again before
+    // the stage-end barrier of that next tile.  (The store is issued behind the counted wait and is older than everything the next one counts.)
+    // (STATS is a template parameter, conv_igemm_pers_bn_kernel: as a run-time switch its 16 registers cost the inference kernel 7 spills)
+    constexpr bool stats_on = STATS;
+    static_assert(2 * (BN / WN) <= EPI && 2 * BN <= NT, "stats layout");
+    auto flush_stats = [&](int m0_, int n0_) {
+        if (tid < 2 * BN) {
+            const int pl = tid / BN, c = tid - pl * BN;
+            const int wn_c = c / (BN / WN), cc = c - wn_c * (BN / WN);
+            const float* q = smem + 2 * TILE + wn_c * EPI + pl * (BN / WN) + cc;
+            float t = q[0];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) t += q[w * WN * EPI];
+            if (n0_ + c < d.Cout) d.stats[((long long)(m0_ / BM) * 2 + pl) * d.Cout + n0_ + c] = t;
+        }
+    };
+    int pm0 = 0, pn0 = 0;                                           // the tile whose sums wait in the slices
+
     int tp = 0;                                                     // bias slot of the current tile
     setup(m0, n0);
     fill(0, 0, tp);
@@ -868,6 +961,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         if (nk > 1) { if (first) VPHO_WAIT_VM(NF); else VPHO_WAIT_VM(NF + NIT); }
         else        { if (first) VPHO_WAIT_VM(0);  else VPHO_WAIT_VM(NIT); }
         VPHO_BARRIER_LDS_ONLY();                                    // (not __syncthreads(): its fence would wait for the previous tile's stores)
+        if (stats_on && !first) flush_stats(pm0, pn0);
         if (first) VPHO_STAMP_AT(2);
         VPHO_PRIO_MAIN();
 #pragma unroll
@@ -914,6 +1008,9 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
         }
         // ---- epilogue through the wave's own LDS slice: no workgroup barrier (the LDS operations of one wave execute in order)
         const float* Bq = smem + 2 * TILE + NW * EPI + etp * BN + wn * (BN / WN) + ec;
+        f32x4 st0[TN], st1[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { st0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; st1[j] = st0[j]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -931,13 +1028,34 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const float t = v[k] + bq[k] + r[k]; o[k] = t > 0.f ? t : t * d.out_slope; }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yr, yo, 0, 0);
+                    if (stats_on) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const float u = yo != -1 ? o[k] : 0.f; st0[j][k] += u; st1[j][k] += u * u; }     // dead rows / columns: nothing
+                    }
                 }
+        if (stats_on) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { st0[j][k] = sum_lane_bits_345(st0[j][k]); st1[j][k] = sum_lane_bits_345(st1[j][k]); }
+                if (lane < 8) {                                     // behind the last pass's read of the slice (one wave's LDS operations execute in order)
+                    *reinterpret_cast<f32x4*>(Cw + j * 32 + ec) = st0[j];
+                    *reinterpret_cast<f32x4*>(Cw + (BN / WN) + j * 32 + ec) = st1[j];
+                }
+            }
+            pm0 = em0; pn0 = en0;
+        }
         if (first) { VPHO_STAMP_AT(4); }
         first = false;
         if (!more) break;
     }
+    if (stats_on) { VPHO_BARRIER_LDS_ONLY(); flush_stats(pm0, pn0); }
     VPHO_STAMP_WRITE(conv, blockIdx.x);
 }
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_kernel(const Geo g) { conv_pers_body<BM, BN, WM, WN, false>(g); }
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 4) void conv_igemm_pers_bn_kernel(const Geo g) { conv_pers_body<BM, BN, WM, WN, true>(g); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Opt-in split-bf16 variant of the direct-to-LDS kernel (vpho_conv_desc.w_planes / plane_terms; VPHO_CONV_MFMA=bf16x6|bf16x9 in the
@@ -1248,6 +1366,16 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         VPHO_REQUIRE(4.0 * d.N * d.ru_H * d.ru_W * (double)d.ru_ld < 3.9e9, "vpho_conv2d_nhwc_f32: res_up map too large");
     }
     hipStream_t s = (hipStream_t)stream;
+    // BatchNorm reductions in the epilogue (ABI 12): the direct-to-LDS kernels' 16-byte epilogue, one partial row per M-tile
+    if (d.stats_rows) *d.stats_rows = 0;
+    const bool stats_shape = g.vec_epilogue && splits == 1 && groups == 1 && !d.row_map && !d.w_planes && (d.in_scale == nullptr);
+    if (d.bn_x) {
+        VPHO_REQUIRE(d.stats && d.stats_rows && d.bn_mean && d.bn_invstd && (d.gate || (d.bn_gamma && d.bn_beta)),
+                     "vpho_conv2d_nhwc_f32: bn_x needs stats, stats_rows, mean / invstd and -- without a stored gate -- gamma / beta");
+        VPHO_REQUIRE(stats_shape && al16(d.bn_x) && al16(d.bn_mean) && al16(d.bn_invstd) && (d.gate || (al16(d.bn_gamma) && al16(d.bn_beta))),
+                     "vpho_conv2d_nhwc_f32: bn_x is served by the direct-to-LDS 16-byte epilogue only (Cout %% 4 == 0, aligned, no splits / groups / pixel list / prologue / planes)");
+    }
+    VPHO_REQUIRE(!d.stats || (d.stats_rows && d.stats_cap > 0 && al16(d.stats)), "vpho_conv2d_nhwc_f32: stats needs stats_rows (host) and stats_cap");
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128) * ny;
     const double m_acc = (d.row_map && d.rows_hint > 0) ? (double)d.rows_hint : (double)M;   // rows the launch really computes
     const double flops = 2.0 * m_acc * d.Cout * g.K * ny;
@@ -1261,10 +1389,16 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     if (big_tiles >= 256 && d.Cout % 128 == 0) variant = 1288;
     else if (tiles_12864 >= 256 && d.Cout >= 48) variant = 12864;
     if (force_tile) variant = force_tile;
+    bool stats_kernel = false, stats_failed = false;               // stats_kernel: the switch below launches conv_igemm_glds_kernel
     auto launch = [&](auto kernel, int bm, int bn, int threads, int cls) {
         vpho::ProfScope prof(cls, s, flops, bytes);
         g.tiles_m = (int)((M + bm - 1) / bm); g.tiles_n = (d.Cout + bn - 1) / bn;
         g.ntiles = g.tiles_m * g.tiles_n;
+        if (d.stats) {
+            const bool on = stats_kernel && stats_shape && g.tiles_m <= d.stats_cap;
+            if (on) *d.stats_rows = g.tiles_m;
+            else { g.d.stats = nullptr; if (d.bn_x) { stats_failed = true; return; } }     // never drop the gate silently
+        }
         hipLaunchKernelGGL(kernel, dim3((g.ntiles + 7) / 8 * 8, ny), dim3(threads), 0, s, g);
     };
     static const int no_glds = getenv("VPHO_CONV_NO_GLDS") ? atoi(getenv("VPHO_CONV_NO_GLDS")) : 0;   // tuning aid
@@ -1279,7 +1413,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
     // a pre-activation prologue rides on the direct-to-LDS kernel when the fragment's k is a plain channel index (1x1, unpadded,
     // Cin a multiple of 32 and within the LDS table); everything else with a prologue takes the register-staged kernel
     const bool pre_on_read = d.in_scale != nullptr && g.uni && d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0 && d.Cin <= GLDS_PRE_MAX;
-    const bool glds = (d.in_scale == nullptr || pre_on_read) && (!no_glds || d.res_up != nullptr || d.x2 != nullptr);
+    const bool glds = (d.in_scale == nullptr || pre_on_read) && (!no_glds || d.res_up != nullptr || d.x2 != nullptr || d.bn_x != nullptr);
+    stats_kernel = glds && variant != 128;
     VPHO_REQUIRE(!d.x2 || (g.uni && variant != 128), "vpho_conv2d_nhwc_f32: x2 is served by the direct-to-LDS kernels with wave-uniform taps only");
     VPHO_REQUIRE(!d.res_up || variant != 128, "vpho_conv2d_nhwc_f32: res_up is not served by the forced register-staged tile");
     // opt-in split-bf16 products (never the default): shapes the split kernel takes, everything else stays on the fp32 kernels
@@ -1322,14 +1457,18 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
         const double r_extent = d.res ? 4.0 * ((double)(d.N - 1) * d.r_sn + (double)(d.OH - 1) * d.r_sy + (double)(d.OW - 1) * d.r_sx + d.Cout) : 0.0;
         const bool simple = d.KH == 1 && d.KW == 1 && d.pad_y == 0 && d.pad_x == 0;
         const bool ok = pers && variant == 1288 && glds && !pre_on_read && d.in_scale == nullptr && g.uni && simple && g.vec_epilogue && !d.row_map && !d.res_up &&
-                        !d.gate && splits == 1 && y_extent < 3.9e9 && r_extent < 3.9e9 && d.y_sn >= 0 && d.y_sy >= 0 && d.y_sx >= 0 &&
+                        !d.gate && !d.bn_x && splits == 1 && y_extent < 3.9e9 && r_extent < 3.9e9 && d.y_sn >= 0 && d.y_sy >= 0 && d.y_sx >= 0 &&
                         (!d.x2 || 4.0 * d.N * d.H2 * d.W2 * (double)d.x2_ld < 3.9e9);
         if (ok && (big_tiles > slots || pers >= 2)) {
             vpho::ProfScope prof(vpho::PROF_CONV128, s, flops, bytes);
             g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (d.Cout + 127) / 128;
             g.ntiles = g.tiles_m * g.tiles_n;
+            if (d.stats) {
+                if (stats_shape && g.tiles_m <= d.stats_cap) *d.stats_rows = g.tiles_m; else g.d.stats = nullptr;
+            }
             const int grid = (int)std::min<long long>((g.ntiles + 7) / 8 * 8, std::max(8, slots / groups / 8 * 8));      // the groups share the slots
-            hipLaunchKernelGGL((conv_igemm_pers_kernel<128, 128, 4, 2>), dim3(grid, groups), dim3(512), 0, s, g);
+            if (g.d.stats) hipLaunchKernelGGL((conv_igemm_pers_bn_kernel<128, 128, 4, 2>), dim3(grid, groups), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((conv_igemm_pers_kernel<128, 128, 4, 2>), dim3(grid, groups), dim3(512), 0, s, g);
             return vpho::check_launch("conv_igemm_pers_kernel");
         }
     }
@@ -1351,5 +1490,8 @@ extern "C" int vpho_conv2d_nhwc_f32(const vpho_conv_desc* dp, void* stream) {
             else      launch(conv_igemm_kernel<64, 64, 2, 2, 1>, 64, 64, 256, vpho::PROF_CONV64);
             break;
     }
+    if (stats_failed)
+        return vpho::fail("vpho_conv2d_nhwc_f32: bn_x: the launch needs %d partial rows (stats_cap %d) or runs a kernel without the BatchNorm epilogue (tile %d)",
+                          g.tiles_m, d.stats_cap, variant);
     return vpho::check_launch("conv_igemm_kernel");
 }

@@ -55,12 +55,16 @@ struct WinoArgs {
     int scatter;                               // with wins: 1 = y is the ordinary (N,H,W,y_ld) map, window pixels written in place, the rest untouched
     // grouped launch (blockIdx.y = group: the twin hand / object branches): the same problem on x + g*x_gs, u + g*u_gs, bias + g*b_gs, y + g*y_gs
     long long x_gs, u_gs, b_gs, y_gs;
+    // conv_winograd_bn_kernel only (ABI 12): BatchNorm reductions in the epilogue, see vpho_conv_desc.stats / bn_x
+    float* stats; const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
 };
 __device__ __forceinline__ WinoArgs wino_group(WinoArgs a, const unsigned g) {
     a.x += g * a.x_gs; a.u += g * a.u_gs; a.y += g * a.y_gs;
     if (a.bias) a.bias += g * a.b_gs;
     return a;
 }
+
+struct WinoBn { float* stats; int cap; int* rows; const float* x; const float* mean; const float* invstd; const float* gamma; const float* beta; };
 
 // tile t -> image n, tile coordinates (ty, tx) on the image's even grid; false past the last live tile
 __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int& tx) {
@@ -91,8 +95,10 @@ __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int&
 // ds_read_b128 just before it needs it -- so one 64-register patch set is enough (the second one was there to cover HBM latency).
 // MODE 0: patches through registers; 1: staged, regular blocks (full maps); 2: RoI-window launches -- a block of the live-tile list is staged
 // when its 64 tiles are live, lie in one image and their bounding pixel region fits IN (decided per workgroup: both loops are in the kernel).
-template <int MODE>
-__global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) {
+// BN (conv_winograd_bn_kernel, training): the reductions of the BatchNorm next to the convolution in the epilogue -- WinoArgs.stats / bn_x,
+// the same contract as vpho_conv_desc.stats / bn_x (include/vpho_hip.h); the inference kernels are the BN = false instantiations.
+template <int MODE, bool BN>
+__device__ __forceinline__ void wino_body(const WinoArgs& a_) {
     const WinoArgs a = wino_group(a_, blockIdx.y);
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     VPHO_STAMP_INIT();
@@ -402,6 +408,11 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) {
         const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         pm_e[e] = s_pitch[trow]; row_e[e] = s_row[trow];
     }
+    // BN: a lane owns one output channel and 16 tiles x 4 pixels of it -- its share of the column sums is two registers
+    float st0 = 0.f, st1 = 0.f, bn_m = 0.f, bn_i = 0.f, bn_g = 0.f, bn_b = 0.f;
+    if constexpr (BN) {
+        if (a.bn_x) { bn_m = a.bn_mean[co]; bn_i = a.bn_invstd[co]; bn_g = a.bn_gamma[co]; bn_b = a.bn_beta[co]; }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         float s0[4], s1[4];
@@ -419,18 +430,50 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) {
             const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
             const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
             const float* gp = a.gate ? a.gate + (long long)row_e[e] * a.y_ld + co : nullptr;
+            const float* xp = nullptr;
+            if constexpr (BN) { if (a.bn_x) xp = a.bn_x + (long long)row_e[e] * a.y_ld + co; }
 #pragma unroll
             for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
                 float v = o[p];
                 if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
                 if ((WINO_ABLATE & 512) && v != 1.2345e-30f) continue;          // timing: the output transform without its stores
+                if constexpr (BN) {
+                    if (xp) {
+                        // gate recomputed from the BatchNorm input: the forward pass's own expression (bn_apply_kernel), hence its sign
+                        const float xh = (xp[offs[p]] - bn_m) * bn_i;
+                        const float t = xh * bn_g + bn_b;
+                        v = t > 0.f ? v : v * a.gate_slope;
+                        st0 += v; st1 += v * xh;
+                        yp[offs[p]] = v;
+                        continue;
+                    }
+                    v = v > 0.f ? v : v * a.out_slope;
+                    st0 += v; st1 += v * v;
+                    yp[offs[p]] = v;
+                    continue;
+                }
                 yp[offs[p]] = v > 0.f ? v : v * a.out_slope;
             }
+        }
+    }
+    if constexpr (BN) {
+        // lanes li / li + 32 hold the two row halves of a channel, the waves wt = 0 / 1 the two tile halves: one partial row per tile
+        // block, [tb][2][Cout], combined in a fixed order (the stage buffers are free: every wave has passed the last stage's barrier)
+        st0 += __shfl_xor(st0, 32); st1 += __shfl_xor(st1, 32);
+        if (lh == 0) { smem[(wt * 2 + 0) * W_CB + wc * 32 + li] = st0; smem[(wt * 2 + 1) * W_CB + wc * 32 + li] = st1; }
+        __syncthreads();
+        if (tid < 2 * W_CB) {
+            const int pl = tid / W_CB, c = tid - pl * W_CB;
+            a.stats[((long long)tb * 2 + pl) * a.Cout + c0 + c] = smem[pl * W_CB + c] + smem[(2 + pl) * W_CB + c];
         }
     }
     VPHO_STAMP_AT(4);
     VPHO_STAMP_WRITE(wino, blockIdx.x);
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) { wino_body<MODE, false>(a_); }
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_winograd_bn_kernel(const WinoArgs a_) { wino_body<MODE, true>(a_); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -667,7 +710,8 @@ __global__ void wino_tile_base_kernel(const int* __restrict__ wins, int N, int* 
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
                        const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
-                       const float* gate = nullptr, float gate_slope = 1.f, int scatter = 0, int groups = 1, long long x_group = 0);
+                       const float* gate = nullptr, float gate_slope = 1.f, int scatter = 0, int groups = 1, long long x_group = 0,
+                       const struct WinoBn* bn = nullptr);
 
 // U = G g G^T on the DEVICE for weights that change every step (training): one thread per (output channel, input channel) pair of the
 // convolution the result is for.  mode 0: that convolution is the forward one (w packed as [Cout][(r*3+s)*Cin + ci]); mode 1: its
@@ -750,6 +794,18 @@ extern "C" int vpho_conv3x3_winograd_gate_nhwc_f32(const float* x, const float* 
     return wino_launch(x, u, nullptr, N, H, W, Cin, x_ld, Cout, 1.f, nullptr, nullptr, 0, y, y_ld, stream, gate, gate_slope);
 }
 
+extern "C" int vpho_conv3x3_winograd_stats_nhwc_f32(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout,
+                                                    float out_slope, float* y, int y_ld, float* stats, int stats_cap, int* stats_rows, const float* bn_x,
+                                                    const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                                    float gate_slope, void* stream) {
+    VPHO_REQUIRE(stats && stats_rows && stats_cap > 0, "vpho_conv3x3_winograd_stats_nhwc_f32: bad argument");
+    *stats_rows = 0;
+    const char* w8 = getenv("VPHO_WINO8");
+    VPHO_REQUIRE(!(w8 && atoi(w8) != 0), "vpho_conv3x3_winograd_stats_nhwc_f32: not served by the 8-wave kernel (VPHO_WINO8)");
+    const WinoBn bn{stats, stats_cap, stats_rows, bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta};
+    return wino_launch(x, u, bias, N, H, W, Cin, x_ld, Cout, out_slope, nullptr, nullptr, 0, y, y_ld, stream, nullptr, gate_slope, 0, 1, 0, &bn);
+}
+
 extern "C" int vpho_winograd_weights_f32(const float* w_packed, int Cout, int Cin, int for_input_gradient, float* u, void* stream) {
     VPHO_REQUIRE(w_packed && u && Cout > 0 && Cin > 0, "vpho_winograd_weights_f32: bad argument");
     VPHO_REQUIRE((for_input_gradient ? Cout : Cin) % 16 == 0, "vpho_winograd_weights_f32: the convolution's input channels must be a multiple of 16");
@@ -767,7 +823,7 @@ extern "C" int vpho_winograd_weights_multi_f32(const void* segments, int n_segme
 
 static int wino_launch(const float* x, const float* u, const float* bias, int N, int H, int W, int Cin, int x_ld, int Cout, float out_slope,
                        const int* wins, const int* tile_base, int tiles_hint, float* y, int y_ld, void* stream,
-                       const float* gate, float gate_slope, int scatter, int groups, long long x_group) {
+                       const float* gate, float gate_slope, int scatter, int groups, long long x_group, const WinoBn* bn) {
     VPHO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vpho_conv3x3_winograd_nhwc_f32: bad argument");
     VPHO_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % (2 * WK) == 0 && Cout % W_CB == 0 && x_ld % 4 == 0 && x_ld >= Cin && y_ld >= Cout,
                  "vpho_conv3x3_winograd_nhwc_f32: needs even H, W, Cin %% 16 == 0, Cout %% 64 == 0, x_ld %% 4 == 0");
@@ -781,6 +837,7 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
     VPHO_REQUIRE(groups >= 1 && (groups == 1 || (!wins && !gate && x_group >= 0 && x_group % 4 == 0)), "vpho_conv3x3_winograd_nhwc_f32: grouped launches take no windows / gate");
     a.x_gs = groups > 1 ? x_group : 0; a.u_gs = groups > 1 ? 16ll * Cout * Cin : 0; a.b_gs = groups > 1 ? Cout : 0;
     a.y_gs = groups > 1 ? (long long)N * H * W * y_ld : 0;
+    a.stats = nullptr; a.bn_x = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
     const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
     const size_t lds_staged = lds + (size_t)W_IN_PIXELS * 64;
     VPHO_DYN_LDS(conv_winograd_kernel<0>, lds);
@@ -808,6 +865,23 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
         // bit-identity test; read per call)
         const char* st = getenv("VPHO_WINO_STAGED");
         const bool staged = st ? atoi(st) != 0 : true;
+        if (bn) {
+            // training: BatchNorm reductions in the epilogue, one partial row per tile block (full maps only)
+            VPHO_REQUIRE(bn->stats && bn->rows && !wins && !gate && groups == 1 && ((uintptr_t)bn->stats & 15) == 0,
+                         "vpho_conv3x3_winograd_stats_nhwc_f32: full maps, one group, no stored gate");
+            VPHO_REQUIRE(tbs <= bn->cap, "vpho_conv3x3_winograd_stats_nhwc_f32: %d partial rows exceed stats_cap %d", tbs, bn->cap);
+            VPHO_REQUIRE(!bn->x || (bn->mean && bn->invstd && bn->gamma && bn->beta), "vpho_conv3x3_winograd_stats_nhwc_f32: bn_x needs the four BatchNorm vectors");
+            a.stats = bn->stats; a.bn_x = bn->x; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+            *bn->rows = tbs;
+            if (staged && wino_staged_ok(a.TH, a.TW, W)) {
+                VPHO_DYN_LDS(conv_winograd_bn_kernel<1>, lds_staged);
+                hipLaunchKernelGGL(conv_winograd_bn_kernel<1>, dim3(blocks, 1), dim3(256), lds_staged, (hipStream_t)stream, a);
+            } else {
+                VPHO_DYN_LDS(conv_winograd_bn_kernel<0>, lds);
+                hipLaunchKernelGGL(conv_winograd_bn_kernel<0>, dim3(blocks, 1), dim3(256), lds, (hipStream_t)stream, a);
+            }
+            return vpho::check_launch("conv_winograd_bn_kernel");
+        }
         // (Round 6, built and NOT kept: a persistent tile walk like conv_igemm_pers_kernel's -- the last super-stage of a tile prepares pixels, V and U of
         // the next tile's first stage, the epilogue runs with them in LDS -- bit-identical, and 1-6 % SLOWER on seven of nine layers (64 x 64 x 64 images
         // 256 -> 256: 1 233 against 1 220 us; 64 x 32 x 32 128 -> 128: 95.8 against 90.0), +1 % on two; docs/LOG.md round 6.  The one-tile kernel's

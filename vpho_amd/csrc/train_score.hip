@@ -298,28 +298,31 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const BnRedArgs a) {
         }
     }
 }
-// sum over the row chunks of one or two partial-sum planes: block = 32 channels x 8 chunk groups (chunks g, g+8, ... per thread,
-// the 8 group sums combined in a fixed order); the result is valid in the threads with g == 0
-template <int PLANES>
-__device__ inline bool finish_sums(const double* __restrict__ part, int chunks, int C, int& c, double& s0, double& s1) {
-    __shared__ double q0[8][32], q1[8][32];
+// sum over the row chunks of one or two partial-sum planes (double: the chunks of col_reduce_kernel; float: the per-tile partial sums a
+// convolution's epilogue wrote, vpho_conv_desc.stats): block = 32 channels x 32 chunk groups (chunks g, g+32, ... per thread, the 32
+// group sums combined in a fixed order); the result is valid in the threads with g == 0.  (Round 6: 8 groups -> 32: a finishing kernel is
+// one short chain of dependent loads per thread, and a training step runs ~370 of them back to back with their consumers.)
+constexpr int FIN_G = 32;
+template <int PLANES, typename T>
+__device__ inline bool finish_sums(const T* __restrict__ part, int chunks, int C, int& c, double& s0, double& s1) {
+    __shared__ double q0[FIN_G][32], q1[FIN_G][32];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     c = blockIdx.x * 32 + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
-        for (int k = g; k < chunks; k += 8) {
-            a0 += part[((long long)k * PLANES) * C + c];
-            if (PLANES == 2) a1 += part[((long long)k * PLANES + 1) * C + c];
+        for (int k = g; k < chunks; k += FIN_G) {
+            a0 += (double)part[((long long)k * PLANES) * C + c];
+            if (PLANES == 2) a1 += (double)part[((long long)k * PLANES + 1) * C + c];
         }
     }
     q0[g][cl] = a0; q1[g][cl] = a1;
     __syncthreads();
     if (g != 0 || c >= C) return false;
     s0 = q0[0][cl]; s1 = q1[0][cl];
-    for (int k = 1; k < 8; ++k) { s0 += q0[k][cl]; s1 += q1[k][cl]; }
+    for (int k = 1; k < FIN_G; ++k) { s0 += q0[k][cl]; s1 += q1[k][cl]; }
     return true;
 }
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(32 * FIN_G) void colsum_finish_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ out) {
     int c; double s, unused;
     if (finish_sums<1>(part, chunks, C, c, s, unused)) out[c] = (float)s;
 }
@@ -346,7 +349,8 @@ int launch_col_reduce(BnRedArgs a, hipStream_t s) {
     return chunks;
 }
 // statistics: mean, biased variance -> invstd = 1/sqrt(var + eps); running stats with the unbiased variance (torch semantics)
-__global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
+template <typename T>
+__global__ __launch_bounds__(32 * FIN_G) void bn_finish_stats_kernel(const T* __restrict__ part, int chunks, int C, long long rows, float eps, float momentum,
                                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var) {
     int c; double s, ss;
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __re
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
 }
-__global__ __launch_bounds__(256) void bn_finish_grads_kernel(const double* __restrict__ part, int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+template <typename T>
+__global__ __launch_bounds__(32 * FIN_G) void bn_finish_grads_kernel(const T* __restrict__ part, int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
     int c; double s, ss;
     if (finish_sums<2>(part, chunks, C, c, s, ss)) { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
 }
@@ -820,7 +825,7 @@ extern "C" int vpho_colsum_f32(const float* x, int ld, long long rows, int cols,
     VPHO_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "vpho_colsum_f32: bad argument");
     BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, cols, ld, 2, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, (hipStream_t)stream);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 32)), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(cols, 32)), dim3(32 * FIN_G), 0, (hipStream_t)stream, (const double*)workspace, chunks, cols, out);
     return vpho::check_launch("colsum kernels");
 }
 
@@ -869,6 +874,43 @@ extern "C" int vpho_im2col_t_f32(const float* x, int N, int H, int W, int Cin, i
 
 extern "C" long long vpho_bn_workspace_bytes(int C) { return C > 0 ? (long long)256 * 2 * C * 8 : -1; }
 
+// the statistics of a [rows][C] matrix from partial sums: double chunks of col_reduce_kernel, or the float partial rows of a convolution's
+// epilogue -- finished directly when there are few, through one column reduction of the partial matrix itself (1/64 ... 1/256 of the data) first
+static const void* reduce_partials(const float* stats, int P, int C, void* workspace, hipStream_t s, int* chunks, bool* is_double) {
+    if (P <= 256) { *chunks = P; *is_double = false; return stats; }
+    BnRedArgs ra{stats, nullptr, nullptr, nullptr, P, 2 * C, 2 * C, 2, 0, (double*)workspace};      // [P][2C] -> [chunks][2C] doubles = [chunks][2][C]
+    *chunks = launch_col_reduce(ra, s);
+    *is_double = true;
+    return workspace;
+}
+static int bn_forward_tail(const float* x, long long rows, int C, int ld, const void* part, int chunks, bool part_double, const float* gamma, const float* beta,
+                           float eps, float momentum, float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                           const float* res, float* y, hipStream_t s) {
+    if (part_double)
+        hipLaunchKernelGGL(bn_finish_stats_kernel<double>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const double*)part, chunks, C, rows, eps, momentum, save_mean, save_invstd,
+                           running_mean, running_var);
+    else
+        hipLaunchKernelGGL(bn_finish_stats_kernel<float>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const float*)part, chunks, C, rows, eps, momentum, save_mean, save_invstd,
+                           running_mean, running_var);
+    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd) &&
+        (!res || aligned16(res)))
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
+    return vpho::check_launch("bn_train_forward kernels");
+}
+static int bn_backward_tail(const float* x, const float* dy, long long rows, int C, int ld, const void* part, int chunks, bool part_double, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+    if (part_double) hipLaunchKernelGGL(bn_finish_grads_kernel<double>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const double*)part, chunks, C, dbeta, dgamma);
+    else hipLaunchKernelGGL(bn_finish_grads_kernel<float>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const float*)part, chunks, C, dbeta, dgamma);
+    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
+        aligned16(dbeta) && aligned16(dgamma))
+        hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
+    else
+        hipLaunchKernelGGL(bn_backward_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
+    return vpho::check_launch("bn_train_backward kernels");
+}
+
 extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, int ld, const float* gamma, const float* beta, float eps, float momentum,
                                          float slope, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* res,
                                          float* y, void* workspace, void* stream) {
@@ -877,14 +919,19 @@ extern "C" int vpho_bn_train_forward_f32(const float* x, long long rows, int C, 
     hipStream_t s = (hipStream_t)stream;
     BnRedArgs ra{x, nullptr, nullptr, nullptr, rows, C, ld, 0, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, s);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, rows, eps, momentum, save_mean, save_invstd,
-                       running_mean, running_var);
-    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(save_mean) && aligned16(save_invstd) &&
-        (!res || aligned16(res)))
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, (const float*)save_mean, (const float*)save_invstd, gamma, beta, res, rows, C, ld, slope, y);
-    return vpho::check_launch("bn_train_forward kernels");
+    return bn_forward_tail(x, rows, C, ld, workspace, chunks, true, gamma, beta, eps, momentum, slope, running_mean, running_var, save_mean, save_invstd, res, y, s);
+}
+
+extern "C" int vpho_bn_train_forward_stats_f32(const float* x, long long rows, int C, int ld, const float* stats, int stats_rows, const float* gamma,
+                                               const float* beta, float eps, float momentum, float slope, float* running_mean, float* running_var,
+                                               float* save_mean, float* save_invstd, const float* res, float* y, void* workspace, void* stream) {
+    VPHO_REQUIRE(x && stats && stats_rows > 0 && gamma && beta && save_mean && save_invstd && y && workspace && rows > 0 && C > 0 && ld >= C,
+                 "vpho_bn_train_forward_stats_f32: bad argument");
+    VPHO_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "vpho_bn_train_forward_stats_f32: running_mean/var must come together");
+    hipStream_t s = (hipStream_t)stream;
+    int chunks; bool dbl;
+    const void* part = reduce_partials(stats, stats_rows, C, workspace, s, &chunks, &dbl);
+    return bn_forward_tail(x, rows, C, ld, part, chunks, dbl, gamma, beta, eps, momentum, slope, running_mean, running_var, save_mean, save_invstd, res, y, s);
 }
 
 extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
@@ -893,13 +940,18 @@ extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long 
     hipStream_t s = (hipStream_t)stream;
     BnRedArgs ra{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace};
     const int chunks = launch_col_reduce(ra, s);
-    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(nblk(C, 32)), dim3(256), 0, s, (const double*)workspace, chunks, C, dbeta, dgamma);
-    if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
-        aligned16(dbeta) && aligned16(dgamma))
-        hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
-    else
-        hipLaunchKernelGGL(bn_backward_kernel<1>, dim3(nblk(rows * C)), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
-    return vpho::check_launch("bn_train_backward kernels");
+    return bn_backward_tail(x, dy, rows, C, ld, workspace, chunks, true, gamma, save_mean, save_invstd, dx, dgamma, dbeta, s);
+}
+
+extern "C" int vpho_bn_train_backward_stats_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
+                                                const float* save_invstd, const float* stats, int stats_rows, float* dx, float* dgamma, float* dbeta,
+                                                void* workspace, void* stream) {
+    VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && stats && stats_rows > 0 && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C,
+                 "vpho_bn_train_backward_stats_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int chunks; bool dbl;
+    const void* part = reduce_partials(stats, stats_rows, C, workspace, s, &chunks, &dbl);
+    return bn_backward_tail(x, dy, rows, C, ld, part, chunks, dbl, gamma, save_mean, save_invstd, dx, dgamma, dbeta, s);
 }
 
 extern "C" int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream) {

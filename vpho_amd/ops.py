@@ -17,7 +17,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 lib.vpho_last_error.restype = C.c_char_p
 lib.vpho_abi_version.restype = C.c_int
-ABI_VERSION = 11                        # include/vpho_hip.h; a stale library must not be found out by a missing symbol halfway through a run
+ABI_VERSION = 12                        # include/vpho_hip.h; a stale library must not be found out by a missing symbol halfway through a run
 if lib.vpho_abi_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} implements ABI version {lib.vpho_abi_version()}, this binding expects {ABI_VERSION}: rebuild the '
                       f'extension (python -m vpho_amd.build --force)')
@@ -69,7 +69,9 @@ class ConvDesc(C.Structure):
                 ('res_up', C.c_void_p), ('ru_H', C.c_int), ('ru_W', C.c_int), ('ru_ld', C.c_int),
                 ('x2', C.c_void_p), ('Cin2', C.c_int), ('x2_ld', C.c_int), ('stride2', C.c_int), ('H2', C.c_int), ('W2', C.c_int),
                 ('groups', C.c_int), ('x_group', C.c_longlong), ('w_group', C.c_longlong), ('bias_group', C.c_longlong), ('y_group', C.c_longlong),
-                ('res_group', C.c_longlong), ('x2_group', C.c_longlong), ('pre_group', C.c_longlong), ('ru_group', C.c_longlong)]
+                ('res_group', C.c_longlong), ('x2_group', C.c_longlong), ('pre_group', C.c_longlong), ('ru_group', C.c_longlong),
+                ('stats', C.c_void_p), ('stats_rows', C.c_void_p), ('stats_cap', C.c_int),
+                ('bn_x', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_invstd', C.c_void_p), ('bn_gamma', C.c_void_p), ('bn_beta', C.c_void_p)]
 
 
 lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
@@ -77,6 +79,28 @@ lib.vpho_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
 
 def _addr(t):
     return None if t is None else t.data_ptr()
+
+
+FUSE_BN = os.environ.get('VPHO_TRAIN_FUSE_BN', '1') != '0'     # A/B aid: 0 = every train-mode BatchNorm runs its own reduction pass
+
+
+class BnFuse:
+    """Carrier of the reductions of a train-mode BatchNorm taken in the epilogue of the convolution next to it (vpho_conv_desc.stats).
+    Forward: ``f = BnFuse(); c = conv2d_nhwc(x, w, bn=f); a, saved = bn_train_forward(c, ..., partials=f)`` -- the convolution leaves the
+    per-tile sums of its output in ``f.stats`` (``f.rows`` partial rows; 0 = the kernel of that shape has no such epilogue and the
+    BatchNorm runs its own pass).  Backward: ``f = BnFuse(c, saved, gamma, beta); da = conv2d_dgrad(dy, w, ..., gate=(a, slope), bn=f)``
+    -- the input-gradient convolution recomputes the activation's sign from the BatchNorm input ``c`` instead of reading the stored
+    activation and leaves sum da | sum da * xhat -- then ``bn_train_backward(c, da, gamma, saved, partials=f)``."""
+    __slots__ = ('stats', 'rows', 'x', 'mean', 'invstd', 'gamma', 'beta', 'stored_gate')
+
+    def __init__(self, x=None, saved=None, gamma=None, beta=None, stored_gate=False):
+        # stored_gate: keep reading the activation's sign from the stored activation (a residual block's closing activation, whose input is
+        # BatchNorm + shortcut) and take only xhat from the BatchNorm input
+        self.stats, self.rows, self.x, self.gamma, self.beta, self.stored_gate = None, 0, x, gamma, beta, stored_gate
+        self.mean, self.invstd = saved if saved is not None else (None, None)
+
+    def live(self):
+        return self.stats is not None and self.rows > 0
 
 
 # Opt-in split-bf16 convolutions (VPHO_CONV_MFMA=bf16x6|bf16x9, inference plan only; default: fp32 MFMA).  The three bf16 planes of
@@ -118,7 +142,7 @@ def _planes_of(w):
 
 def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad_x=None, out=None, out_hw=None,
                 out_view=None, res=None, in_scale=None, in_shift=None, in_slope=1.0, out_slope=1.0, cin=None, split=None, gate=None,
-                rows=None, rows_scatter=False, res_up=None, x2=None, stride2=1, groups=1, x_shared=False, x2_shared=False):
+                rows=None, rows_scatter=False, res_up=None, x2=None, stride2=1, groups=1, x_shared=False, x2_shared=False, bn=None):
     """x: (N,H,W,x_ld) fp32 NHWC, w: (Cout, kh*kw*Cin) packed.  Returns (N,OH,OW,Cout) (or writes ``out``).
     ``groups`` = G > 1: G convolutions of one shape in ONE launch (the twin hand / object branches, vpho_conv_desc.groups): w (G,Cout,K),
     bias (G,Cout), in_scale / in_shift (G,Cin); x, res, x2, res_up and the result hold the groups' images one after the other
@@ -133,7 +157,10 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     destination, slope): y = gate > 0 ? y : slope * y (LeakyReLU backward fused into an input-gradient convolution).
     ``rows`` = a ``RoiWindows``: only the listed output pixels are computed and the result is the COMPACT (N*OH*OW, Cout)
     matrix whose first ``rows.count`` rows are live (``roi_align_nhwc(..., win=rows)`` reads it); with ``rows_scatter`` the listed
-    pixels are written at their own positions of the ordinary (N,OH,OW,Cout) output and the other pixels are left untouched."""
+    pixels are written at their own positions of the ordinary (N,OH,OW,Cout) output and the other pixels are left untouched.
+    ``bn`` = a ``BnFuse``: the reductions of the train-mode BatchNorm next to this convolution in its epilogue (see BnFuse; with
+    ``bn.x`` the gate is recomputed from the BatchNorm input and ``gate`` -- which the caller still passes -- is used only where the
+    fused epilogue does not apply)."""
     N, H, W, x_ld = x.shape
     G = groups
     if G > 1:
@@ -214,7 +241,22 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
     if terms and G == 1 and split is None and in_scale is None and gate is None and res_up is None and x2 is None and cin % 16 == 0 and w.is_contiguous() and w.shape[1] == kh * kw * cin:
         planes = _planes_of(w)                              # kept alive by the cache
         d.w_planes, d.plane_terms = planes.data_ptr(), terms
+    rows_out = None
+    if bn is not None and FUSE_BN and G == 1 and split is None and rows is None and in_scale is None and out_view is None and not d.w_planes and cout % 4 == 0:
+        cap = (N * OH * OW + 63) // 64                          # the smallest M-tile is 64 rows
+        bn.stats = torch.empty((cap, 2, cout), device=x.device, dtype=torch.float32)
+        rows_out = C.c_int(0)
+        d.stats, d.stats_cap, d.stats_rows = bn.stats.data_ptr(), cap, C.cast(C.pointer(rows_out), C.c_void_p)
+        if bn.x is not None:
+            assert gate is not None and bn.x.shape == ret.shape and bn.x.is_contiguous() and ret.is_contiguous()
+            if bn.stored_gate:
+                d.bn_x, d.bn_mean, d.bn_invstd = (_ptr(t, torch.float32).value for t in (bn.x, bn.mean, bn.invstd))
+            else:
+                d.gate, d.gate_slope = None, gate[1]
+                d.bn_x, d.bn_mean, d.bn_invstd, d.bn_gamma, d.bn_beta = (_ptr(t, torch.float32).value for t in (bn.x, bn.mean, bn.invstd, bn.gamma, bn.beta))
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
+    if rows_out is not None:
+        bn.rows = rows_out.value
     return ret
 
 
@@ -336,7 +378,27 @@ def winograd_ok(H, W, cin, cout, x_ld):
 _TRAIN_WINOGRAD = os.environ.get('VPHO_TRAIN_WINOGRAD', '1') != '0'
 
 
-def conv3x3_train(x, w, bias=None, out_slope=1.0, rows=None):
+def _wino8():
+    return os.environ.get('VPHO_WINO8', '0') not in ('0', '')      # the 8-wave experiment kernel has no BatchNorm epilogue (read per call, like the library)
+
+
+def _winograd_bn(x, u, bias, out_slope, cin, cout, bn, gate_slope=1.0):
+    """full-map Winograd convolution with the BatchNorm reductions in its epilogue (vpho_conv3x3_winograd_stats_nhwc_f32)"""
+    N, H, W, x_ld = x.shape
+    out = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    cap = (N * H * W + 255) // 256
+    bn.stats = torch.empty((cap, 2, cout), device=x.device, dtype=torch.float32)
+    rows_out = C.c_int(0)
+    bx = (bn.x, bn.mean, bn.invstd, bn.gamma, bn.beta) if bn.x is not None else (None,) * 5
+    if bn.x is not None:
+        assert bn.x.shape == out.shape and bn.x.is_contiguous()
+    _call('vpho_conv3x3_winograd_stats_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope), _f32(out), I(cout),
+          _f32(bn.stats), I(cap), C.byref(rows_out), *[_f32(t) for t in bx], F(gate_slope))
+    bn.rows = rows_out.value
+    return out
+
+
+def conv3x3_train(x, w, bias=None, out_slope=1.0, rows=None, bn=None):
     """3x3 / stride 1 / pad 1 convolution of the TRAINING path: Winograd F(2x2,3x3) with the weight transform on the device where the
     shape allows, else the direct kernel (VPHO_TRAIN_WINOGRAD=0: always the direct kernel).  ``rows`` (a RoiWindows): the output is
     only ever read inside these windows (RoIAlign), so only their pixels are computed -- in place in the ordinary (N,H,W,Cout) map,
@@ -344,8 +406,10 @@ def conv3x3_train(x, w, bias=None, out_slope=1.0, rows=None):
     N, H, W, x_ld = x.shape
     cout, cin = w.shape[0], w.shape[1] // 9
     if not _TRAIN_WINOGRAD or not winograd_ok(H, W, cin, cout, x_ld) or w.shape[1] != 9 * cin:
-        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope)
+        return conv2d_nhwc(x, w, bias, kh=3, kw=3, pad=1, out_slope=out_slope, bn=bn)
     u = winograd_weights_device(w)
+    if bn is not None and FUSE_BN and rows is None and not _wino8():
+        return _winograd_bn(x, u, bias, out_slope, cin, cout, bn)
     if rows is not None:
         assert rows.shape == (N, H, W)
         out = torch.zeros((N, H, W, cout), device=x.device, dtype=torch.float32)
@@ -355,7 +419,7 @@ def conv3x3_train(x, w, bias=None, out_slope=1.0, rows=None):
     return conv3x3_winograd(x, u, bias, out_slope)
 
 
-def conv3x3_dgrad_winograd(dy, w, gate=None, rows=None):
+def conv3x3_dgrad_winograd(dy, w, gate=None, rows=None, bn=None):
     """input gradient of a 3x3 / stride 1 / pad 1 convolution with packed weights w (Cout, 9*Cin): dX = conv3x3(dY, flipped / transposed
     w), optionally through the backward of the LeakyReLU that produced the convolution's input (gate = (that input, slope)).
     ``rows`` (a RoiWindows, no gate): dY is zero outside the windows' interior, so dX is computed on the window pixels only and is
@@ -374,6 +438,8 @@ def conv3x3_dgrad_winograd(dy, w, gate=None, rows=None):
     if gate is None:
         return conv3x3_winograd(dy, u, None, 1.0)
     g, slope = gate
+    if bn is not None and bn.x is not None and FUSE_BN and not _wino8():
+        return _winograd_bn(dy, u, None, 1.0, cout, cin, bn, gate_slope=slope)
     assert g.shape == (N, H, W, cin) and g.is_contiguous()
     out = torch.empty((N, H, W, cin), device=dy.device, dtype=torch.float32)
     _call('vpho_conv3x3_winograd_gate_nhwc_f32', _f32(dy), _f32(u), _f32(g), F(slope), I(N), I(H), I(W), I(cout), I(ld), I(cin), _f32(out), I(cin))
@@ -1115,23 +1181,34 @@ def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None, groups=None
     return dw
 
 
-def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0, res=None):
-    """x (..., C) NHWC -> y, (save_mean, save_invstd); running stats updated in place (nn.BatchNorm2d.train())"""
+def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0, res=None, partials=None):
+    """x (..., C) NHWC -> y, (save_mean, save_invstd); running stats updated in place (nn.BatchNorm2d.train()).
+    partials: the BnFuse the convolution that produced x filled -- the reduction pass over x is then skipped"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y, mean, invstd = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
     ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
+    if partials is not None and partials.live():
+        assert partials.stats.shape[-1] == Cc
+        _call('vpho_bn_train_forward_stats_f32', _f32(x), LL(rows), I(Cc), I(Cc), _f32(partials.stats), I(partials.rows), _f32(gamma), _f32(beta), F(eps), F(momentum),
+              F(slope), _f32(running_mean), _f32(running_var), _f32(mean), _f32(invstd), _f32(res), _f32(y), _ptr(ws))
+        return y, (mean, invstd)
     _call('vpho_bn_train_forward_f32', _f32(x), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(beta), F(eps), F(momentum), F(slope),
           _f32(running_mean), _f32(running_var), _f32(mean), _f32(invstd), _f32(res), _f32(y), _ptr(ws))
     return y, (mean, invstd)
 
 
-def bn_train_backward(x, dy, gamma, saved):
-    """-> dx, dgamma, dbeta"""
+def bn_train_backward(x, dy, gamma, saved, partials=None):
+    """-> dx, dgamma, dbeta.  partials: the BnFuse the convolution that produced dy filled (sum dy | sum dy * xhat)"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx, dg, db = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
     ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
+    if partials is not None and partials.x is not None and partials.live():
+        assert partials.stats.shape[-1] == Cc
+        _call('vpho_bn_train_backward_stats_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]), _f32(partials.stats),
+              I(partials.rows), _f32(dx), _f32(dg), _f32(db), _ptr(ws))
+        return dx, dg, db
     _call('vpho_bn_train_backward_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]), _f32(dx), _f32(dg), _f32(db), _ptr(ws))
     return dx, dg, db
 

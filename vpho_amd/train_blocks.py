@@ -6,6 +6,8 @@ from . import ops
 from . import conv_backward as CB
 
 SLOPE = 0.01                                             # nn.LeakyReLU() default (backbone_FPN_HFL.py:326)
+import os
+FUSE_LRELU_BWD = os.environ.get('VPHO_TRAIN_FUSE_LRELU', '1') != '0'      # A/B aid: 0 = one stand-alone LeakyReLU backward per bottleneck (same bits)
 
 
 class BottleneckTrain:
@@ -15,39 +17,59 @@ class BottleneckTrain:
     def __init__(self, params, stride=1):
         self.p, self.stride = params, stride
 
-    def _bn(self, name, x, slope, res=None):
+    def _bn(self, name, x, slope, res=None, partials=None):
         b = self.p[name]
-        return ops.bn_train_forward(x, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=slope, res=res)
+        return ops.bn_train_forward(x, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=slope, res=res, partials=partials)
+
+    def _bn_back(self, name, c, saved):
+        b = self.p[name]
+        return ops.BnFuse(c, saved, b['gamma'], b['beta'])
 
     def forward(self, x):
+        # every convolution leaves the column sums of its output for the BatchNorm behind it (ops.BnFuse)
         p, s = self.p, self.stride
-        c1 = ops.conv2d_nhwc(x, p['conv1'])
-        a1, s1 = self._bn('bn1', c1, SLOPE)
-        c2 = ops.conv3x3_train(a1, p['conv2']) if s == 1 else ops.conv2d_nhwc(a1, p['conv2'], kh=3, kw=3, stride=s, pad=1)
-        a2, s2 = self._bn('bn2', c2, SLOPE)
-        c3 = ops.conv2d_nhwc(a2, p['conv3'])
+        f1, f2, f3, fd = ops.BnFuse(), ops.BnFuse(), ops.BnFuse(), ops.BnFuse()
+        c1 = ops.conv2d_nhwc(x, p['conv1'], bn=f1)
+        a1, s1 = self._bn('bn1', c1, SLOPE, partials=f1)
+        c2 = ops.conv3x3_train(a1, p['conv2'], bn=f2) if s == 1 else ops.conv2d_nhwc(a1, p['conv2'], kh=3, kw=3, stride=s, pad=1, bn=f2)
+        a2, s2 = self._bn('bn2', c2, SLOPE, partials=f2)
+        c3 = ops.conv2d_nhwc(a2, p['conv3'], bn=f3)
         if 'down' in p:
-            cd = ops.conv2d_nhwc(x, p['down'], stride=s)
-            res, sd = self._bn('bnd', cd, 1.0)
+            cd = ops.conv2d_nhwc(x, p['down'], stride=s, bn=fd)
+            res, sd = self._bn('bnd', cd, 1.0, partials=fd)
         else:
             cd, res, sd = None, x, None
-        out, s3 = self._bn('bn3', c3, SLOPE, res=res)                  # lrelu(bn3(c3) + shortcut): the add rides in the BatchNorm apply
+        out, s3 = self._bn('bn3', c3, SLOPE, res=res, partials=f3)     # lrelu(bn3(c3) + shortcut): the add rides in the BatchNorm apply
         self.saved = dict(x=x, c1=c1, a1=a1, s1=s1, c2=c2, a2=a2, s2=s2, c3=c3, s3=s3, cd=cd, sd=sd, out=out)
         return out
 
-    def backward(self, dout):
-        """-> dx, grads {name: tensor} for every conv weight (packed layout) and BatchNorm gamma/beta"""
+    def bn3_fuse(self):
+        """carrier for the sums of this block's bn3 backward, to be filled by the convolution that produces (and gates) the gradient at the
+        block's output: the NEXT block's conv1 input-gradient convolution (backward(..., gate_input=True, bn_prev=...))"""
+        S, b = self.saved, self.p['bn3']
+        return ops.BnFuse(S['c3'], S['s3'], b['gamma'], b['beta'], stored_gate=True)
+
+    def backward(self, dout, gated=False, gate_input=False, bn_prev=None, bn3=None):
+        """-> dx, grads {name: tensor} for every conv weight (packed layout) and BatchNorm gamma/beta.
+        gated: dout has already been taken through the backward of this block's closing LeakyReLU (by the block behind it, see
+        gate_input).  gate_input (identity-shortcut blocks): this block's input IS the previous block's output, so the backward of THAT
+        block's closing LeakyReLU rides in the epilogue of the convolution that produces dx (its gate = the input): the stand-alone
+        element-wise pass of one block per pair goes.  bn_prev (with gate_input): the previous block's ``bn3_fuse()`` -- the same epilogue
+        also leaves the two sums of that block's bn3 backward; bn3 (with gated): this block's own carrier, filled that way."""
         p, s, S = self.p, self.stride, self.saved
         H, W = S['x'].shape[1:3]
         g = {}
-        dsum = ops.lrelu_bwd(dout, S['out'], SLOPE)
-        dc3, g['bn3.gamma'], g['bn3.beta'] = ops.bn_train_backward(S['c3'], dsum, p['bn3']['gamma'], S['s3'])
+        dsum = dout if gated else ops.lrelu_bwd(dout, S['out'], SLOPE)
+        dc3, g['bn3.gamma'], g['bn3.beta'] = ops.bn_train_backward(S['c3'], dsum, p['bn3']['gamma'], S['s3'], partials=bn3 if gated else None)
         g['conv3'] = CB.conv2d_wgrad(S['a2'], dc3, 1, 1)
-        da2 = CB.conv2d_dgrad(dc3, p['conv3'], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], SLOPE))
-        dc2, g['bn2.gamma'], g['bn2.beta'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'])
+        # the input-gradient convolutions take the activation's backward AND the two sums of the BatchNorm backward in their epilogue
+        f2 = self._bn_back('bn2', S['c2'], S['s2'])
+        da2 = CB.conv2d_dgrad(dc3, p['conv3'], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], SLOPE), bn=f2)
+        dc2, g['bn2.gamma'], g['bn2.beta'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'], partials=f2)
         g['conv2'] = CB.conv2d_wgrad(S['a1'], dc2, 3, 3, s, 1)
-        da1 = CB.conv2d_dgrad(dc2, p['conv2'], (H, W), 3, 3, s, 1, gate=(S['a1'], SLOPE))
-        dc1, g['bn1.gamma'], g['bn1.beta'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
+        f1 = self._bn_back('bn1', S['c1'], S['s1'])
+        da1 = CB.conv2d_dgrad(dc2, p['conv2'], (H, W), 3, 3, s, 1, gate=(S['a1'], SLOPE), bn=f1)
+        dc1, g['bn1.gamma'], g['bn1.beta'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'], partials=f1)
         g['conv1'] = CB.conv2d_wgrad(S['x'], dc1, 1, 1)
         if 'down' in p:
             dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1)
@@ -55,7 +77,8 @@ class BottleneckTrain:
             g['down'] = CB.conv2d_wgrad(S['x'], dcd, 1, 1, s, 0)
             dx = CB.conv2d_dgrad(dcd, p['down'], (H, W), 1, 1, 1, 0, res=dx) if s == 1 else ops.add_lrelu(dx, CB.conv2d_dgrad(dcd, p['down'], (H, W), 1, 1, s, 0))
         else:
-            dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1, res=dsum)      # identity shortcut: the sum rides in the dgrad epilogue
+            # identity shortcut: the sum rides in the dgrad epilogue (and, on request, the previous block's LeakyReLU backward behind it)
+            dx = CB.conv2d_dgrad(dc1, p['conv1'], (H, W), 1, 1, res=dsum, gate=(S['x'], SLOPE) if gate_input else None, bn=bn_prev if gate_input else None)
         return dx, g
 
 
@@ -128,9 +151,10 @@ class FPNTrain:
         of the two outputs are RoIAligns over these windows, so the smoothing convolutions compute the window pixels only"""
         self.calls = {}
         x = ops.nchw_to_nhwc(rgb_nchw.float().contiguous(), 4)
-        c0 = ops.conv2d_nhwc(x, self.stem['conv'], kh=7, kw=7, stride=2, pad=3)
+        f0 = ops.BnFuse()
+        c0 = ops.conv2d_nhwc(x, self.stem['conv'], kh=7, kw=7, stride=2, pad=3, bn=f0)
         b = self.stem['bn']
-        a0, s0 = ops.bn_train_forward(c0, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=SLOPE)
+        a0, s0 = ops.bn_train_forward(c0, b['gamma'], b['beta'], b['running_mean'], b['running_var'], slope=SLOPE, partials=f0)
         c1 = ops.maxpool_nhwc(a0, 3, 2, 1)
         c2 = self._run_layer('layer1_h', c1, 'h')
         c3h, c3o = self._run_layer('layer2_h', c2, 'h'), self._run_layer('layer2_o', c2, 'o')
@@ -152,8 +176,14 @@ class FPNTrain:
 
     # -------------------------------------------------------------------------------------------------- backward
     def _back_layer(self, name, tag, dy, grads):
-        for k, b in reversed(self.calls[(name, tag)]):
-            dy, g = b.backward(dy)
+        seq = self.calls[(name, tag)]
+        gated, f3 = False, None
+        for i in range(len(seq) - 1, -1, -1):
+            k, b = seq[i]
+            fuse = FUSE_LRELU_BWD and i > 0 and 'down' not in b.p          # block i's input = block i-1's output (same layer)
+            f_prev = seq[i - 1][1].bn3_fuse() if fuse else None            # ... and the sums of block i-1's bn3 backward come with it
+            dy, g = b.backward(dy, gated=gated, gate_input=fuse, bn_prev=f_prev, bn3=f3)
+            gated, f3 = fuse, f_prev
             for gk, gv in g.items():
                 if gk in ('conv1', 'conv2', 'conv3', 'down'):
                     key = f'{k}.{"downsample.0" if gk == "down" else gk}.weight'
@@ -251,22 +281,24 @@ class EncoderTrain:
 
     def forward(self, x):
         """x (N,32,32,cin_pad) NHWC (channels >= cin zero) -> encoding (N, C*2*2) in the reference's NCHW flatten order, stage maps"""
-        bn = lambda p, t: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=SLOPE)
+        bn = lambda p, t, f: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=SLOPE, partials=f)
         self.saved = dict(x=x, blocks=[], pools=[])
-        h = ops.conv2d_nhwc(x, *self.project)
+        fh = ops.BnFuse()                                                 # every convolution leaves the column sums of its output for the BatchNorm behind it
+        h = ops.conv2d_nhwc(x, *self.project, bn=fh)
         stages = []
         for i, (k, p) in enumerate(self.blocks):
-            a0, s0 = bn(p['bn'], h)
-            c1 = ops.conv2d_nhwc(a0, *p['conv1'])
-            a1, s1 = bn(p['bn1'], c1)
-            c2 = ops.conv3x3_train(a1, *p['conv2'])
-            a2, s2 = bn(p['bn2'], c2)
-            out = ops.conv2d_nhwc(a2, *p['conv3'], res=h)
+            f1, f2, fn = ops.BnFuse(), ops.BnFuse(), ops.BnFuse()
+            a0, s0 = bn(p['bn'], h, fh)
+            c1 = ops.conv2d_nhwc(a0, *p['conv1'], bn=f1)
+            a1, s1 = bn(p['bn1'], c1, f1)
+            c2 = ops.conv3x3_train(a1, *p['conv2'], bn=f2)
+            a2, s2 = bn(p['bn2'], c2, f2)
+            out = ops.conv2d_nhwc(a2, *p['conv3'], res=h, bn=fn)
             self.saved['blocks'].append(dict(h=h, a0=a0, s0=s0, c1=c1, a1=a1, s1=s1, c2=c2, a2=a2, s2=s2))
-            h = out
+            h, fh = out, fn
             if i % 2 == 1:
                 self.saved['pools'].append(h)
-                h = ops.maxpool_nhwc(h, 2, 2, 0)
+                h, fh = ops.maxpool_nhwc(h, 2, 2, 0), None               # the next BatchNorm reads the pooled map: its own pass
                 stages.append(h)
         N = h.shape[0]
         return ops.nhwc_to_nchw(h).view(N, -1), stages
@@ -292,16 +324,20 @@ class EncoderTrain:
             # out = conv3(a2) + h
             G[f'{k}.conv3.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dh, 1, 1), *self.shapes[f'{k}.conv3.weight'])
             G[f'{k}.conv3.bias'] = CB.conv2d_bias_grad(dh)
-            da2 = CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1, gate=(S['a2'], SLOPE))
-            dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'])
+            fb = lambda name, c, saved: ops.BnFuse(c, saved, p[name]['gamma'], p[name]['beta'])
+            f2 = fb('bn2', S['c2'], S['s2'])
+            da2 = CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1, gate=(S['a2'], SLOPE), bn=f2)
+            dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'], partials=f2)
             G[f'{k}.conv2.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a1'], dc2, 3, 3, 1, 1), *self.shapes[f'{k}.conv2.weight'])
             G[f'{k}.conv2.bias'] = CB.conv2d_bias_grad(dc2)
-            da1 = CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1, gate=(S['a1'], SLOPE))
-            dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'])
+            f1 = fb('bn1', S['c1'], S['s1'])
+            da1 = CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1, gate=(S['a1'], SLOPE), bn=f1)
+            dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'], partials=f1)
             G[f'{k}.conv1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a0'], dc1, 1, 1), *self.shapes[f'{k}.conv1.weight'])
             G[f'{k}.conv1.bias'] = CB.conv2d_bias_grad(dc1)
-            da0 = CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1, gate=(S['a0'], SLOPE))
-            dmain, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'] = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'])
+            f0 = fb('bn', S['h'], S['s0'])
+            da0 = CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1, gate=(S['a0'], SLOPE), bn=f0)
+            dmain, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'] = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'], partials=f0)
             dh = ops.add_lrelu(dmain, dh)                                 # identity shortcut
         x = self.saved['x']
         G['project.weight'] = _unpack_grad(CB.conv2d_wgrad(x, dh, 1, 1), *self.shapes['project.weight'])
@@ -331,10 +367,11 @@ class HeatmapHeadTrain:
 
     def forward(self, x):
         import torch
-        bn = lambda p, t, slope: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=slope)
+        bn = lambda p, t, slope, f=None: ops.bn_train_forward(t, p['gamma'], p['beta'], p['running_mean'], p['running_var'], slope=slope, partials=f)
         c0 = ops.conv3x3_train(x, *self.c0)
-        c1 = ops.conv3x3_train(c0, *self.c1)
-        a1, s1 = bn(self.bn1, c1, 1.0)
+        f1 = ops.BnFuse()
+        c1 = ops.conv3x3_train(c0, *self.c1, bn=f1)
+        a1, s1 = bn(self.bn1, c1, 1.0, f1)
         N, H, W, _ = a1.shape
         co = self.shapes['deconv_layers.0.weight'][1]
         up = torch.empty((N, 2 * H, 2 * W, co), device=x.device)
@@ -352,8 +389,9 @@ class HeatmapHeadTrain:
         N, H, W, _ = S['a1'].shape
         G['final_layer.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dout, 1, 1), *self.shapes['final_layer.weight'])
         G['final_layer.bias'] = CB.conv2d_bias_grad(dout)
-        da2 = CB.conv2d_dgrad(dout, self.final[0], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], 0.0))
-        dup, G['deconv_layers.1.weight'], G['deconv_layers.1.bias'] = ops.bn_train_backward(S['up'], da2, self.bn2['gamma'], S['s2'])
+        f2 = ops.BnFuse(S['up'], S['s2'], self.bn2['gamma'], self.bn2['beta'])
+        da2 = CB.conv2d_dgrad(dout, self.final[0], S['a2'].shape[1:3], 1, 1, gate=(S['a2'], 0.0), bn=f2)
+        dup, G['deconv_layers.1.weight'], G['deconv_layers.1.bias'] = ops.bn_train_backward(S['up'], da2, self.bn2['gamma'], S['s2'], partials=f2)
         cin, co = self.shapes['deconv_layers.0.weight'][:2]
         dwt = torch.zeros(self.shapes['deconv_layers.0.weight'], device=dout.device)
         da1 = None
