@@ -545,9 +545,12 @@ VPHO_API int vpho_bn_train_backward_f32(const float* x, const float* dy, long lo
 VPHO_API int vpho_bn_train_forward_stats_f32(const float* x, long long rows, int C, int ld, const float* stats, int stats_rows, const float* gamma,
                                     const float* beta, float eps, float momentum, float slope, float* running_mean, float* running_var,
                                     float* save_mean, float* save_invstd, const float* res, float* y, void* workspace, void* stream);
+/* backward: stats may be NULL (stats_rows 0: the call takes its own reduction pass).  res (may be NULL): the other branch of a residual sum,
+ * added to dx (encoding.Residual's identity shortcut, encoding.py:21-36: d input = BatchNorm backward + d shortcut).  dx_colsum (may be NULL;
+ * C floats): the column sums of the dx it stores = the bias gradient of the convolution that produced x, taken while dx is written. */
 VPHO_API int vpho_bn_train_backward_stats_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
-                                     const float* save_invstd, const float* stats, int stats_rows, float* dx, float* dgamma, float* dbeta,
-                                     void* workspace, void* stream);
+                                     const float* save_invstd, const float* stats, int stats_rows, const float* res, float* dx, float* dgamma,
+                                     float* dbeta, float* dx_colsum, void* workspace, void* stream);
 /* dx = y > 0 ? dy : dy * slope: backward of nn.LeakyReLU(slope) / nn.ReLU (slope 0) given its OUTPUT y */
 VPHO_API int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream);
 /* nn.MaxPool2d backward (backbone_FPN_HFL.py:209): dx[n,iy,ix,c] = sum of dy over the windows whose first maximum (row-major)

@@ -189,3 +189,21 @@ def test_layer_backward_is_the_same_with_and_without_the_fused_reductions(monkey
     for k in g0:
         if k.startswith('L.0.3.'):
             assert rel(g1[k], g0[k]) < 1e-4, (k, rel(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize('rows,C', [(64 * 32 * 32, 128), (300, 36), (5000, 7)])
+def test_batchnorm_backward_with_shortcut_add_and_column_sums(rows, C):
+    """encoding.Residual's backward in one pass: dx = BatchNorm backward + d shortcut, and the column sums of dx (the bias gradient of the
+    convolution in front) -- bit for bit the element-wise kernel + add, column sums to fp64 rounding"""
+    from vpho_amd import ops
+    x, dy, res = _rand((rows, C), 41), _rand((rows, C), 42), _rand((rows, C), 43)
+    gamma, beta = _rand((C,), 44).abs() + 0.5, _rand((C,), 45)
+    _, saved = ops.bn_train_forward(x, gamma, beta, slope=0.01)
+    dx0, dg0, db0 = ops.bn_train_backward(x, dy, gamma, saved)
+    dx1, dg1, db1, cs = ops.bn_train_backward(x, dy, gamma, saved, res=res, want_colsum=True)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dx1, dx0 + res)
+    want = dx1.double().sum(0)
+    np.testing.assert_allclose(cs.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(dx1.abs().sum(0).max()))
+    dx2, _, _, cs2 = ops.bn_train_backward(x, dy, gamma, saved, want_colsum=True)
+    assert torch.equal(dx2, dx0) and torch.equal(ops.bn_train_backward(x, dy, gamma, saved, want_colsum=True)[3], cs2)

@@ -409,6 +409,69 @@ __global__ void bn_backward_kernel(const float* __restrict__ x, const float* __r
     for (int v = 0; v < V; ++v) { const float xh = (xv[v] - mu[v]) * is[v]; o[v] = ga[v] * is[v] / m * (m * dv[v] - db[v] - xh * dg[v]); }
     stv<V>(dx + r * ld + c, o);
 }
+// The same element-wise backward with (a) the other branch of a residual sum added to the result (encoding.Residual's identity shortcut:
+// dx = BatchNorm backward + dres) and (b) the column sums of what it stores -- the bias gradient of the convolution that produced x
+// (d bias = sum over pixels of the gradient at its output) -- taken on the way out instead of by a second pass over dx: the tiling of
+// col_reduce_kernel (block = 8 channel groups of V x 32 row groups over a chunk of rows, fp64 partials [chunk][C], fixed order), every
+// element computed by the expression of bn_backward_kernel.
+struct BnBackSumArgs {
+    const float* x; const float* dy; const float* mean; const float* invstd; const float* gamma; const float* dbeta; const float* dgamma; const float* res;
+    long long rows; int C, ld, rows_per_chunk; float* dx; double* part;
+};
+template <int V>
+__global__ __launch_bounds__(256) void bn_backward_sum_kernel(const BnBackSumArgs a) {
+    __shared__ double p0[32][8 * V];
+    const int cq = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int c = (blockIdx.x * 8 + cq) * V;
+    const long long r0 = (long long)blockIdx.y * a.rows_per_chunk, r1 = r0 + a.rows_per_chunk < a.rows ? r0 + a.rows_per_chunk : a.rows;
+    double s0[V];
+    float mu[V], is[V], ga[V], db[V], dg[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { s0[v] = 0.0; mu[v] = is[v] = ga[v] = db[v] = dg[v] = 0.f; }
+    const bool live = c < a.C;
+    if (live) {
+        ldv<V>(a.mean + c, mu); ldv<V>(a.invstd + c, is); ldv<V>(a.gamma + c, ga); ldv<V>(a.dbeta + c, db); ldv<V>(a.dgamma + c, dg);
+        const float m = (float)a.rows;
+        for (long long r = r0 + g; r < r1; r += 128) {
+            float xv[4][V], dv[4][V], rv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + 32 * u;
+#pragma unroll
+                for (int v = 0; v < V; ++v) { xv[u][v] = 0.f; dv[u][v] = 0.f; rv[u][v] = 0.f; }
+                if (rr < r1) {
+                    ldv<V>(a.x + rr * a.ld + c, xv[u]); ldv<V>(a.dy + rr * a.ld + c, dv[u]);
+                    if (a.res) ldv<V>(a.res + rr * a.ld + c, rv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + 32 * u;
+                if (rr >= r1) continue;
+                float o[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float xh = (xv[u][v] - mu[v]) * is[v];
+                    o[v] = ga[v] * is[v] / m * (m * dv[u][v] - db[v] - xh * dg[v]);
+                    if (a.res) o[v] = o[v] + rv[u][v];
+                    s0[v] += (double)o[v];
+                }
+                stv<V>(a.dx + rr * a.ld + c, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) p0[g][cq * V + v] = s0[v];
+    __syncthreads();
+    if (threadIdx.x < 8 * V) {
+        const int cc = blockIdx.x * 8 * V + threadIdx.x;
+        if (cc < a.C) {
+            double t0 = p0[0][threadIdx.x];
+            for (int k = 1; k < 32; ++k) t0 += p0[k][threadIdx.x];
+            a.part[(long long)blockIdx.y * a.C + cc] = t0;
+        }
+    }
+}
 // dx = y > 0 ? dy : dy * slope  (LeakyReLU backward given its output; slope > 0 keeps the sign of the input)
 template <int V>
 __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n, float slope, float* __restrict__ dx) {
@@ -900,9 +963,22 @@ static int bn_forward_tail(const float* x, long long rows, int C, int ld, const 
     return vpho::check_launch("bn_train_forward kernels");
 }
 static int bn_backward_tail(const float* x, const float* dy, long long rows, int C, int ld, const void* part, int chunks, bool part_double, const float* gamma,
-                            const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+                            const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, hipStream_t s,
+                            const float* res = nullptr, float* dx_colsum = nullptr, void* workspace = nullptr) {
     if (part_double) hipLaunchKernelGGL(bn_finish_grads_kernel<double>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const double*)part, chunks, C, dbeta, dgamma);
     else hipLaunchKernelGGL(bn_finish_grads_kernel<float>, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const float*)part, chunks, C, dbeta, dgamma);
+    if (res || dx_colsum) {
+        // (the finishing kernel above has consumed the partial sums: the workspace is free for the column sums of dx)
+        const bool vec = C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
+                         aligned16(dbeta) && aligned16(dgamma) && (!res || aligned16(res));
+        BnBackSumArgs a{x, dy, save_mean, save_invstd, gamma, dbeta, dgamma, res, rows, C, ld, 0, dx, (double*)workspace};
+        const int ch = col_chunks(rows, C, vec ? 4 : 1, &a.rows_per_chunk);
+        const dim3 grid((C + (vec ? 32 : 8) - 1) / (vec ? 32 : 8), ch);
+        if (vec) hipLaunchKernelGGL(bn_backward_sum_kernel<4>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(bn_backward_sum_kernel<1>, grid, dim3(256), 0, s, a);
+        if (dx_colsum) hipLaunchKernelGGL(colsum_finish_kernel, dim3(nblk(C, 32)), dim3(32 * FIN_G), 0, s, (const double*)workspace, ch, C, dx_colsum);
+        return vpho::check_launch("bn_train_backward kernels");
+    }
     if (C % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(save_mean) && aligned16(save_invstd) &&
         aligned16(dbeta) && aligned16(dgamma))
         hipLaunchKernelGGL(bn_backward_kernel<4>, dim3(nblk(rows * (C / 4))), dim3(256), 0, s, x, dy, save_mean, save_invstd, gamma, (const float*)dbeta, (const float*)dgamma, rows, C, ld, dx);
@@ -944,14 +1020,19 @@ extern "C" int vpho_bn_train_backward_f32(const float* x, const float* dy, long 
 }
 
 extern "C" int vpho_bn_train_backward_stats_f32(const float* x, const float* dy, long long rows, int C, int ld, const float* gamma, const float* save_mean,
-                                                const float* save_invstd, const float* stats, int stats_rows, float* dx, float* dgamma, float* dbeta,
-                                                void* workspace, void* stream) {
-    VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && stats && stats_rows > 0 && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C,
+                                                const float* save_invstd, const float* stats, int stats_rows, const float* res, float* dx, float* dgamma,
+                                                float* dbeta, float* dx_colsum, void* workspace, void* stream) {
+    VPHO_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && ld >= C && (stats == nullptr) == (stats_rows <= 0),
                  "vpho_bn_train_backward_stats_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     int chunks; bool dbl;
-    const void* part = reduce_partials(stats, stats_rows, C, workspace, s, &chunks, &dbl);
-    return bn_backward_tail(x, dy, rows, C, ld, part, chunks, dbl, gamma, save_mean, save_invstd, dx, dgamma, dbeta, s);
+    const void* part;
+    if (stats) part = reduce_partials(stats, stats_rows, C, workspace, s, &chunks, &dbl);
+    else {
+        BnRedArgs ra{x, dy, save_mean, save_invstd, rows, C, ld, 1, 0, (double*)workspace};
+        chunks = launch_col_reduce(ra, s); dbl = true; part = workspace;
+    }
+    return bn_backward_tail(x, dy, rows, C, ld, part, chunks, dbl, gamma, save_mean, save_invstd, dx, dgamma, dbeta, s, res, dx_colsum, workspace);
 }
 
 extern "C" int vpho_lrelu_bwd_f32(const float* dy, const float* y, long long n, float slope, float* dx, void* stream) {

@@ -1121,7 +1121,7 @@ def relu_bwd(dy, dy_off, ld_dy, y, y_off, ld_y, rows, cols):
 def colsum(x):
     rows, cols = x.shape
     out = _new((cols,), x)
-    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(cols)), dtype=torch.uint8, device=x.device)
+    ws = _bn_workspace(cols, x.device)
     _call('vpho_colsum_f32', _f32(x), I(cols), LL(rows), I(cols), _f32(out), _ptr(ws))
     return out
 
@@ -1181,13 +1181,27 @@ def conv2d_wgrad_nhwc(x, dy, kh, kw, stride, pad_y, pad_x, cin=None, groups=None
     return dw
 
 
+_BN_WS = {}
+
+
+def _bn_workspace(Cc, device):
+    """scratch of the BatchNorm reductions (256 chunks x 2 x C doubles), one per (device, stream): every user is stream-ordered and done with it
+    when its call's last kernel has run; allocating it per call cost the training step ~270 allocator round trips"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    need = lib.vpho_bn_workspace_bytes(I(Cc))
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _BN_WS[key] = torch.empty(max(need, 256 * 2 * 2048 * 8), dtype=torch.uint8, device=device)
+    return ws
+
+
 def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, slope=1.0, res=None, partials=None):
     """x (..., C) NHWC -> y, (save_mean, save_invstd); running stats updated in place (nn.BatchNorm2d.train()).
     partials: the BnFuse the convolution that produced x filled -- the reduction pass over x is then skipped"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y, mean, invstd = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
-    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
+    ws = _bn_workspace(Cc, x.device)
     if partials is not None and partials.live():
         assert partials.stats.shape[-1] == Cc
         _call('vpho_bn_train_forward_stats_f32', _f32(x), LL(rows), I(Cc), I(Cc), _f32(partials.stats), I(partials.rows), _f32(gamma), _f32(beta), F(eps), F(momentum),
@@ -1198,17 +1212,23 @@ def bn_train_forward(x, gamma, beta, running_mean=None, running_var=None, eps=1e
     return y, (mean, invstd)
 
 
-def bn_train_backward(x, dy, gamma, saved, partials=None):
-    """-> dx, dgamma, dbeta.  partials: the BnFuse the convolution that produced dy filled (sum dy | sum dy * xhat)"""
+def bn_train_backward(x, dy, gamma, saved, partials=None, res=None, want_colsum=False):
+    """-> dx, dgamma, dbeta (, column sums of dx).  partials: the BnFuse the convolution that produced dy filled (sum dy | sum dy * xhat).
+    res: a gradient of x's shape added to dx (the identity shortcut of a pre-activation residual block); want_colsum: also return the
+    column sums of the stored dx (the bias gradient of the convolution that produced x), taken while dx is written"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx, dg, db = torch.empty_like(x), _new((Cc,), x), _new((Cc,), x)
-    ws = torch.empty(lib.vpho_bn_workspace_bytes(I(Cc)), dtype=torch.uint8, device=x.device)
-    if partials is not None and partials.x is not None and partials.live():
-        assert partials.stats.shape[-1] == Cc
-        _call('vpho_bn_train_backward_stats_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]), _f32(partials.stats),
-              I(partials.rows), _f32(dx), _f32(dg), _f32(db), _ptr(ws))
-        return dx, dg, db
+    ws = _bn_workspace(Cc, x.device)
+    live = partials is not None and partials.x is not None and partials.live()
+    if live or res is not None or want_colsum:
+        cs = _new((Cc,), x) if want_colsum else None
+        if live:
+            assert partials.stats.shape[-1] == Cc
+        assert res is None or (res.shape == x.shape and res.is_contiguous())
+        _call('vpho_bn_train_backward_stats_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]),
+              _f32(partials.stats) if live else None, I(partials.rows if live else 0), _f32(res), _f32(dx), _f32(dg), _f32(db), _f32(cs), _ptr(ws))
+        return (dx, dg, db, cs) if want_colsum else (dx, dg, db)
     _call('vpho_bn_train_backward_f32', _f32(x), _f32(dy), LL(rows), I(Cc), I(Cc), _f32(gamma), _f32(saved[0]), _f32(saved[1]), _f32(dx), _f32(dg), _f32(db), _ptr(ws))
     return dx, dg, db
 

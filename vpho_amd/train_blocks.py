@@ -312,6 +312,7 @@ class EncoderTrain:
         sp = self.saved['pools'][-1].shape[1] // 2
         dh = d_encoding.view(N, C, sp, sp).permute(0, 2, 3, 1).contiguous()
         n_stage = len(self.saved['pools'])
+        dh_colsum = None                                                  # column sums of dh when the kernel that wrote dh took them
         for i in reversed(range(len(self.blocks))):
             k, p = self.blocks[i]
             S = self.saved['blocks'][i]
@@ -319,29 +320,29 @@ class EncoderTrain:
                 stage = i // 2
                 if d_stage1 is not None and stage == 1:
                     dh = ops.add_lrelu(dh, d_stage1)
-                dh = ops.maxpool_bwd(self.saved['pools'][stage], dh, 2, 2, 0)
+                dh, dh_colsum = ops.maxpool_bwd(self.saved['pools'][stage], dh, 2, 2, 0), None
             H, W = S['h'].shape[1:3]
             # out = conv3(a2) + h
             G[f'{k}.conv3.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a2'], dh, 1, 1), *self.shapes[f'{k}.conv3.weight'])
-            G[f'{k}.conv3.bias'] = CB.conv2d_bias_grad(dh)
+            G[f'{k}.conv3.bias'] = dh_colsum if dh_colsum is not None else CB.conv2d_bias_grad(dh)
             fb = lambda name, c, saved: ops.BnFuse(c, saved, p[name]['gamma'], p[name]['beta'])
             f2 = fb('bn2', S['c2'], S['s2'])
             da2 = CB.conv2d_dgrad(dh, p['conv3'][0], (H, W), 1, 1, gate=(S['a2'], SLOPE), bn=f2)
-            dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'], partials=f2)
+            # (the bias gradient of a convolution in front of a BatchNorm = the column sums of that BatchNorm's input gradient: taken while it is written)
+            dc2, G[f'{k}.bn2.weight'], G[f'{k}.bn2.bias'], G[f'{k}.conv2.bias'] = ops.bn_train_backward(S['c2'], da2, p['bn2']['gamma'], S['s2'], partials=f2, want_colsum=True)
             G[f'{k}.conv2.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a1'], dc2, 3, 3, 1, 1), *self.shapes[f'{k}.conv2.weight'])
-            G[f'{k}.conv2.bias'] = CB.conv2d_bias_grad(dc2)
             f1 = fb('bn1', S['c1'], S['s1'])
             da1 = CB.conv2d_dgrad(dc2, p['conv2'][0], (H, W), 3, 3, 1, 1, gate=(S['a1'], SLOPE), bn=f1)
-            dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'], partials=f1)
+            dc1, G[f'{k}.bn1.weight'], G[f'{k}.bn1.bias'], G[f'{k}.conv1.bias'] = ops.bn_train_backward(S['c1'], da1, p['bn1']['gamma'], S['s1'], partials=f1, want_colsum=True)
             G[f'{k}.conv1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['a0'], dc1, 1, 1), *self.shapes[f'{k}.conv1.weight'])
-            G[f'{k}.conv1.bias'] = CB.conv2d_bias_grad(dc1)
             f0 = fb('bn', S['h'], S['s0'])
             da0 = CB.conv2d_dgrad(dc1, p['conv1'][0], (H, W), 1, 1, gate=(S['a0'], SLOPE), bn=f0)
-            dmain, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'] = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'], partials=f0)
-            dh = ops.add_lrelu(dmain, dh)                                 # identity shortcut
+            # identity shortcut: d h = BatchNorm backward + d out, in one pass; its column sums are the bias gradient of whichever convolution
+            # produced h (the previous block's conv3, or the projection)
+            dh, G[f'{k}.bn.weight'], G[f'{k}.bn.bias'], dh_colsum = ops.bn_train_backward(S['h'], da0, p['bn']['gamma'], S['s0'], partials=f0, res=dh, want_colsum=True)
         x = self.saved['x']
         G['project.weight'] = _unpack_grad(CB.conv2d_wgrad(x, dh, 1, 1), *self.shapes['project.weight'])
-        G['project.bias'] = CB.conv2d_bias_grad(dh)
+        G['project.bias'] = dh_colsum if dh_colsum is not None else CB.conv2d_bias_grad(dh)
         dx = CB.conv2d_dgrad(dh, self.project[0], x.shape[1:3], 1, 1)
         return dx, G
 
@@ -405,9 +406,8 @@ class HeatmapHeadTrain:
             d = CB.conv2d_dgrad(dph, wp, (H, W), 2, 2, 1, pad_y=pady, pad_x=padx)
             da1 = d if da1 is None else ops.add_lrelu(da1, d)
         G['deconv_layers.0.weight'] = dwt
-        dc1, G['conv_layers.2.weight'], G['conv_layers.2.bias'] = ops.bn_train_backward(S['c1'], da1, self.bn1['gamma'], S['s1'])
+        dc1, G['conv_layers.2.weight'], G['conv_layers.2.bias'], G['conv_layers.1.bias'] = ops.bn_train_backward(S['c1'], da1, self.bn1['gamma'], S['s1'], want_colsum=True)
         G['conv_layers.1.weight'] = _unpack_grad(CB.conv2d_wgrad(S['c0'], dc1, 3, 3, 1, 1), *self.shapes['conv_layers.1.weight'])
-        G['conv_layers.1.bias'] = CB.conv2d_bias_grad(dc1)
         dc0 = CB.conv2d_dgrad(dc1, self.c1[0], S['c0'].shape[1:3], 3, 3, 1, 1)
         G['conv_layers.0.weight'] = _unpack_grad(CB.conv2d_wgrad(S['x'], dc0, 3, 3, 1, 1), *self.shapes['conv_layers.0.weight'])
         G['conv_layers.0.bias'] = CB.conv2d_bias_grad(dc0)
