@@ -207,3 +207,38 @@ def test_batchnorm_backward_with_shortcut_add_and_column_sums(rows, C):
     np.testing.assert_allclose(cs.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(dx1.abs().sum(0).max()))
     dx2, _, _, cs2 = ops.bn_train_backward(x, dy, gamma, saved, want_colsum=True)
     assert torch.equal(dx2, dx0) and torch.equal(ops.bn_train_backward(x, dy, gamma, saved, want_colsum=True)[3], cs2)
+
+
+def test_phase_convolutions_append_their_sums():
+    """maps written by several strided convolutions: the four phases of a stride-2 input gradient (gate recomputed from the BatchNorm input,
+    backward sums) and the four phases of a transposed convolution (forward sums over the 2H x 2W map)"""
+    from vpho_amd import ops, conv_backward as CB
+    N, H, W, cin, cout = 4, 16, 16, 32, 48
+    c = _rand((N, H, W, cin), 51)
+    gamma, beta = _rand((cin,), 52).abs() + 0.5, _rand((cin,), 53) * 0.3
+    a, saved = ops.bn_train_forward(c, gamma, beta, slope=0.01)
+    w = _rand((cout, 9 * cin), 54, (9 * cin) ** -0.5)
+    dy = _rand((N, H // 2, W // 2, cout), 55)
+    want = CB.conv2d_dgrad(dy, w, (H, W), 3, 3, 2, 1, gate=(a, 0.01))
+    f = ops.BnFuse(c, saved, gamma, beta)
+    got = CB.conv2d_dgrad(dy, w, (H, W), 3, 3, 2, 1, gate=(a, 0.01), bn=f)
+    assert f.live() and f.parts == 4 and torch.equal(got, want)
+    xh = ((c - saved[0]) * saved[1]).reshape(-1, cin).double()
+    d2 = got.reshape(-1, cin).double()
+    part = f.stats[:f.rows].double()
+    np.testing.assert_allclose(part[:, 0].sum(0).cpu().numpy(), d2.sum(0).cpu().numpy(), rtol=2e-5, atol=2e-5 * float(d2.abs().sum(0).max()))
+    np.testing.assert_allclose(part[:, 1].sum(0).cpu().numpy(), (d2 * xh).sum(0).cpu().numpy(), rtol=2e-5, atol=2e-5 * float((d2 * xh).abs().sum(0).max()))
+    # forward: four 2x2 phase convolutions into one (N, 2H, 2W, co) map
+    co = 64
+    up = torch.empty((N, 2 * H, 2 * W, co), device='cuda')
+    f2 = ops.BnFuse(parts=4)
+    for py in (0, 1):
+        for px in (0, 1):
+            wp = _rand((co, 4 * cin), 60 + 2 * py + px, (4 * cin) ** -0.5)
+            ops.conv2d_nhwc(c, wp, None, kh=2, kw=2, pad_y=1 - py, pad_x=1 - px, out_hw=(H, W),
+                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co), bn=f2)
+    assert f2.live()
+    u2 = up.reshape(-1, co).double()
+    part = f2.stats[:f2.rows].double()
+    np.testing.assert_allclose(part[:, 0].sum(0).cpu().numpy(), u2.sum(0).cpu().numpy(), rtol=2e-5, atol=2e-5 * float(u2.abs().sum(0).max()))
+    np.testing.assert_allclose(part[:, 1].sum(0).cpu().numpy(), (u2 * u2).sum(0).cpu().numpy(), rtol=2e-5)

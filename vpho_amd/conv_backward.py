@@ -174,6 +174,10 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
     assert py == px == pad and res is None
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
     dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)
+    phases = [(py, px) for py in (0, 1) for px in (0, 1) if _phase_taps(py, kh, pad) and _phase_taps(px, kw, pad)]
+    fuse = gate is not None and bn is not None and bn.x is not None
+    if fuse:
+        bn.parts = len(phases)                              # every phase appends its partial sums (the pixels of the other parities stay zero: no terms)
     for py in (0, 1):
         ty = _phase_taps(py, kh, pad)
         for px in (0, 1):
@@ -185,7 +189,8 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
             sub = _derived(w_packed, ('s2', kh, kw, pad, py, px), lambda w, ty=ty, tx=tx: _phase_weights(_pad_rows4(w), cin, kh, kw, ty, tx))
             # phase output (a, b) reads dY rows a + oy0 .. : a stride-1 convolution with padding -oy0 / -ox0
             ops.conv2d_nhwc(dy, sub, None, kh=khp, kw=kwp, stride=1, pad_y=-oy0, pad_x=-ox0,
-                            out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin), gate=gate)
+                            out_hw=(H // 2, W // 2), out_view=(dx, H * W * cin, 2 * W * cin, 2 * cin, (py * W + px) * cin), gate=gate,
+                            bn=bn if fuse else None)
     return dx
 
 

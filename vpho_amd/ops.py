@@ -91,16 +91,19 @@ class BnFuse:
     BatchNorm runs its own pass).  Backward: ``f = BnFuse(c, saved, gamma, beta); da = conv2d_dgrad(dy, w, ..., gate=(a, slope), bn=f)``
     -- the input-gradient convolution recomputes the activation's sign from the BatchNorm input ``c`` instead of reading the stored
     activation and leaves sum da | sum da * xhat -- then ``bn_train_backward(c, da, gamma, saved, partials=f)``."""
-    __slots__ = ('stats', 'rows', 'x', 'mean', 'invstd', 'gamma', 'beta', 'stored_gate')
+    __slots__ = ('stats', 'rows', 'x', 'mean', 'invstd', 'gamma', 'beta', 'stored_gate', 'parts', 'calls', 'failed')
 
-    def __init__(self, x=None, saved=None, gamma=None, beta=None, stored_gate=False):
+    def __init__(self, x=None, saved=None, gamma=None, beta=None, stored_gate=False, parts=1):
         # stored_gate: keep reading the activation's sign from the stored activation (a residual block's closing activation, whose input is
-        # BatchNorm + shortcut) and take only xhat from the BatchNorm input
+        # BatchNorm + shortcut) and take only xhat from the BatchNorm input.
+        # parts > 1: the map is written by several convolutions, each into its own strided part (the four phases of a transposed convolution
+        # / of a stride-2 input gradient, ``out_view``): every launch appends its partial rows; the sums count only when all parts came
         self.stats, self.rows, self.x, self.gamma, self.beta, self.stored_gate = None, 0, x, gamma, beta, stored_gate
         self.mean, self.invstd = saved if saved is not None else (None, None)
+        self.parts, self.calls, self.failed = parts, 0, False
 
     def live(self):
-        return self.stats is not None and self.rows > 0
+        return self.stats is not None and self.rows > 0 and not self.failed and self.calls == self.parts
 
 
 # Opt-in split-bf16 convolutions (VPHO_CONV_MFMA=bf16x6|bf16x9, inference plan only; default: fp32 MFMA).  The three bf16 planes of
@@ -242,21 +245,31 @@ def conv2d_nhwc(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, pad_y=None, pad
         planes = _planes_of(w)                              # kept alive by the cache
         d.w_planes, d.plane_terms = planes.data_ptr(), terms
     rows_out = None
-    if bn is not None and FUSE_BN and G == 1 and split is None and rows is None and in_scale is None and out_view is None and not d.w_planes and cout % 4 == 0:
+    if bn is not None and FUSE_BN and G == 1 and split is None and rows is None and in_scale is None and (out_view is None or bn.parts > 1) and not d.w_planes and cout % 4 == 0:
         cap = (N * OH * OW + 63) // 64                          # the smallest M-tile is 64 rows
-        bn.stats = torch.empty((cap, 2, cout), device=x.device, dtype=torch.float32)
+        if bn.stats is None:
+            bn.stats = torch.empty((cap * bn.parts, 2, cout), device=x.device, dtype=torch.float32)
+        base = bn.rows                                          # parts > 1: this launch appends behind the rows of the earlier parts
+        assert base + cap <= bn.stats.shape[0] and bn.stats.shape[2] == cout
         rows_out = C.c_int(0)
-        d.stats, d.stats_cap, d.stats_rows = bn.stats.data_ptr(), cap, C.cast(C.pointer(rows_out), C.c_void_p)
+        d.stats, d.stats_cap, d.stats_rows = bn.stats.data_ptr() + base * 2 * cout * 4, cap, C.cast(C.pointer(rows_out), C.c_void_p)
         if bn.x is not None:
             assert gate is not None and bn.x.shape == ret.shape and bn.x.is_contiguous() and ret.is_contiguous()
+            bx = _ptr(bn.x, torch.float32).value + (4 * out_view[4] if out_view is not None else 0)      # laid out like y, like the gate
             if bn.stored_gate:
-                d.bn_x, d.bn_mean, d.bn_invstd = (_ptr(t, torch.float32).value for t in (bn.x, bn.mean, bn.invstd))
+                d.bn_x, d.bn_mean, d.bn_invstd = bx, _ptr(bn.mean, torch.float32).value, _ptr(bn.invstd, torch.float32).value
             else:
                 d.gate, d.gate_slope = None, gate[1]
-                d.bn_x, d.bn_mean, d.bn_invstd, d.bn_gamma, d.bn_beta = (_ptr(t, torch.float32).value for t in (bn.x, bn.mean, bn.invstd, bn.gamma, bn.beta))
+                d.bn_x = bx
+                d.bn_mean, d.bn_invstd, d.bn_gamma, d.bn_beta = (_ptr(t, torch.float32).value for t in (bn.mean, bn.invstd, bn.gamma, bn.beta))
+    elif bn is not None:
+        bn.failed = True
     _check(lib.vpho_conv2d_nhwc_f32(C.byref(d), _stream()))
     if rows_out is not None:
-        bn.rows = rows_out.value
+        bn.calls += 1
+        if rows_out.value == 0:
+            bn.failed = True
+        bn.rows += rows_out.value
     return ret
 
 
@@ -394,7 +407,7 @@ def _winograd_bn(x, u, bias, out_slope, cin, cout, bn, gate_slope=1.0):
         assert bn.x.shape == out.shape and bn.x.is_contiguous()
     _call('vpho_conv3x3_winograd_stats_nhwc_f32', _f32(x), _f32(u), _f32(bias), I(N), I(H), I(W), I(cin), I(x_ld), I(cout), F(out_slope), _f32(out), I(cout),
           _f32(bn.stats), I(cap), C.byref(rows_out), *[_f32(t) for t in bx], F(gate_slope))
-    bn.rows = rows_out.value
+    bn.rows, bn.calls = rows_out.value, 1
     return out
 
 

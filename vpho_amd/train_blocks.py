@@ -376,10 +376,11 @@ class HeatmapHeadTrain:
         N, H, W, _ = a1.shape
         co = self.shapes['deconv_layers.0.weight'][1]
         up = torch.empty((N, 2 * H, 2 * W, co), device=x.device)
+        f2 = ops.BnFuse(parts=len(self.deconv))                       # the four phases append their column sums: no pass over the 2H x 2W map
         for (py, px), (wp, pady, padx) in self.deconv.items():
             ops.conv2d_nhwc(a1, wp, None, kh=2, kw=2, pad_y=pady, pad_x=padx, out_hw=(H, W),
-                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co))
-        a2, s2 = bn(self.bn2, up, 0.0)
+                            out_view=(up, 4 * H * W * co, 4 * W * co, 2 * co, (py * 2 * W + px) * co), bn=f2)
+        a2, s2 = bn(self.bn2, up, 0.0, f2)
         out = ops.conv2d_nhwc(a2, *self.final)
         self.saved = dict(x=x, c0=c0, c1=c1, a1=a1, s1=s1, up=up, a2=a2, s2=s2)
         return out
