@@ -74,6 +74,7 @@ _copy(tag + '_train_stats_bs32.txt', f'{rnd}_train_step_bs32_kernel_stats.txt',
 if os.path.exists(g + tag + '_train_pmc_hbm.json'):
     shutil.copy(g + tag + '_train_pmc_hbm.json', f'profiles/{rnd}_train_pmc_hbm_traffic.json')
     _copy(tag + '_train_pmc_hbm.txt', f'{rnd}_train_pmc_hbm_traffic.txt', f'# HBM traffic per launch of one training step (two rocprofv3 --pmc passes: FETCH_SIZE; WRITE_SIZE) of  VPHO_WGRAD_STREAM=0 python3 train.py --steps 1 --warmup 1 --no_roofline  ({rnd}; (2*FETCH_SIZE + WRITE_SIZE)*1024 B)')
+_copy(tag + '_train_pmc_mfma.txt', f'{rnd}_train_pmc_mfma_busy.txt', f'# MFMA pipe utilisation per kernel of one training step (one rocprofv3 --pmc pass: SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT) of  VPHO_WGRAD_STREAM=0 python3 train.py --steps 1 --warmup 1 --no_roofline  ({rnd}; summary by scripts/pmc_mfma_summary.py)')
 if _copy(tag + '_force_optim.json', f'{rnd}_force_optim.json'):
     f = json.load(open(g + tag + '_force_optim.json'))
     print('force:', round(f['value'], 1), f.get('unit'), (f.get('roofline') or {}).get('frac'), (f.get('roofline') or {}).get('traffic'))

@@ -51,6 +51,13 @@ if has cfg4; then
   { for sw in VPHO_HEAD_CB VPHO_CONV_PERS VPHO_WINO_STAGED; do bash scripts/ab.sh cfg4_$sw "$sw=0" "$sw=1" 2 -- python3 bench.py --no_cpu_baseline --no_opt_in --no_kernel_timing $C4 --steps 6 2>&1 | grep run; done; } > $O/${T}_cfg4_ab.txt 2>&1
   scrub ${T}_cfg4_prof ${T}_cfg4_pmc_f ${T}_cfg4_pmc_w; head -8 $O/${T}_cfg4_stats.txt | cut -c1-150; cat $O/${T}_cfg4_ab.txt
 fi
+if has trainmfma; then
+  # only the matrix-pipe counter pass of one training step
+  scrub ${T}_train_pmc_m
+  VPHO_WGRAD_STREAM=0 prof ${T}_train_pmc_m --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/${T}_train_pmc_m -o m -- python3 $R/train.py --steps 1 --warmup 1 --no_roofline &&
+  python3 scripts/pmc_mfma_summary.py $(csv ${T}_train_pmc_m counter_collection) $(csv ${T}_train_pmc_m kernel_trace) > $O/${T}_train_pmc_mfma.txt
+  scrub ${T}_train_pmc_m; head -24 $O/${T}_train_pmc_mfma.txt | cut -c1-170
+fi
 if has traintrace; then
   # only the one-stream kernel trace of the training step + statistics + idle gaps (quick look between kernel changes)
   scrub ${T}_train_prof
@@ -67,8 +74,10 @@ if has train; then
   python3 scripts/rocpd_stats.py $(db ${T}_train_prof32) 40 --last-ms 200 > $O/${T}_train_stats_bs32.txt 2>&1 &&
   VPHO_WGRAD_STREAM=0 prof ${T}_train_pmc_f --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_train_pmc_f -o f -- python3 $R/train.py --steps 1 --warmup 1 --no_roofline &&
   VPHO_WGRAD_STREAM=0 prof ${T}_train_pmc_w --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_train_pmc_w -o w -- python3 $R/train.py --steps 1 --warmup 1 --no_roofline &&
-  python3 scripts/pmc_summary.py $(csv ${T}_train_pmc_f counter_collection) $(csv ${T}_train_pmc_w counter_collection) $O/${T}_train_pmc_hbm.json > $O/${T}_train_pmc_hbm.txt
-  scrub ${T}_train_prof ${T}_train_prof32 ${T}_train_pmc_f ${T}_train_pmc_w; head -30 $O/${T}_train_stats.txt | cut -c1-160
+  python3 scripts/pmc_summary.py $(csv ${T}_train_pmc_f counter_collection) $(csv ${T}_train_pmc_w counter_collection) $O/${T}_train_pmc_hbm.json > $O/${T}_train_pmc_hbm.txt &&
+  VPHO_WGRAD_STREAM=0 prof ${T}_train_pmc_m --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/${T}_train_pmc_m -o m -- python3 $R/train.py --steps 1 --warmup 1 --no_roofline &&
+  python3 scripts/pmc_mfma_summary.py $(csv ${T}_train_pmc_m counter_collection) $(csv ${T}_train_pmc_m kernel_trace) > $O/${T}_train_pmc_mfma.txt
+  scrub ${T}_train_prof ${T}_train_prof32 ${T}_train_pmc_f ${T}_train_pmc_w ${T}_train_pmc_m; head -30 $O/${T}_train_stats.txt | cut -c1-160
 fi
 if has force; then
   gstep 300 $O/${T}_force_optim.log python3 force_optim.py --pairs 10048 && grep '^{' $O/${T}_force_optim.log > $O/${T}_force_optim.json &&
