@@ -41,12 +41,12 @@ def test_no_kernel_spills_vector_registers_unannounced(kernels):
     """Kernels known to spill say why in their sources: the persistent force optimiser (1024-thread workgroup: 128 registers, of which 49
     hold per-item state; since round 6 its two iteration loops are scratch-free -- what is left is loop-invariant values parked around
     the loop that does not use them, the table fill and the once-per-launch report: 18 registers, down from 179), the attention
-    backward (2 registers) and the Winograd kernel's epilogue (1 register, outside the loop)."""
-    # conv_winograd_kernel: ONE accumulator dword saved and restored in the output transform (after the main loop, 256 + 256 registers in use)
-    allowed = {'force_optim_kernel<false>': 20, 'force_optim_kernel<true>': 28, 'mha_bwd_kernel': 8, 'conv_winograd_kernel<0>': 8, 'conv_winograd_kernel<1>': 8,
-               'conv_winograd_kernel<2>': 8,
-               # the training instantiations with the BatchNorm reductions in the output transform: three accumulator dwords, all behind the main loop
-               'conv_winograd_bn_kernel<0>': 8, 'conv_winograd_bn_kernel<1>': 8,
+    backward (2 registers) and the training-only epilogues with BatchNorm sums (1-3 registers, outside the loops)."""
+    # the Winograd inference kernels are scratch-free since round 6 (the tile records of the output transform are fetched in two batches); the training
+    # instantiations with the BatchNorm sums in the output transform (bn: forward sums, bnb: backward sums with the gate recomputed) park up to two
+    # accumulator dwords, behind the main loop
+    allowed = {'force_optim_kernel<false>': 20, 'force_optim_kernel<true>': 28, 'mha_bwd_kernel': 8,
+               'conv_winograd_bn_kernel<0>': 2, 'conv_winograd_bn_kernel<1>': 2, 'conv_winograd_bnb_kernel<0>': 3, 'conv_winograd_bnb_kernel<1>': 3,
                # the persistent walk with the BatchNorm sums: the statistics pointer is parked across the tile loop (one 8-byte reload per TILE, none in the k loop)
                'conv_igemm_pers_bn_kernel<128, 128, 4, 2>': 2}
     bad = {k: v['spill'] for k, v in kernels.items() if v.get('spill', 0) > allowed.get(k, 0)}
@@ -63,7 +63,7 @@ BUDGET = {
     # the occupancy would leave half of the slots idle without a word
     'conv_igemm_pers_kernel<128, 128, 4, 2>': (4, 128), 'conv_igemm_pers_bn_kernel<128, 128, 4, 2>': (4, 128),
     'conv_winograd_kernel<0>': (1, 256), 'conv_winograd_kernel<1>': (1, 256), 'conv_winograd_kernel<2>': (1, 256),   # one wave per SIMD by design: 256 accumulators
-    'conv_winograd_bn_kernel<0>': (1, 256), 'conv_winograd_bn_kernel<1>': (1, 256),
+    'conv_winograd_bn_kernel<0>': (1, 256), 'conv_winograd_bn_kernel<1>': (1, 256), 'conv_winograd_bnb_kernel<0>': (1, 256), 'conv_winograd_bnb_kernel<1>': (1, 256),
     'conv_winograd8_kernel': (2, 256),
     'conv_wgrad_tn_kernel<64, 64, 2, 2>': (4, 128), 'conv_wgrad_tn_kernel<128, 128, 4, 2>': (4, 128), 'conv_wgrad_tn_kernel<128, 64, 4, 2>': (4, 128),
     'mano_fk_kernel<16>': (3, 168),
@@ -75,8 +75,7 @@ def test_hot_kernels_keep_their_register_budget(kernels, name):
     assert name in kernels, sorted(kernels)[:20]
     waves, regs = BUDGET[name]
     k = kernels[name]
-    # the Winograd kernel saves one accumulator dword in its output transform (behind the main loop; timed the same: DESIGN 4c)
-    spill_ok = 1 if name.startswith('conv_winograd_kernel<') else 3 if name.startswith('conv_winograd_bn_kernel<') else 2 if name.startswith('conv_igemm_pers_bn_kernel<') else 0
+    spill_ok = 2 if name.startswith(('conv_winograd_bn_kernel<', 'conv_igemm_pers_bn_kernel<')) else 3 if name.startswith('conv_winograd_bnb_kernel<') else 0
     assert k['occupancy'] >= waves and k['vgpr'] <= regs and k.get('spill', 0) <= spill_ok, (name, k)
 
 

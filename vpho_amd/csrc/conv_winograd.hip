@@ -95,9 +95,11 @@ __device__ inline bool wino_tile(const WinoArgs& a, int t, int& n, int& ty, int&
 // ds_read_b128 just before it needs it -- so one 64-register patch set is enough (the second one was there to cover HBM latency).
 // MODE 0: patches through registers; 1: staged, regular blocks (full maps); 2: RoI-window launches -- a block of the live-tile list is staged
 // when its 64 tiles are live, lie in one image and their bounding pixel region fits IN (decided per workgroup: both loops are in the kernel).
-// BN (conv_winograd_bn_kernel, training): the reductions of the BatchNorm next to the convolution in the epilogue -- WinoArgs.stats / bn_x,
-// the same contract as vpho_conv_desc.stats / bn_x (include/vpho_hip.h); the inference kernels are the BN = false instantiations.
-template <int MODE, bool BN>
+// BN (training): the reductions of the BatchNorm next to the convolution in the epilogue -- WinoArgs.stats / bn_x, the same contract as
+// vpho_conv_desc.stats / bn_x (include/vpho_hip.h).  BN = 1 (conv_winograd_bn_kernel): the forward form (sum v | sum v^2: two registers);
+// BN = 2 (conv_winograd_bnb_kernel): the backward form (gate recomputed from bn_x, sum v | sum v * xhat: six registers and a pointer -- kept
+// out of the forward instantiation, whose output transform already runs with 256 + 256 registers in use); 0: the inference kernels.
+template <int MODE, int BN>
 __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
     const WinoArgs a = wino_group(a_, blockIdx.y);
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -397,24 +399,28 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
     VPHO_STAMP_AT(3);
 
     // ---- output transform on the accumulators: A^T = [1 1 1 0; 0 1 -1 -1]; row e -> tile, lane -> output channel
-    // (with both loops in the kernel the compiler saves ONE accumulator dword to scratch here and reloads it once: outside the loop, tests/test_kernel_resources.py)
     const int co = c0 + wc * 32 + li;
     const float bias = s_bias[wc * 32 + li];
     // the 16 destination records of this lane's tile rows in ONE LDS round trip (the patch registers are dead by now): read one by one
     // inside the loop each was a dependent LDS latency in front of its stores
+    // (the records of the lane's tile rows are fetched in two batches of eight: sixteen at once held 32 registers on top of the 256
+    // accumulators being read out, and the one dword that did not fit went through scratch -- a kernel with a private segment pays for it
+    // at every wave launch, not only at the spill)
     int pm_e[16], row_e[16];
+    auto fetch_records = [&](int e0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        pm_e[e] = s_pitch[trow]; row_e[e] = s_row[trow];
-    }
+        for (int e = e0; e < e0 + 8; ++e) {
+            const int trow = wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            pm_e[e] = s_pitch[trow]; row_e[e] = s_row[trow];
+        }
+    };
+    fetch_records(0);
     // BN: a lane owns one output channel and 16 tiles x 4 pixels of it -- its share of the column sums is two registers
     float st0 = 0.f, st1 = 0.f, bn_m = 0.f, bn_i = 0.f, bn_g = 0.f, bn_b = 0.f;
-    if constexpr (BN) {
-        if (a.bn_x) { bn_m = a.bn_mean[co]; bn_i = a.bn_invstd[co]; bn_g = a.bn_gamma[co]; bn_b = a.bn_beta[co]; }
-    }
+    if constexpr (BN == 2) { bn_m = a.bn_mean[co]; bn_i = a.bn_invstd[co]; bn_g = a.bn_gamma[co]; bn_b = a.bn_beta[co]; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
+        if (e == 4) fetch_records(8);
         float s0[4], s1[4];
 #pragma unroll
         for (int fx = 0; fx < 4; ++fx) {
@@ -431,22 +437,22 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
             const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
             const float* gp = a.gate ? a.gate + (long long)row_e[e] * a.y_ld + co : nullptr;
             const float* xp = nullptr;
-            if constexpr (BN) { if (a.bn_x) xp = a.bn_x + (long long)row_e[e] * a.y_ld + co; }
+            if constexpr (BN == 2) xp = a.bn_x + (long long)row_e[e] * a.y_ld + co;
 #pragma unroll
             for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
                 float v = o[p];
                 if (gp) v = gp[offs[p]] > 0.f ? v : v * a.gate_slope;
                 if ((WINO_ABLATE & 512) && v != 1.2345e-30f) continue;          // timing: the output transform without its stores
-                if constexpr (BN) {
-                    if (xp) {
-                        // gate recomputed from the BatchNorm input: the forward pass's own expression (bn_apply_kernel), hence its sign
-                        const float xh = (xp[offs[p]] - bn_m) * bn_i;
-                        const float t = xh * bn_g + bn_b;
-                        v = t > 0.f ? v : v * a.gate_slope;
-                        st0 += v; st1 += v * xh;
-                        yp[offs[p]] = v;
-                        continue;
-                    }
+                if constexpr (BN == 2) {
+                    // gate recomputed from the BatchNorm input: the forward pass's own expression (bn_apply_kernel), hence its sign
+                    const float xh = (xp[offs[p]] - bn_m) * bn_i;
+                    const float t = xh * bn_g + bn_b;
+                    v = t > 0.f ? v : v * a.gate_slope;
+                    st0 += v; st1 += v * xh;
+                    yp[offs[p]] = v;
+                    continue;
+                }
+                if constexpr (BN == 1) {
                     v = v > 0.f ? v : v * a.out_slope;
                     st0 += v; st1 += v * v;
                     yp[offs[p]] = v;
@@ -456,7 +462,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
             }
         }
     }
-    if constexpr (BN) {
+    if constexpr (BN != 0) {
         // lanes li / li + 32 hold the two row halves of a channel, the waves wt = 0 / 1 the two tile halves: one partial row per tile
         // block, [tb][2][Cout], combined in a fixed order (the stage buffers are free: every wave has passed the last stage's barrier)
         st0 += __shfl_xor(st0, 32); st1 += __shfl_xor(st1, 32);
@@ -471,9 +477,11 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
     VPHO_STAMP_WRITE(wino, blockIdx.x);
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) { wino_body<MODE, false>(a_); }
+__global__ __launch_bounds__(256) void conv_winograd_kernel(const WinoArgs a_) { wino_body<MODE, 0>(a_); }
 template <int MODE>
-__global__ __launch_bounds__(256) void conv_winograd_bn_kernel(const WinoArgs a_) { wino_body<MODE, true>(a_); }
+__global__ __launch_bounds__(256) void conv_winograd_bn_kernel(const WinoArgs a_) { wino_body<MODE, 1>(a_); }
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_winograd_bnb_kernel(const WinoArgs a_) { wino_body<MODE, 2>(a_); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -873,12 +881,17 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
             VPHO_REQUIRE(!bn->x || (bn->mean && bn->invstd && bn->gamma && bn->beta), "vpho_conv3x3_winograd_stats_nhwc_f32: bn_x needs the four BatchNorm vectors");
             a.stats = bn->stats; a.bn_x = bn->x; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
             *bn->rows = tbs;
-            if (staged && wino_staged_ok(a.TH, a.TW, W)) {
-                VPHO_DYN_LDS(conv_winograd_bn_kernel<1>, lds_staged);
-                hipLaunchKernelGGL(conv_winograd_bn_kernel<1>, dim3(blocks, 1), dim3(256), lds_staged, (hipStream_t)stream, a);
+            const bool st1 = staged && wino_staged_ok(a.TH, a.TW, W);
+            VPHO_DYN_LDS(conv_winograd_bn_kernel<1>, lds_staged);
+            VPHO_DYN_LDS(conv_winograd_bn_kernel<0>, lds);
+            VPHO_DYN_LDS(conv_winograd_bnb_kernel<1>, lds_staged);
+            VPHO_DYN_LDS(conv_winograd_bnb_kernel<0>, lds);
+            if (bn->x) {
+                if (st1) hipLaunchKernelGGL(conv_winograd_bnb_kernel<1>, dim3(blocks, 1), dim3(256), lds_staged, (hipStream_t)stream, a);
+                else     hipLaunchKernelGGL(conv_winograd_bnb_kernel<0>, dim3(blocks, 1), dim3(256), lds, (hipStream_t)stream, a);
             } else {
-                VPHO_DYN_LDS(conv_winograd_bn_kernel<0>, lds);
-                hipLaunchKernelGGL(conv_winograd_bn_kernel<0>, dim3(blocks, 1), dim3(256), lds, (hipStream_t)stream, a);
+                if (st1) hipLaunchKernelGGL(conv_winograd_bn_kernel<1>, dim3(blocks, 1), dim3(256), lds_staged, (hipStream_t)stream, a);
+                else     hipLaunchKernelGGL(conv_winograd_bn_kernel<0>, dim3(blocks, 1), dim3(256), lds, (hipStream_t)stream, a);
             }
             return vpho::check_launch("conv_winograd_bn_kernel");
         }
