@@ -16,7 +16,8 @@ def _rand(shape, seed, scale=1.0):
 
 # (N, H, W, cin, cout, k): 128x128 / 128x64 / 64x64 tile classes of the direct kernel, ragged pixel counts and channel tails, and the Winograd shapes
 SHAPES = [(64, 32, 32, 64, 256, 1), (16, 16, 16, 256, 64, 1), (2, 9, 7, 32, 40, 1), (3, 8, 8, 36, 132, 1), (64, 16, 16, 128, 128, 3),
-          (4, 32, 32, 64, 64, 3), (2, 10, 6, 16, 64, 3), (2, 8, 8, 12, 20, 3)]
+          (4, 32, 32, 64, 64, 3), (2, 10, 6, 16, 64, 3), (2, 8, 8, 12, 20, 3),
+          (3, 12, 12, 64, 128, 3), (2, 20, 12, 128, 64, 3)]      # 6 tiles per row: the Winograd kernel's register-path instantiations, ragged tile blocks
 
 
 @pytest.mark.parametrize('N,H,W,cin,cout,k', SHAPES)

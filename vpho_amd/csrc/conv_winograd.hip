@@ -417,7 +417,28 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
     fetch_records(0);
     // BN: a lane owns one output channel and 16 tiles x 4 pixels of it -- its share of the column sums is two registers
     float st0 = 0.f, st1 = 0.f, bn_m = 0.f, bn_i = 0.f, bn_g = 0.f, bn_b = 0.f;
-    if constexpr (BN == 2) { bn_m = a.bn_mean[co]; bn_i = a.bn_invstd[co]; bn_g = a.bn_gamma[co]; bn_b = a.bn_beta[co]; }
+    constexpr int BNX_FLOATS = W_TB * 4 * W_CB;                      // the block's BatchNorm-input tile: 64 tiles x 4 pixels x 64 channels = 64 KB
+    if constexpr (BN == 2) {
+        bn_m = a.bn_mean[co]; bn_i = a.bn_invstd[co]; bn_g = a.bn_gamma[co]; bn_b = a.bn_beta[co];
+        // The BatchNorm input of the block's 256 output pixels comes into the (idle) stage buffers by LDS-DMA, 64 instructions of 1 KB
+        // (one tile = 4 pixels x 64 channels each), one memory round trip for the workgroup.  Read element by element through registers
+        // instead -- 64 dependent 4-byte loads per lane with 256 + 256 registers in use, a handful in flight at a time -- the same data cost
+        // the gated input-gradient launches +40 % (3 x 3 64 -> 64 on 64 x 64 maps: 182 us against 128 for the forward convolution).
+        static_assert(BNX_FLOATS <= 2 * W_STAGE, "BatchNorm-input tile does not fit the stage buffers");
+        const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bn_x), 0, 0xFFFFFFF0u, 0x00020000);
+        const int pl = lane >> 4, cq = (lane & 15) * 4;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int t = wave * 16 + i;
+            const int pmv = s_pitch[t], rw = s_row[t];
+            const int pitch = pmv >> 4;
+            const int poff = pl == 0 ? 0 : pl == 1 ? 1 : pl == 2 ? pitch : pitch + 1;
+            const bool live = ((pmv >> pl) & 1) && c0 + cq < a.Cout;
+            const int off = live ? (int)(unsigned)((((long long)rw + poff) * a.y_ld + c0 + cq) * 4) : -1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (__attribute__((address_space(3))) void*)(smem + t * 256), 16, off, 0, 0, 0);
+        }
+        VPHO_SYNC_LDS_DMA();
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         if (e == 4) fetch_records(8);
@@ -436,8 +457,8 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
             const float o[4] = {y00 + bias, y01 + bias, y10 + bias, y11 + bias};
             const long long offs[4] = {0, (long long)a.y_ld, (long long)pitch * a.y_ld, (long long)(pitch + 1) * a.y_ld};
             const float* gp = a.gate ? a.gate + (long long)row_e[e] * a.y_ld + co : nullptr;
-            const float* xp = nullptr;
-            if constexpr (BN == 2) xp = a.bn_x + (long long)row_e[e] * a.y_ld + co;
+            const float* xp = nullptr;                               // BN == 2: this lane's channel of the tile's four pixels, in LDS
+            if constexpr (BN == 2) xp = smem + (wt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 256 + wc * 32 + li;
 #pragma unroll
             for (int p = 0; p < 4; ++p) if ((pm >> p) & 1) {
                 float v = o[p];
@@ -445,7 +466,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
                 if ((WINO_ABLATE & 512) && v != 1.2345e-30f) continue;          // timing: the output transform without its stores
                 if constexpr (BN == 2) {
                     // gate recomputed from the BatchNorm input: the forward pass's own expression (bn_apply_kernel), hence its sign
-                    const float xh = (xp[offs[p]] - bn_m) * bn_i;
+                    const float xh = (xp[p * W_CB] - bn_m) * bn_i;
                     const float t = xh * bn_g + bn_b;
                     v = t > 0.f ? v : v * a.gate_slope;
                     st0 += v; st1 += v * xh;
@@ -466,11 +487,12 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a_) {
         // lanes li / li + 32 hold the two row halves of a channel, the waves wt = 0 / 1 the two tile halves: one partial row per tile
         // block, [tb][2][Cout], combined in a fixed order (the stage buffers are free: every wave has passed the last stage's barrier)
         st0 += __shfl_xor(st0, 32); st1 += __shfl_xor(st1, 32);
-        if (lh == 0) { smem[(wt * 2 + 0) * W_CB + wc * 32 + li] = st0; smem[(wt * 2 + 1) * W_CB + wc * 32 + li] = st1; }
+        float* S = smem + BNX_FLOATS;                                // (behind the BatchNorm-input tile other waves may still be reading)
+        if (lh == 0) { S[(wt * 2 + 0) * W_CB + wc * 32 + li] = st0; S[(wt * 2 + 1) * W_CB + wc * 32 + li] = st1; }
         __syncthreads();
         if (tid < 2 * W_CB) {
             const int pl = tid / W_CB, c = tid - pl * W_CB;
-            a.stats[((long long)tb * 2 + pl) * a.Cout + c0 + c] = smem[pl * W_CB + c] + smem[(2 + pl) * W_CB + c];
+            a.stats[((long long)tb * 2 + pl) * a.Cout + c0 + c] = S[pl * W_CB + c] + S[(2 + pl) * W_CB + c];
         }
     }
     VPHO_STAMP_AT(4);
@@ -879,6 +901,8 @@ static int wino_launch(const float* x, const float* u, const float* bias, int N,
                          "vpho_conv3x3_winograd_stats_nhwc_f32: full maps, one group, no stored gate");
             VPHO_REQUIRE(tbs <= bn->cap, "vpho_conv3x3_winograd_stats_nhwc_f32: %d partial rows exceed stats_cap %d", tbs, bn->cap);
             VPHO_REQUIRE(!bn->x || (bn->mean && bn->invstd && bn->gamma && bn->beta), "vpho_conv3x3_winograd_stats_nhwc_f32: bn_x needs the four BatchNorm vectors");
+            VPHO_REQUIRE(!bn->x || (((uintptr_t)bn->x & 15) == 0 && y_ld % 4 == 0 && 4.0 * N * H * W * y_ld < 3.9e9),
+                         "vpho_conv3x3_winograd_stats_nhwc_f32: bn_x must be 16-byte aligned, y_ld %% 4 == 0, below 3.9 GB (it is fetched by 16-byte LDS-DMA)");
             a.stats = bn->stats; a.bn_x = bn->x; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
             *bn->rows = tbs;
             const bool st1 = staged && wino_staged_ok(a.TH, a.TW, W);
