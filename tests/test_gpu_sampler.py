@@ -56,6 +56,33 @@ def test_register_ring_pose_encoder_is_bit_identical_to_the_lds_ring_kernel(nets
 
 
 @pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
+def test_64_row_pose_encoder_is_bit_identical_to_the_32_row_kernel(nets, name, D):
+    """round 6: pose_encoder_reg64_kernel (64 hypotheses per workgroup: every weight fragment feeds two matrix instructions; the default from
+    16 384 rows on, VPHO_PE_ROWS=64 / 32 forces either): same k order per output, so scores and a whole ODE solve are bit-identical; ragged last
+    block (6 387 = 99 x 64 + 51 rows), a launch at the switch-over size, and the stage-state prologue in controller mode"""
+    import os
+    bs, S = 3, 2129
+    feat, x = seeded((bs, 1024), 60, 0.3).cuda(), seeded((bs * S, D), 61, 1.5).cuda()
+    init = seeded((8 * 50, D), 62, 20.0).cuda()
+    feat8 = seeded((8, 1024), 63, 0.3).cuda()
+    featb, xb = seeded((64, 1024), 64, 0.3).cuda(), seeded((64 * 256, D), 65, 1.5).cuda()      # 16 384 rows: the 64-row kernel by default
+    res = {}
+    for rows in ('32', '64'):
+        os.environ['VPHO_PE_ROWS'] = rows
+        try:
+            sc = nets[name].score(feat, x, 0.3, S).clone()
+            scb = nets[name].score(featb, xb, 0.3, 256).clone()
+            xs, xf, st = nets[name].sample(feat8, init, 50, 0.65, 12, xs_f64=True)
+            res[rows] = (sc, xs.clone(), xf.clone(), st['nfev'], scb)
+        finally:
+            os.environ.pop('VPHO_PE_ROWS', None)
+    assert torch.isfinite(res['64'][0]).all() and float(res['64'][0].abs().max()) > 0
+    assert torch.equal(res['32'][0], res['64'][0]) and torch.equal(res['32'][4], res['64'][4])
+    assert res['32'][3] == res['64'][3] and torch.equal(res['32'][1], res['64'][1]) and torch.equal(res['32'][2], res['64'][2])
+    assert torch.equal(nets[name].score(featb, xb, 0.3, 256), res['32'][4])                       # the default choice at 16 384 rows
+
+
+@pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
 @pytest.mark.parametrize('bs,S', [(64, 100), (5, 64), (3, 2129), (2, 600), (7, 40)])
 def test_persistent_score_head_is_bit_identical_to_the_one_tile_kernels(nets, name, D, bs, S):
     """round 5: (a) the epilogue's per-image terms (cimg) come from an LDS copy of the <= 3 images a 128-row tile spans (sample_num >= 64)

@@ -57,6 +57,7 @@ def test_no_kernel_spills_vector_registers_unannounced(kernels):
 BUDGET = {
     'score_head_kernel<true>': (4, 128), 'score_head_kernel<false>': (4, 128),      # two 512-thread workgroups per CU (57 KB of LDS each)
     'pose_encoder_reg_kernel<1>': (4, 128), 'pose_encoder_reg_kernel<3>': (4, 128), 'pose_encoder_reg_kernel<4>': (4, 128),
+    'pose_encoder_reg64_kernel<1>': (4, 128), 'pose_encoder_reg64_kernel<3>': (4, 128), 'pose_encoder_reg64_kernel<4>': (4, 128),
     'conv_igemm_glds_kernel<128, 128, 4, 2, false>': (4, 128), 'conv_igemm_glds_kernel<128, 64, 4, 2, false>': (4, 128),
     'conv_igemm_glds_kernel<64, 64, 2, 2, false>': (4, 128),
     # the persistent tile walk sizes its grid as 2 workgroups per CU (<= 128 registers, 73 KB of LDS): a compiler change that drops

@@ -288,15 +288,19 @@ __global__ __launch_bounds__(512) void pose_encoder_kernel(const PoseEncArgs a) 
 // A operand (stage state X, then -- aliased, the state is dead by then -- the 32 x 256 intermediate) and the biases: 35 KB, three
 // workgroup barriers instead of twelve, <= 128 registers: the footprint of ONE direct-convolution workgroup, so it takes the next
 // free slot of any CU instead of a whole CU.
-template <int N1>
-__global__ __launch_bounds__(512, 4) void pose_encoder_reg_kernel(const PoseEncArgs a) {
+// RT = row tiles of 32 hypotheses per workgroup.  RT = 1: the kernel as described above.  RT = 2 (round 6, launches of >= 16 384 rows --
+// BASELINE cfg4's 32 768): a workgroup streams the same 352 KB of weights for 64 rows instead of 32 -- every B fragment feeds two matrix
+// instructions, half the L2 -> register weight traffic per row -- with the A fragments read one 8-k slice ahead instead of a whole chunk
+// ahead (16 registers for two tiles); 68 KB of LDS.  Same k order per output element: bit-identical to RT = 1.
+template <int N1, int RT>
+__device__ __forceinline__ void pe_reg_body(const PoseEncArgs& a) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
-    constexpr int K1 = N1 * 32, X_LD = K1 + 4, NCH = N1 + 8;
-    float* H1 = smem;                              // [32][PE_H_LD]   (layer 2's A operand)
-    float* Xs = smem;                              // [32][X_LD]      (layer 1's A operand; dead before H1 is written)
-    float* Bs = smem + PE_ROWS * PE_H_LD;          // [2][256] biases
+    constexpr int K1 = N1 * 32, X_LD = K1 + 4, NCH = N1 + 8, ROWS = PE_ROWS * RT;
+    float* H1 = smem;                              // [ROWS][PE_H_LD]   (layer 2's A operand)
+    float* Xs = smem;                              // [ROWS][X_LD]      (layer 1's A operand; dead before H1 is written)
+    float* Bs = smem + ROWS * PE_H_LD;             // [2][256] biases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int r0 = blockIdx.x * PE_ROWS;
+    const int r0 = blockIdx.x * ROWS;
     if (ctl_skip(a.ctl, a.ctl_mode)) return;
     KSlots ks = a.ks;
     const double* yv = a.y;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(512, 4) void pose_encoder_reg_kernel(const PoseEncA
     __builtin_amdgcn_sched_barrier(0);       // the first three weight chunks are out and stay in flight (L2 hits) while the stage state is formed
 
     Bs[tid] = tid < 256 ? a.b0[tid] : a.b2[tid - 256];
-    for (int i = tid; i < PE_ROWS * (K1 / 4); i += 512) {
+    for (int i = tid; i < ROWS * (K1 / 4); i += 512) {
         const int r = i / (K1 / 4), c = (i - r * (K1 / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r0 + r < a.R && c < a.Dp) {
@@ -377,62 +381,102 @@ __global__ __launch_bounds__(512, 4) void pose_encoder_reg_kernel(const PoseEncA
     }
     __syncthreads();
 
-    f32x16 acc;
+    f32x16 acc[RT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    struct AFrag { f32x4 a[4]; };
-    auto aload = [&](int c, AFrag& f) {
-        const float* As = c < N1 ? Xs + li * X_LD + c * 32 + 4 * lh : H1 + li * PE_H_LD + (c - N1) * 32 + 4 * lh;
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) f.a[kk] = *reinterpret_cast<const f32x4*>(As + kk * 8);
-    };
-    auto mfmas = [&](const AFrag& f, const WFrag& w) {
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // layer boundary: every wave's last reads of Xs are consumed (their products have issued) before H1 = relu(acc + b0) is written over
+    // it, and H1 is complete in every wave before anyone reads it as the next A operand
+    auto boundary = [&]() {
+        __syncthreads();
+        const int col = wave * 32 + li;
+        const float bv = Bs[col];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk][q], w.b[kk][q], acc, 0, 0, 0);
-    };
-    AFrag fa[2];
-    aload(0, fa[0]);
-    // the sched_barriers pin the order "next A fragments, this chunk's 16 MFMAs, the weight loads of chunk c + 3": left to itself the
-    // scheduler sinks every weight load to just in front of its use (shorter live ranges under the 128-register cap): 4 MFMAs of cover
-    // for an L2 round trip instead of 2 chunks
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH && c + 1 != N1) aload(c + 1, fa[(c + 1) & 1]);       // next chunk's A fragments while this chunk multiplies
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa[c & 1], wr[c % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 3 < NCH) wload(c + 3, wr[c % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 == N1) {
-            // layer boundary: every wave's last reads of Xs are consumed (their products have issued) before H1 = relu(acc + b0) is
-            // written over it, and H1 is complete in every wave before anyone reads it as the next A operand
-            __syncthreads();
-            const int col = wave * 32 + li;
-            const float bv = Bs[col];
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float v = acc[e] + bv;
+                const int row = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = acc[t][e] + bv;
                 H1[row * PE_H_LD + col] = v > 0.f ? v : 0.f;
-                acc[e] = 0.f;
+                acc[t][e] = 0.f;
             }
-            __syncthreads();
-            aload(N1, fa[N1 & 1]);
+        __syncthreads();
+    };
+    if constexpr (RT == 1) {
+        struct AFrag { f32x4 a[4]; };
+        auto aload = [&](int c, AFrag& f) {
+            const float* As = c < N1 ? Xs + li * X_LD + c * 32 + 4 * lh : H1 + li * PE_H_LD + (c - N1) * 32 + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) f.a[kk] = *reinterpret_cast<const f32x4*>(As + kk * 8);
+        };
+        auto mfmas = [&](const AFrag& f, const WFrag& w) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk][q], w.b[kk][q], acc[0], 0, 0, 0);
+        };
+        AFrag fa[2];
+        aload(0, fa[0]);
+        // the sched_barriers pin the order "next A fragments, this chunk's 16 MFMAs, the weight loads of chunk c + 3": left to itself the
+        // scheduler sinks every weight load to just in front of its use (shorter live ranges under the 128-register cap): 4 MFMAs of cover
+        // for an L2 round trip instead of 2 chunks
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH && c + 1 != N1) aload(c + 1, fa[(c + 1) & 1]);       // next chunk's A fragments while this chunk multiplies
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[c & 1], wr[c % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 3 < NCH) wload(c + 3, wr[c % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 == N1) { boundary(); aload(N1, fa[N1 & 1]); }
+        }
+    } else {
+        // two row tiles: the A fragments of one 8-k slice (2 x 16 bytes) are read one slice ahead of the 8 matrix instructions that use them
+        auto aslice = [&](int c, int kk, f32x4 (&f)[RT]) {
+            const float* As = c < N1 ? Xs + li * X_LD + c * 32 + 4 * lh + kk * 8 : H1 + li * PE_H_LD + (c - N1) * 32 + 4 * lh + kk * 8;
+            const int ld = c < N1 ? X_LD : PE_H_LD;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) f[t] = *reinterpret_cast<const f32x4*>(As + 32 * t * ld);
+        };
+        f32x4 fa[2][RT];
+        aslice(0, 0, fa[0]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int s = (c * 4 + kk) & 1;
+                if (kk < 3) aslice(c, kk + 1, fa[s ^ 1]);
+                else if (c + 1 < NCH && c + 1 != N1) aslice(c + 1, 0, fa[s ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][t][q], wr[c % 3].b[kk][q], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c + 3 < NCH) wload(c + 3, wr[c % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 == N1) { boundary(); aslice(N1, 0, fa[(N1 * 4) & 1]); }
         }
     }
     const int col = wave * 32 + li;
     const float bv = Bs[256 + col];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row < a.R) {
-            const float v = acc[e] + bv;
-            a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = r0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row < a.R) {
+                const float v = acc[t][e] + bv;
+                a.out[(long long)row * 256 + col] = v > 0.f ? v : 0.f;
+            }
         }
-    }
 }
+template <int N1>
+__global__ __launch_bounds__(512, 4) void pose_encoder_reg_kernel(const PoseEncArgs a) { pe_reg_body<N1, 1>(a); }
+template <int N1>
+__global__ __launch_bounds__(512, 4) void pose_encoder_reg64_kernel(const PoseEncArgs a) { pe_reg_body<N1, 2>(a); }
 
 // --------------------------------------------------------------------------------------------- fused score head
 struct HeadArgs {
@@ -1494,6 +1538,22 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         } else {
             const size_t pe_lds = (size_t)(PE_ROWS * PE_H_LD + 512) * sizeof(float);            // 35 328 B
             VPHO_REQUIRE(K1 <= 128 && (pa.Dp & 3) == 0, "pose encoder: input dimension %d (padded %d) not supported (<= 128, multiple of 4)", c.w->D, pa.Dp);
+            // 64-row workgroups from 16 384 rows on (256 workgroups = one per CU at least; BASELINE cfg4: 32 768 rows); VPHO_PE_ROWS=32 / 64 forces
+            // either (A/B aid, read per call; the two are bit-identical)
+            const char* rows_env = getenv("VPHO_PE_ROWS");
+            const bool rows64 = rows_env ? atoi(rows_env) == 64 : c.R >= 16384;
+            if (rows64) {
+                const size_t lds64 = (size_t)(2 * PE_ROWS * PE_H_LD + 512) * sizeof(float);          // 68 608 B
+                const dim3 grid64((unsigned)((c.R + 2 * PE_ROWS - 1) / (2 * PE_ROWS)));
+                VPHO_DYN_LDS(pose_encoder_reg64_kernel<1>, lds64); VPHO_DYN_LDS(pose_encoder_reg64_kernel<2>, lds64);
+                VPHO_DYN_LDS(pose_encoder_reg64_kernel<3>, lds64); VPHO_DYN_LDS(pose_encoder_reg64_kernel<4>, lds64);
+                switch (K1 / 32) {
+                    case 1: hipLaunchKernelGGL(pose_encoder_reg64_kernel<1>, grid64, dim3(512), lds64, c.s, pa); break;
+                    case 2: hipLaunchKernelGGL(pose_encoder_reg64_kernel<2>, grid64, dim3(512), lds64, c.s, pa); break;
+                    case 3: hipLaunchKernelGGL(pose_encoder_reg64_kernel<3>, grid64, dim3(512), lds64, c.s, pa); break;
+                    default: hipLaunchKernelGGL(pose_encoder_reg64_kernel<4>, grid64, dim3(512), lds64, c.s, pa); break;
+                }
+            } else
             switch (K1 / 32) {
                 case 1: hipLaunchKernelGGL(pose_encoder_reg_kernel<1>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
                 case 2: hipLaunchKernelGGL(pose_encoder_reg_kernel<2>, pe_grid, dim3(512), pe_lds, c.s, pa); break;
