@@ -173,8 +173,9 @@ def conv2d_dgrad(dy, w_packed, in_hw, kh, kw, stride=1, pad=0, pad_y=None, pad_x
                                bn=bn if (gate is not None and bn is not None and bn.x is not None) else None)
     assert py == px == pad and res is None
     assert stride == 2 and H % 2 == 0 and W % 2 == 0, 'stride 1 or 2 (even input size)'
-    dx = torch.zeros((N, H, W, cin), device=dy.device, dtype=dy.dtype)
     phases = [(py, px) for py in (0, 1) for px in (0, 1) if _phase_taps(py, kh, pad) and _phase_taps(px, kw, pad)]
+    # all four parities have taps (3x3): every pixel of dx is written by its phase; fewer (1x1 / stride 2: one): the others stay zero
+    dx = (torch.empty if len(phases) == 4 else torch.zeros)((N, H, W, cin), device=dy.device, dtype=dy.dtype)
     fuse = gate is not None and bn is not None and bn.x is not None
     if fuse:
         bn.parts = len(phases)                              # every phase appends its partial sums (the pixels of the other parities stay zero: no terms)
