@@ -371,7 +371,10 @@ def main():
         if world == 1 and not args.no_opt_in and (score_mfma, conv_mfma) == ('f32', 'f32'):
             result['opt_in'] = {'split_bf16x6': secondary_leg(args, model, batches, E, post_rows, {'VPHO_SCORE_MFMA': 'bf16x6', 'VPHO_CONV_MFMA': 'bf16x6'},
                 'same step, same evaluator; fp32 products of the score head and of the direct convolutions as 6 exact bf16 products each '
-                '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`')}
+                '(--score_mfma bf16x6 --conv_mfma bf16x6), fp32 storage and accumulation; opt-in, not `value`'),
+                               # all nine cross products: every fp32 product exact (nothing dropped), fp32 accumulation -- VERDICT r5 item 10: reported beside x6
+                               'split_bf16x9': secondary_leg(args, model, batches, E, post_rows, {'VPHO_SCORE_MFMA': 'bf16x9', 'VPHO_CONV_MFMA': 'bf16x9'},
+                'same step with all nine bf16 products per fp32 product (--score_mfma bf16x9 --conv_mfma bf16x9): no term dropped; opt-in, not `value`')}
         if world == 1 and not args.no_opt_in and eng.roi_window and not args.no_roi_window:
             # the RoI-window saving is data dependent (boxes that span the crop lose it): the same step with the full stride-4 maps
             result['value_full_maps'] = secondary_leg(args, model, batches, E, post_rows, {'VPHO_ROI_WINDOW': '0'},
@@ -478,6 +481,7 @@ def compact_line(full):
         }
     line['value_full_maps'] = g(full, 'value_full_maps', 'value')
     line['opt_in_split_bf16x6_value'] = g(full, 'opt_in', 'split_bf16x6', 'value')
+    line['opt_in_split_bf16x9_value'] = g(full, 'opt_in', 'split_bf16x9', 'value')
     line['step_ms_min_median_max'] = full.get('step_ms_min_median_max')
     line['host_busy_threads'] = g(full, 'host_cpu', 'busy_threads_equivalent')
     line['metrics_rows_gathered'] = full.get('metrics_rows_gathered')
