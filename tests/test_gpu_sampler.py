@@ -57,8 +57,8 @@ def test_register_ring_pose_encoder_is_bit_identical_to_the_lds_ring_kernel(nets
 
 @pytest.mark.parametrize('name,D', [('hand', 96), ('obj', 9)])
 def test_64_row_pose_encoder_is_bit_identical_to_the_32_row_kernel(nets, name, D):
-    """round 6: pose_encoder_reg64_kernel (64 hypotheses per workgroup: every weight fragment feeds two matrix instructions; the default from
-    16 384 rows on, VPHO_PE_ROWS=64 / 32 forces either): same k order per output, so scores and a whole ODE solve are bit-identical; ragged last
+    """round 6: pose_encoder_reg64_kernel (64 hypotheses per workgroup: every weight fragment feeds two matrix instructions; the default above
+    8 192 rows, VPHO_PE_ROWS=64 / 32 forces either): same k order per output, so scores and a whole ODE solve are bit-identical; ragged last
     block (6 387 = 99 x 64 + 51 rows), a launch at the switch-over size, and the stage-state prologue in controller mode"""
     import os
     bs, S = 3, 2129

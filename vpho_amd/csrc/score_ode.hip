@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void pose_encoder_kernel(const PoseEncArgs a) 
 // A operand (stage state X, then -- aliased, the state is dead by then -- the 32 x 256 intermediate) and the biases: 35 KB, three
 // workgroup barriers instead of twelve, <= 128 registers: the footprint of ONE direct-convolution workgroup, so it takes the next
 // free slot of any CU instead of a whole CU.
-// RT = row tiles of 32 hypotheses per workgroup.  RT = 1: the kernel as described above.  RT = 2 (round 6, launches of >= 16 384 rows --
+// RT = row tiles of 32 hypotheses per workgroup.  RT = 1: the kernel as described above.  RT = 2 (round 6, launches of more than 8 192 rows --
 // BASELINE cfg4's 32 768): a workgroup streams the same 352 KB of weights for 64 rows instead of 32 -- every B fragment feeds two matrix
 // instructions, half the L2 -> register weight traffic per row -- with the A fragments read one 8-k slice ahead instead of a whole chunk
 // ahead (16 registers for two tiles); 68 KB of LDS.  Same k order per output element: bit-identical to RT = 1.
@@ -1538,10 +1538,12 @@ int eval_net(Ctx& c, const float* X, float t, int rhs_mode, float coef, float* o
         } else {
             const size_t pe_lds = (size_t)(PE_ROWS * PE_H_LD + 512) * sizeof(float);            // 35 328 B
             VPHO_REQUIRE(K1 <= 128 && (pa.Dp & 3) == 0, "pose encoder: input dimension %d (padded %d) not supported (<= 128, multiple of 4)", c.w->D, pa.Dp);
-            // 64-row workgroups from 16 384 rows on (256 workgroups = one per CU at least; BASELINE cfg4: 32 768 rows); VPHO_PE_ROWS=32 / 64 forces
-            // either (A/B aid, read per call; the two are bit-identical)
+            // 64-row workgroups above 8 192 rows, i.e. as soon as 32-row workgroups would be more than one per CU (measured, isolated launches, hand /
+            // object network: 12 800 rows 35.4 / 33.1 -> 30.4 / 27.9 us, 16 384 rows 35.8 / 32.6 -> 30.7 / 26.8, 32 768 rows -- BASELINE cfg4 -- 67.7 / 58.7 ->
+            // 57.8 / 47.8; at the README config's 6 400 rows the 32-row kernel wins, 18.7 against 28.9: 200 workgroups against 100 on 256 CUs).
+            // VPHO_PE_ROWS=32 / 64 forces either (A/B aid, read per call; the two are bit-identical)
             const char* rows_env = getenv("VPHO_PE_ROWS");
-            const bool rows64 = rows_env ? atoi(rows_env) == 64 : c.R >= 16384;
+            const bool rows64 = rows_env ? atoi(rows_env) == 64 : c.R > 8192;
             if (rows64) {
                 const size_t lds64 = (size_t)(2 * PE_ROWS * PE_H_LD + 512) * sizeof(float);          // 68 608 B
                 const dim3 grid64((unsigned)((c.R + 2 * PE_ROWS - 1) / (2 * PE_ROWS)));
